@@ -1,0 +1,449 @@
+/*
+ * halart.h — C ABI of libhalart.so, the MI355X-native replacement for the hot path of
+ * hala-renderer's ray-tracing renderer (reference: src/rt_renderer.rs, src/raytracing_program.rs,
+ * src/envmap.rs, src/scene/loader/gpu_uploader.rs).
+ *
+ * The reference has no FFI boundary of its own: its "operator API" is the public Rust surface
+ * `HalaRenderer` / `HalaRayTracingProgram` / `cpu::HalaScene`.  Every export below is what an
+ * `extern "C"` Rust shim with those names would bind to; the reference item each entry point
+ * replaces is cited as file:line (relative to the reference checkout).
+ *
+ * Conventions (reference: src/error.rs:5-22 — every fallible method returns Result<_, HalaRendererError>):
+ *   - every fallible function returns an int status: 0 = Ok, non-zero = Err; the message of the last
+ *     error on the calling thread is returned by hala_last_error_message() (== HalaRendererError::message()).
+ *   - nothing aborts or throws across the boundary.
+ *   - one handle <-> one host thread <-> one GPU (the reference is !Send/!Sync: src/renderer.rs:44).
+ *   - all pointers are plain host pointers unless the name says `_device`/`d_` (then a HIP device pointer).
+ *   - the library REQUIRES a HIP device: there is no CPU execution path in it.
+ */
+#ifndef HALART_H
+#define HALART_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HALA_OK 0
+#define HALA_ERR 1
+
+#define HALA_INVALID_INDEX 0xffffffffu /* u32::MAX "none" marker (src/scene/cpu/node.rs:23-25) */
+#define HALA_MAX_CAMERA_COUNT 8        /* src/scene/loader/gpu_uploader.rs:39 */
+#define HALA_MAX_LIGHT_COUNT 32        /* src/scene/loader/gpu_uploader.rs:40 */
+
+/* ------------------------------------------------------------------------------------------------
+ * Byte-exact device records (what the reference's shaders read).  Sizes/offsets are static_asserted
+ * in hala-renderer_amd/csrc/hala_types.h and checked from Python in tests/test_layouts.py.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* src/scene/vertex.rs:2-9 — 44 B */
+typedef struct hala_vertex {
+  float position[3];
+  float normal[3];
+  float tangent[3];
+  float tex_coord[2];
+} hala_vertex;
+
+/* src/scene/gpu/camera.rs:10-20 — 80 B, align 16 */
+typedef struct hala_gpu_camera {
+  float position[3]; float _pad0;
+  float right[3];    float _pad1;
+  float up[3];       float _pad2;
+  float forward[3];
+  float yfov;
+  float focal_distance_or_xmag;
+  float aperture_or_ymag;
+  uint32_t type; /* 0 perspective, 1 orthographic */
+  uint32_t _pad3;
+} hala_gpu_camera;
+
+/* src/scene/gpu/light.rs:7-32 — 80 B, align 16 */
+typedef struct hala_gpu_light {
+  float intensity[3]; float _pad0;
+  float position[3];  float _pad1;
+  float u[3];         float _pad2;
+  float v[3];
+  float radius;
+  float area;
+  uint32_t type; /* 0 point, 1 directional, 2 spot, 3 quad, 4 sphere (src/scene/cpu/light.rs:7-12) */
+  uint32_t _pad3[2];
+} hala_gpu_light;
+
+/* light AABB, `HalaAABB` of the absent hala-gfx crate: fields min/max per gpu_uploader.rs:169-180 — 24 B */
+typedef struct hala_aabb {
+  float min[3];
+  float max[3];
+} hala_aabb;
+
+/* src/scene/gpu/material.rs:6-48 — 144 B, align 16 */
+typedef struct hala_gpu_material {
+  /* HalaMedium, 32 B */
+  float medium_color[3];
+  float medium_density;
+  float medium_anisotropy;
+  uint32_t medium_type;
+  float _medium_padding[2];
+
+  float base_color[3];
+  float opacity;
+  float emission[3];
+  float anisotropic;
+  float metallic;
+  float roughness;
+  float subsurface;
+  float specular_tint;
+  float sheen;
+  float sheen_tint;
+  float clearcoat;
+  float clearcoat_roughness;
+  float clearcoat_tint[3];
+  float specular_transmission;
+  float ior;
+  float ax;
+  float ay;
+  uint32_t base_color_map_index;
+  uint32_t normal_map_index;
+  uint32_t metallic_roughness_map_index;
+  uint32_t emission_map_index;
+  uint32_t type; /* 0 diffuse, 1 disney (src/scene/cpu/material.rs:7-9) */
+} hala_gpu_material;
+
+/* src/scene/gpu/mesh.rs:32-39 — 96 B (glam::Mat4 is 16-aligned) */
+typedef struct hala_gpu_mesh_data {
+  float transform[16]; /* column-major object->world */
+  uint32_t material_index;
+  uint32_t _pad0;
+  uint64_t vertices; /* device address of this primitive's hala_vertex[] */
+  uint64_t indices;  /* device address of this primitive's uint32_t[]    */
+  uint64_t _pad1;
+} hala_gpu_mesh_data;
+
+/* src/rt_renderer.rs:44-65 — 112 B, filled per frame at :408-427 */
+typedef struct hala_global_uniform {
+  float ground_color[4];
+  float sky_color[4];
+  float resolution[2];
+  uint32_t max_depth;
+  uint32_t rr_depth;
+  uint32_t frame_index;
+  uint32_t camera_index;
+  uint32_t env_type; /* 0 SKY, 1 MAP (src/rt_renderer.rs:24-28) */
+  uint32_t env_map_width;
+  uint32_t env_map_height;
+  float env_total_sum;
+  float env_rotation; /* degrees / 360 (src/rt_renderer.rs:420) */
+  float env_intensity;
+  float exposure_value;
+  uint32_t enable_tonemap;
+  uint32_t enable_aces;
+  uint32_t use_simple_aces;
+  uint32_t num_of_lights;
+  uint32_t _pad[3];
+} hala_global_uniform;
+
+/* ------------------------------------------------------------------------------------------------
+ * Borrowed view of cpu::HalaScene (src/scene/cpu/scene.rs:17-26).  The renderer copies what it
+ * needs during hala_rt_set_scene; the caller keeps ownership (as with `&mut cpu::HalaScene`).
+ * ---------------------------------------------------------------------------------------------- */
+
+/* src/scene/cpu/node.rs:2-12.  world transforms are recomputed by the library exactly as
+ * update_node_hierarchies does (src/scene/cpu/scene.rs:99-114): parents must precede children. */
+typedef struct hala_node_desc {
+  const char* name;
+  int32_t parent;            /* -1 == None */
+  float local_transform[16]; /* column-major glam::Mat4 */
+  uint32_t mesh_index;       /* HALA_INVALID_INDEX == none */
+  uint32_t camera_index;
+  uint32_t light_index;
+} hala_node_desc;
+
+/* src/scene/cpu/mesh.rs:6-13 (meshlet fields are rasterizer-only and omitted) */
+typedef struct hala_primitive_desc {
+  const uint32_t* indices;
+  uint32_t index_count;
+  const hala_vertex* vertices;
+  uint32_t vertex_count;
+  uint32_t material_index;
+} hala_primitive_desc;
+
+typedef struct hala_mesh_desc {
+  const hala_primitive_desc* primitives;
+  uint32_t primitive_count;
+} hala_mesh_desc;
+
+/* src/scene/cpu/material.rs:24-50, :75-80 */
+typedef struct hala_material_desc {
+  uint32_t type; /* 0 DIFFUSE, 1 DISNEY; anything else is an error (from_u8 panics in the reference) */
+  float base_color[3];
+  float opacity;
+  float emission[3];
+  float anisotropic;
+  float metallic;
+  float roughness;
+  float subsurface;
+  float specular_tint;
+  float sheen;
+  float sheen_tint;
+  float clearcoat;
+  float clearcoat_roughness;
+  float clearcoat_tint[3];
+  float specular_transmission;
+  float ior;
+  uint32_t medium_type; /* 0 NONE, 1 ABSORB, 2 SCATTER, 3 EMISSIVE */
+  float medium_color[3];
+  float medium_density;
+  float medium_anisotropy;
+  uint32_t base_color_map_index;
+  uint32_t emission_map_index;
+  uint32_t normal_map_index;
+  uint32_t metallic_roughness_map_index;
+} hala_material_desc;
+
+/* src/scene/cpu/light.rs:30-39 */
+typedef struct hala_light_desc {
+  float color[3];
+  float intensity;
+  uint32_t light_type; /* 0..4 */
+  float param0;
+  float param1;
+} hala_light_desc;
+
+/* src/scene/cpu/camera.rs:4-29 */
+typedef struct hala_camera_desc {
+  uint32_t type; /* 0 perspective, 1 orthographic */
+  float aspect;
+  float yfov;
+  float znear;
+  float zfar;
+  float focal_distance;
+  float aperture;
+  float xmag;
+  float ymag;
+} hala_camera_desc;
+
+/* src/scene/cpu/image_data.rs:14-20; format codes are this library's own small enum */
+#define HALA_FORMAT_R8G8B8A8_UNORM 0
+#define HALA_FORMAT_R8G8B8A8_SRGB 1
+#define HALA_FORMAT_R32G32B32A32_SFLOAT 2
+typedef struct hala_image_desc {
+  uint32_t format;
+  uint32_t width;
+  uint32_t height;
+  const void* data;
+  size_t num_of_bytes;
+} hala_image_desc;
+
+typedef struct hala_index_pair {
+  uint32_t key;
+  uint32_t value;
+} hala_index_pair;
+
+typedef struct hala_scene_desc {
+  const hala_node_desc* nodes;         uint32_t node_count;
+  const hala_mesh_desc* meshes;        uint32_t mesh_count;
+  const hala_material_desc* materials; uint32_t material_count;
+  const hala_light_desc* lights;       uint32_t light_count;
+  const hala_camera_desc* cameras;     uint32_t camera_count;
+  const hala_index_pair* texture2image_mapping; uint32_t texture_count; /* BTreeMap<u32,u32>, ascending key */
+  const hala_index_pair* image2data_mapping;    uint32_t image_count;
+  const hala_image_desc* image_data;   uint32_t image_data_count;
+} hala_scene_desc;
+
+/* ------------------------------------------------------------------------------------------------
+ * Errors
+ * ---------------------------------------------------------------------------------------------- */
+/* HalaRendererError::message() (src/error.rs:23) of the last failed call on this thread. */
+const char* hala_last_error_message(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * HalaRenderer (src/rt_renderer.rs:568-1353, trait src/renderer.rs:210-324)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct hala_rt_renderer hala_rt_renderer;
+
+/* HalaRenderer::new (src/rt_renderer.rs:650-813).  Headless: width/height replace gpu_req.{width,height}
+ * (:661-662), device_ordinal replaces the winit window/swapchain.  max_frames == 0 => u64::MAX (:774). */
+int hala_rt_create(const char* name, uint32_t width, uint32_t height, int device_ordinal,
+                   uint32_t max_depth, uint32_t rr_depth, int enable_tonemap, int enable_aces,
+                   int use_simple_aces, uint64_t max_frames, hala_rt_renderer** out);
+/* Drop order of src/rt_renderer.rs:620-633: images, then everything else. */
+void hala_rt_destroy(hala_rt_renderer* r);
+
+/* push_general_shader{,_with_file} (src/rt_renderer.rs:925-995) and push_hit_shaders{,_with_file}
+ * (:1003-1112).  SPIR-V has no meaning for HIP kernels: the call is validated, recorded (so that
+ * commit can enforce "at least one raygen shader was pushed" like the reference pipeline would) and
+ * otherwise ignored.  stage: 0 raygen, 1 miss, 2 callable. */
+int hala_rt_push_general_shader(hala_rt_renderer* r, const void* code, size_t code_size, int stage,
+                                const char* debug_name);
+int hala_rt_push_general_shader_with_file(hala_rt_renderer* r, const char* file_path, int stage,
+                                          const char* debug_name);
+int hala_rt_push_hit_shaders(hala_rt_renderer* r, const void* closest_hit, size_t closest_hit_size,
+                             const void* any_hit, size_t any_hit_size, const void* intersection,
+                             size_t intersection_size, const char* debug_name);
+int hala_rt_push_hit_shaders_with_file(hala_rt_renderer* r, const char* closest_hit_path,
+                                       const char* any_hit_path, const char* intersection_path,
+                                       const char* debug_name);
+
+/* load_blue_noise_texture (src/rt_renderer.rs:1117-1156).  Optional here (mandatory at commit in the
+ * reference, :319): the built-in integrator draws its samples from a counter-based RNG. */
+int hala_rt_load_blue_noise_pixels(hala_rt_renderer* r, const uint8_t* rgba8, uint32_t width,
+                                   uint32_t height);
+
+/* set_scene (src/rt_renderer.rs:1161-1178) -> HalaSceneGPUUploader::upload(.., false, false, true)
+ * (src/scene/loader/gpu_uploader.rs:63-545, :774-967). */
+int hala_rt_set_scene(hala_rt_renderer* r, const hala_scene_desc* scene);
+
+/* set_envmap (src/rt_renderer.rs:1184-1195) -> EnvMap::new_with_file (src/envmap.rs:38-232).
+ * _pixels takes the already decoded image (RGB or RGBA f32, row 0 = top) and applies the same
+ * validation (NaN/Inf rejection :63-71), alpha := 1 repack (:72-89) and table build (:239-388);
+ * _file decodes Radiance .hdr (RGBE) or .pfm itself and honours ./out/<stem>.dist_cache (:90-142). */
+int hala_rt_set_envmap_pixels(hala_rt_renderer* r, const float* pixels, uint32_t channels,
+                              uint32_t width, uint32_t height, float rotation_degrees);
+int hala_rt_set_envmap_file(hala_rt_renderer* r, const char* path, float rotation_degrees);
+
+/* src/rt_renderer.rs:1199-1219 */
+void hala_rt_set_ground_color(hala_rt_renderer* r, const float rgba[4]);
+void hala_rt_set_sky_color(hala_rt_renderer* r, const float rgba[4]);
+void hala_rt_set_env_intensity(hala_rt_renderer* r, float intensity);
+void hala_rt_set_exposure_value(hala_rt_renderer* r, float exposure_value);
+
+/* commit (src/rt_renderer.rs:136-379): fails with "The scene in GPU is none!" without a scene (:138).
+ * Here it also flattens the instances to world space, builds the BVH on the GPU (the work the
+ * reference hands to vkCmdBuildAccelerationStructuresKHR: gpu_uploader.rs:784-811, :937-959) and
+ * allocates the wavefront queues. */
+int hala_rt_commit(hala_rt_renderer* r);
+
+/* update (src/rt_renderer.rs:387-471): pre_update bookkeeping (src/renderer.rs:266-281), the
+ * `total_frames > max_frames` early-out (:394-396), the HalaGlobalUniform fill (:408-427) and one
+ * trace_rays(width, height, 1) (:458-464) == one sample per pixel.  ui_fn is dropped. */
+int hala_rt_update(hala_rt_renderer* r, double delta_time, uint32_t width, uint32_t height);
+/* render (src/rt_renderer.rs:475-502): no swapchain to present to; flushes the stream. */
+int hala_rt_render(hala_rt_renderer* r);
+/* wait_idle (src/renderer.rs:251-256) */
+int hala_rt_wait_idle(hala_rt_renderer* r);
+
+/* save_images (src/rt_renderer.rs:1224-1352): <stem>_color.pfm (accum, tonemapped on the host exactly
+ * as :1256-1316), <stem>_albedo.pfm, <stem>_normal.pfm; PFM layout of :1318-1334. */
+int hala_rt_save_images(hala_rt_renderer* r, const char* path);
+
+/* Test/bench access to what save_images reads back (:1239-1254): which = 0 accum, 1 albedo, 2 normal
+ * (RGBA32F, 4*W*H floats, row 0 = top), 3 final (tonemapped RGBA32F the raygen stage writes, :688). */
+int hala_rt_read_image(hala_rt_renderer* r, int which, float* dst_rgba32f);
+
+/* info()/statistics() (src/renderer.rs:212-218, :135-207) */
+typedef struct hala_rt_info {
+  uint32_t width;
+  uint32_t height;
+} hala_rt_info;
+typedef struct hala_rt_statistics {
+  uint64_t total_frames;       /* HalaRendererStatistics::total_frames */
+  double last_gpu_ms;          /* GPU time of the last update (get_gpu_frame_time, renderer.rs:275) */
+  uint64_t rays_last_update;   /* closest-hit + shadow traversals launched by the last update */
+  uint64_t rays_total;
+  double traverse_ms_last_update; /* time inside the traversal kernels only */
+} hala_rt_statistics;
+int hala_rt_get_info(hala_rt_renderer* r, hala_rt_info* out);
+int hala_rt_get_statistics(hala_rt_renderer* r, hala_rt_statistics* out);
+/* the 112-B record the last update uploaded (src/rt_renderer.rs:408-427) */
+int hala_rt_get_global_uniform(hala_rt_renderer* r, hala_global_uniform* out);
+
+/* What upload() packed (gpu_uploader.rs:99-122 cameras, :148-303 lights + AABBs, :306-331 materials,
+ * :843-885 primitives/instances) — read back from the device for parity tests. Each call copies
+ * min(capacity, count) records and returns the count through *count. */
+int hala_rt_get_packed_cameras(hala_rt_renderer* r, hala_gpu_camera* dst, uint32_t capacity, uint32_t* count);
+int hala_rt_get_packed_lights(hala_rt_renderer* r, hala_gpu_light* dst, hala_aabb* dst_aabbs, uint32_t capacity, uint32_t* count);
+int hala_rt_get_packed_materials(hala_rt_renderer* r, hala_gpu_material* dst, uint32_t capacity, uint32_t* count);
+int hala_rt_get_packed_primitives(hala_rt_renderer* r, hala_gpu_mesh_data* dst, float* dst_instance_3x4, uint32_t capacity, uint32_t* count);
+/* env tables of set_envmap (src/envmap.rs:239-388): total_sum, marginal[H], conditional[W*H] */
+int hala_rt_get_env_distribution(hala_rt_renderer* r, float* total_sum, float* marginal, float* conditional);
+
+/* Multi-GPU pixel-tile sharding (no reference equivalent; BASELINE.json north_star).  The frame is cut
+ * into tile_size x tile_size tiles; tile t belongs to rank perm(t) % world (perm = fixed bijective
+ * scramble).  After this call update() renders only this rank's tiles into a tile-major buffer;
+ * hala_rt_tile_buffer gives its device address + byte size (per AOV) for the RCCL all-gather, and
+ * hala_rt_scatter_gathered_tiles de-interleaves the gathered [world][tiles_per_rank][ts][ts][4] buffer
+ * into the row-major images of this renderer. */
+int hala_rt_set_tile_shard(hala_rt_renderer* r, uint32_t rank, uint32_t world, uint32_t tile_size);
+int hala_rt_tile_buffer(hala_rt_renderer* r, int which, void** d_ptr, size_t* bytes);
+int hala_rt_scatter_gathered_tiles(hala_rt_renderer* r, int which, const void* d_gathered, size_t bytes);
+
+/* ------------------------------------------------------------------------------------------------
+ * The ray-batch operator under the renderer: what vkCmdTraceRaysKHR + the closest-hit stage do for
+ * one batch (src/rt_renderer.rs:458-464, src/raytracing_program.rs:330-340).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct hala_ray {
+  float origin[3];
+  float tmin;
+  float direction[3];
+  float tmax;
+} hala_ray; /* 32 B */
+
+typedef struct hala_hit {
+  float t;       /* < 0 => miss */
+  float u;
+  float v;
+  uint32_t prim; /* global triangle id (instance order, then triangle order); HALA_INVALID_INDEX on miss */
+} hala_hit; /* 16 B */
+
+/* mode 0: closest hit; mode 1: any hit (shadow): t = 1 if occluded else -1. Rays/hits are DEVICE
+ * pointers (coalesced 32-B / 16-B records). If d_counters != NULL (device, 2 x uint64) the kernel
+ * also adds the number of BVH nodes visited and triangles tested (for the algorithmic-bytes figure). */
+int hala_rt_trace_rays(hala_rt_renderer* r, const hala_ray* d_rays, hala_hit* d_hits, uint32_t count,
+                       int mode, uint64_t* d_counters, void* hip_stream);
+/* trace_rays_indirect (src/raytracing_program.rs:338-340): d_indirect points at a device-resident
+ * VkTraceRaysIndirectCommandKHR {uint32 width, height, depth}; width*height*depth rays are traced. */
+int hala_rt_trace_rays_indirect(hala_rt_renderer* r, const hala_ray* d_rays, hala_hit* d_hits,
+                                const uint32_t* d_indirect, int mode, void* hip_stream);
+/* Host-pointer convenience wrapper used by the tests (copies in/out around the same kernel). */
+int hala_rt_trace_rays_host(hala_rt_renderer* r, const hala_ray* rays, hala_hit* hits, uint32_t count,
+                            int mode, uint64_t counters[2]);
+
+/* BVH introspection for the oracle cross-check: 64-B nodes + 48-B triangles as laid out in HBM. */
+typedef struct hala_bvh_info {
+  uint32_t node_count;
+  uint32_t triangle_count;
+  uint32_t max_depth;
+  uint32_t lds_node_count; /* nodes staged in LDS by the traversal kernel */
+  float scene_min[3];
+  float scene_max[3];
+} hala_bvh_info;
+int hala_rt_get_bvh_info(hala_rt_renderer* r, hala_bvh_info* out);
+int hala_rt_download_bvh(hala_rt_renderer* r, void* nodes_64B, void* triangles_48B);
+/* Refit after vertex/transform edits (north_star "BVH build/refit"; the reference rebuilds only):
+ * re-flattens instances with the given node local transforms and refits AABBs bottom-up on the GPU. */
+int hala_rt_update_node_transform(hala_rt_renderer* r, uint32_t node_index, const float local_transform[16]);
+int hala_rt_refit(hala_rt_renderer* r);
+
+/* ------------------------------------------------------------------------------------------------
+ * Stand-alone pieces of the path (usable without a renderer)
+ * ---------------------------------------------------------------------------------------------- */
+/* EnvMap::build_distribution_maps (src/envmap.rs:239-388) on the GPU. pixels: RGBA32F host, W*H*4. */
+int hala_envmap_build_distribution(int device_ordinal, const float* rgba32f, uint32_t width,
+                                   uint32_t height, float* total_sum, float* marginal,
+                                   float* conditional);
+/* save_images' host tonemap (src/rt_renderer.rs:1256-1316) applied in place to RGBA32F pixels. */
+void hala_tonemap_pixels(float* rgba32f, size_t pixel_count, int enable_tonemap, int enable_aces,
+                         int use_simple_aces);
+/* save_images' PFM writer (src/rt_renderer.rs:1318-1334). */
+int hala_write_pfm(const char* path, const float* rgba32f, uint32_t width, uint32_t height);
+
+/* HalaRayTracingProgramDesc (src/raytracing_program.rs:25-55): parses the serde JSON field names and
+ * defaults; returns the parsed counts (used by the host mirror of HalaRayTracingProgram::new). */
+typedef struct hala_rtprog_desc_info {
+  uint32_t raygen_count;
+  uint32_t miss_count;
+  uint32_t hit_count;
+  uint32_t callable_count;
+  uint32_t push_constant_size;
+  uint32_t binding_count;
+  uint32_t ray_recursion_depth;
+} hala_rtprog_desc_info;
+int hala_rtprog_parse_desc(const char* desc_json, hala_rtprog_desc_info* out);
+
+const char* hala_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HALART_H */

@@ -1,0 +1,434 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see spec_math.h).
+// oracle_bvh.cpp — scene flattening (RENDER_SPEC §3), a CPU binned-SAH BVH2 builder (the oracle's own; the
+// product builds its BVH on the GPU and the two are compared through traversal RESULTS, never topology), the
+// traversal rule of RENDER_SPEC §4, a brute-force intersector and a structural validator for product BVHs.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+#include "oracle_api.h"
+#include "oracle_scene.h"
+
+using namespace orc;
+
+static constexpr uint32_t kAbsent = 0xffffffffu;
+
+// RENDER_SPEC §3: p' = (fma(m8,z, fma(m4,y, m0*x))) + m12  (column-major 4x4, affine)
+static inline V3 transform_point(const float* m, V3 p) {
+  return V3{fmaf(m[8], p.z, fmaf(m[4], p.y, m[0] * p.x)) + m[12], fmaf(m[9], p.z, fmaf(m[5], p.y, m[1] * p.x)) + m[13],
+            fmaf(m[10], p.z, fmaf(m[6], p.y, m[2] * p.x)) + m[14]};
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// builder
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+struct Box {
+  float mn[3], mx[3];
+  void reset() { for (int i = 0; i < 3; ++i) { mn[i] = std::numeric_limits<float>::infinity(); mx[i] = -mn[i]; } }
+  void grow(const float* p) { for (int i = 0; i < 3; ++i) { mn[i] = std::min(mn[i], p[i]); mx[i] = std::max(mx[i], p[i]); } }
+  void grow(const Box& b) { for (int i = 0; i < 3; ++i) { mn[i] = std::min(mn[i], b.mn[i]); mx[i] = std::max(mx[i], b.mx[i]); } }
+  float half_area() const {
+    float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+    if (dx < 0) return 0.0f;
+    return dx * dy + dy * dz + dz * dx;
+  }
+};
+struct BuildRef { Box box; float c[3]; uint32_t id; };
+struct ChildRef { uint32_t child, count; Box box; };
+
+struct Builder {
+  std::vector<BuildRef>& refs;
+  std::vector<Node>& nodes;
+  uint32_t max_leaf = 4;
+  Builder(std::vector<BuildRef>& r, std::vector<Node>& n) : refs(r), nodes(n) {}
+
+  ChildRef build(uint32_t first, uint32_t count) {
+    Box bounds, cb;
+    bounds.reset(); cb.reset();
+    for (uint32_t i = first; i < first + count; ++i) { bounds.grow(refs[i].box); cb.grow(refs[i].c); }
+    auto make_leaf = [&]() { return ChildRef{first, count, bounds}; };
+    if (count == 1) return make_leaf();
+    // binned SAH over 3 axes, 16 bins
+    const int NB = 16;
+    float best_cost = std::numeric_limits<float>::infinity();
+    int best_axis = -1, best_split = -1;
+    for (int axis = 0; axis < 3; ++axis) {
+      float lo = cb.mn[axis], hi = cb.mx[axis];
+      if (!(hi > lo)) continue;
+      Box bb[NB]; uint32_t bc[NB];
+      for (int b = 0; b < NB; ++b) { bb[b].reset(); bc[b] = 0; }
+      float scale = (float)NB / (hi - lo);
+      for (uint32_t i = first; i < first + count; ++i) {
+        int b = std::min(NB - 1, std::max(0, (int)((refs[i].c[axis] - lo) * scale)));
+        bb[b].grow(refs[i].box); bc[b]++;
+      }
+      float right_area[NB]; uint32_t right_cnt[NB];
+      Box acc; acc.reset(); uint32_t cnt = 0;
+      for (int b = NB - 1; b > 0; --b) { acc.grow(bb[b]); cnt += bc[b]; right_area[b] = acc.half_area(); right_cnt[b] = cnt; }
+      acc.reset(); cnt = 0;
+      for (int b = 0; b < NB - 1; ++b) {
+        acc.grow(bb[b]); cnt += bc[b];
+        if (cnt == 0 || right_cnt[b + 1] == 0) continue;
+        float cost = acc.half_area() * (float)cnt + right_area[b + 1] * (float)right_cnt[b + 1];
+        if (cost < best_cost) { best_cost = cost; best_axis = axis; best_split = b; }
+      }
+    }
+    uint32_t mid;
+    if (best_axis < 0) {
+      if (count <= max_leaf) return make_leaf();
+      mid = first + count / 2;  // all centroids coincide: split by index
+    } else {
+      float leaf_cost = (float)count * bounds.half_area();
+      float split_cost = 0.5f * bounds.half_area() + best_cost;
+      if (count <= max_leaf && leaf_cost <= split_cost) return make_leaf();
+      float lo = cb.mn[best_axis], hi = cb.mx[best_axis];
+      float scale = (float)NB / (hi - lo);
+      auto it = std::partition(refs.begin() + first, refs.begin() + first + count, [&](const BuildRef& r) {
+        int b = std::min(NB - 1, std::max(0, (int)((r.c[best_axis] - lo) * scale)));
+        return b <= best_split;
+      });
+      mid = (uint32_t)(it - refs.begin());
+      if (mid == first || mid == first + count) mid = first + count / 2;
+    }
+    uint32_t my = (uint32_t)nodes.size();
+    nodes.push_back(Node{});
+    ChildRef a = build(first, mid - first);
+    ChildRef b = build(mid, first + count - mid);
+    Node& n = nodes[my];
+    memcpy(n.c0min, a.box.mn, 12); memcpy(n.c0max, a.box.mx, 12);
+    memcpy(n.c1min, b.box.mn, 12); memcpy(n.c1max, b.box.mx, 12);
+    n.child0 = a.child; n.count0 = a.count; n.child1 = b.child; n.count1 = b.count;
+    return ChildRef{my, 0, bounds};
+  }
+};
+}  // namespace
+
+static void build_bvh(orc_scene* s) {
+  const uint32_t N = (uint32_t)s->tris_by_id.size();
+  std::vector<BuildRef> refs(N);
+  for (uint32_t i = 0; i < N; ++i) {
+    const Tri& t = s->tris_by_id[i];
+    float v1[3], v2[3];
+    for (int k = 0; k < 3; ++k) { v1[k] = t.v0[k] + t.e1[k]; v2[k] = t.v0[k] + t.e2[k]; }
+    refs[i].box.reset(); refs[i].box.grow(t.v0); refs[i].box.grow(v1); refs[i].box.grow(v2);
+    for (int k = 0; k < 3; ++k) refs[i].c[k] = 0.5f * (refs[i].box.mn[k] + refs[i].box.mx[k]);
+    refs[i].id = i;
+  }
+  s->nodes.clear();
+  if (N == 0) {
+    Node n{}; n.child0 = kAbsent; n.child1 = kAbsent; s->nodes.push_back(n);
+  } else {
+    s->nodes.reserve(N);
+    Builder b(refs, s->nodes);
+    ChildRef root = b.build(0, N);
+    if (root.count > 0) {  // the whole scene is one leaf: root node with one child
+      Node n{};
+      memcpy(n.c0min, root.box.mn, 12); memcpy(n.c0max, root.box.mx, 12);
+      n.child0 = root.child; n.count0 = root.count; n.child1 = kAbsent; n.count1 = 0;
+      s->nodes.push_back(n);
+    }
+  }
+  s->tris.resize(N);
+  for (uint32_t i = 0; i < N; ++i) s->tris[i] = s->tris_by_id[refs[i].id];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// scene
+// ---------------------------------------------------------------------------------------------------------
+extern "C" orc_scene* orc_scene_create(const orc_scene_desc* desc) {
+  orc_scene* s = new orc_scene();
+  std::vector<float> world((size_t)desc->node_count * 16);
+  orc_update_node_hierarchies(desc, world.data());
+  // own the geometry
+  s->owned_vertices.resize(desc->mesh_count ? 0 : 0);
+  std::vector<std::vector<std::pair<size_t, size_t>>> slot(desc->mesh_count);
+  for (uint32_t m = 0; m < desc->mesh_count; ++m) {
+    for (uint32_t p = 0; p < desc->meshes[m].primitive_count; ++p) {
+      const orc_primitive_desc& pr = desc->meshes[m].primitives[p];
+      s->owned_vertices.emplace_back(pr.vertices, pr.vertices + pr.vertex_count);
+      s->owned_indices.emplace_back(pr.indices, pr.indices + pr.index_count);
+      slot[m].push_back({s->owned_vertices.size() - 1, s->owned_indices.size() - 1});
+    }
+  }
+  // RENDER_SPEC §3 / gpu_uploader.rs:843-875: instances in node order, then primitive order
+  for (int i = 0; i < 3; ++i) { s->bounds_min[i] = std::numeric_limits<float>::infinity(); s->bounds_max[i] = -s->bounds_min[i]; }
+  for (uint32_t k = 0; k < desc->node_count; ++k) {
+    const orc_node_desc& node = desc->nodes[k];
+    if (node.mesh_index == ORC_NONE) continue;
+    const float* w = world.data() + 16 * k;
+    for (uint32_t p = 0; p < desc->meshes[node.mesh_index].primitive_count; ++p) {
+      const orc_primitive_desc& pr = desc->meshes[node.mesh_index].primitives[p];
+      Instance inst;
+      memcpy(inst.transform, w, 64);
+      inst.material_index = pr.material_index;
+      inst.first_triangle = (uint32_t)s->tris_by_id.size();
+      inst.vertices = s->owned_vertices[slot[node.mesh_index][p].first].data();
+      inst.indices = s->owned_indices[slot[node.mesh_index][p].second].data();
+      uint32_t inst_id = (uint32_t)s->instances.size();
+      s->instances.push_back(inst);
+      for (uint32_t t = 0; t < pr.index_count / 3; ++t) {  // primitive_count = index_count / 3 (gpu_uploader.rs:804)
+        V3 v[3];
+        for (int c = 0; c < 3; ++c) {
+          const float* pp = inst.vertices[inst.indices[3 * t + c]].position;
+          v[c] = transform_point(w, v3(pp[0], pp[1], pp[2]));
+          const float a[3] = {v[c].x, v[c].y, v[c].z};
+          for (int i = 0; i < 3; ++i) { s->bounds_min[i] = std::min(s->bounds_min[i], a[i]); s->bounds_max[i] = std::max(s->bounds_max[i], a[i]); }
+        }
+        Tri tr;
+        V3 e1 = v[1] - v[0], e2 = v[2] - v[0];
+        tr.v0[0] = v[0].x; tr.v0[1] = v[0].y; tr.v0[2] = v[0].z; tr.id = (uint32_t)s->tris_by_id.size();
+        tr.e1[0] = e1.x; tr.e1[1] = e1.y; tr.e1[2] = e1.z; tr.pad1 = 0;
+        tr.e2[0] = e2.x; tr.e2[1] = e2.y; tr.e2[2] = e2.z; tr.pad2 = 0;
+        s->tris_by_id.push_back(tr);
+        s->tri_instance.push_back(inst_id);
+        for (int c = 0; c < 3; ++c) { s->tri_verts9.push_back(v[c].x); s->tri_verts9.push_back(v[c].y); s->tri_verts9.push_back(v[c].z); }
+      }
+    }
+  }
+  if (s->tris_by_id.empty()) for (int i = 0; i < 3; ++i) { s->bounds_min[i] = 0.0f; s->bounds_max[i] = 0.0f; }
+  V3 ext = v3(s->bounds_max[0] - s->bounds_min[0], s->bounds_max[1] - s->bounds_min[1], s->bounds_max[2] - s->bounds_min[2]);
+  s->ray_eps = sqrtf(dot3(ext, ext)) * 1e-5f;  // RENDER_SPEC §3
+  build_bvh(s);
+  s->materials.resize(desc->material_count);
+  for (uint32_t i = 0; i < desc->material_count; ++i) orc_pack_material(&desc->materials[i], &s->materials[i]);
+  s->camera_count = orc_pack_cameras(desc, s->cameras);
+  if (s->camera_count < 0) s->camera_count = 0;
+  s->light_count = orc_pack_lights(desc, s->lights, std::vector<orc_aabb>(32).data());
+  if (s->light_count < 0) s->light_count = 0;
+  return s;
+}
+extern "C" void orc_scene_destroy(orc_scene* s) { delete s; }
+extern "C" void orc_scene_set_envmap(orc_scene* s, const float* rgba, uint32_t width, uint32_t height) {
+  s->env.width = width; s->env.height = height;
+  s->env.pixels.assign(rgba, rgba + (size_t)width * height * 4);
+  for (size_t i = 0; i < (size_t)width * height; ++i) s->env.pixels[4 * i + 3] = 1.0f;  // src/envmap.rs:87
+  s->env.marginal.resize(height); s->env.conditional.resize((size_t)width * height);
+  orc_envmap_build_distribution(s->env.pixels.data(), width, height, &s->env.total_sum, s->env.marginal.data(), s->env.conditional.data());
+}
+extern "C" uint32_t orc_scene_triangle_count(const orc_scene* s) { return (uint32_t)s->tris_by_id.size(); }
+extern "C" uint32_t orc_scene_node_count(const orc_scene* s) { return (uint32_t)s->nodes.size(); }
+extern "C" void orc_scene_bounds(const orc_scene* s, float mn[3], float mx[3]) { memcpy(mn, s->bounds_min, 12); memcpy(mx, s->bounds_max, 12); }
+extern "C" void orc_scene_get_triangles(const orc_scene* s, float* out9) {
+  memcpy(out9, s->tri_verts9.data(), s->tri_verts9.size() * sizeof(float));
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// RENDER_SPEC §4.2 ray/triangle, §4.3 ray/box, §4.4 traversal order
+// ---------------------------------------------------------------------------------------------------------
+namespace orc {
+
+struct RayPre { V3 o, d, idir, ood; float tmin; };
+
+static inline float safe_inv(float d) {
+  float dd = fabsf(d) < 1e-20f ? copysignf(1e-20f, d) : d;
+  return 1.0f / dd;
+}
+static inline RayPre make_ray(V3 o, V3 d, float tmin) {
+  RayPre r; r.o = o; r.d = d; r.tmin = tmin;
+  r.idir = v3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
+  r.ood = r.o * r.idir;
+  return r;
+}
+// returns true and the entry distance if the (padded) slab interval is non-empty against [tmin, tlimit]
+static inline bool box_test(const RayPre& r, const float* mn, const float* mx, float tlimit, float* tnear) {
+  float x0 = fmaf(mn[0], r.idir.x, -r.ood.x), x1 = fmaf(mx[0], r.idir.x, -r.ood.x);
+  float y0 = fmaf(mn[1], r.idir.y, -r.ood.y), y1 = fmaf(mx[1], r.idir.y, -r.ood.y);
+  float z0 = fmaf(mn[2], r.idir.z, -r.ood.z), z1 = fmaf(mx[2], r.idir.z, -r.ood.z);
+  float tn = maxf(maxf(minf(x0, x1), minf(y0, y1)), maxf(minf(z0, z1), r.tmin));
+  float tf = minf(minf(maxf(x0, x1), maxf(y0, y1)), minf(maxf(z0, z1), tlimit));
+  *tnear = tn;
+  return tn <= tf * 1.0000004f;
+}
+// Möller–Trumbore with the fma placement of spec_math.h. Returns true if (u,v) is inside and fills t,u,v.
+static inline bool tri_test(const RayPre& r, const Tri& tr, float* t, float* u, float* v) {
+  V3 e1 = v3(tr.e1[0], tr.e1[1], tr.e1[2]), e2 = v3(tr.e2[0], tr.e2[1], tr.e2[2]);
+  V3 p = cross3(r.d, e2);
+  float det = dot3(e1, p);
+  if (det == 0.0f) return false;
+  float inv = 1.0f / det;
+  V3 tv = r.o - v3(tr.v0[0], tr.v0[1], tr.v0[2]);
+  float uu = dot3(tv, p) * inv;
+  if (!(uu >= 0.0f && uu <= 1.0f)) return false;
+  V3 q = cross3(tv, e1);
+  float vv = dot3(r.d, q) * inv;
+  if (!(vv >= 0.0f && uu + vv <= 1.0f)) return false;
+  *t = dot3(e2, q) * inv; *u = uu; *v = vv;
+  return true;
+}
+
+template <bool ANY>
+static inline bool traverse(const Node* nodes, const Tri* tris, const RayPre& r, float tmax, Hit* best, Counters* c) {
+  best->t = tmax; best->prim = ORC_NONE; best->u = 0.0f; best->v = 0.0f;
+  uint32_t stack[1024]; int sp = 0;
+  uint32_t cur = 0;
+  for (;;) {
+    const Node& n = nodes[cur];
+    if (c) c->nodes++;
+    float tn0 = 0.0f, tn1 = 0.0f;
+    bool valid0 = !(n.count0 == 0 && n.child0 == kAbsent), valid1 = !(n.count1 == 0 && n.child1 == kAbsent);
+    bool h0 = valid0 && box_test(r, n.c0min, n.c0max, best->t, &tn0);
+    bool h1 = valid1 && box_test(r, n.c1min, n.c1max, best->t, &tn1);
+    // order: nearer entry first, ties -> child 0
+    int order[2] = {0, 1};
+    if (h0 && h1 && tn1 < tn0) { order[0] = 1; order[1] = 0; }
+    uint32_t next = kAbsent;
+    for (int k = 0; k < 2; ++k) {
+      int ci = order[k];
+      bool h = ci == 0 ? h0 : h1;
+      if (!h) continue;
+      uint32_t child = ci == 0 ? n.child0 : n.child1, count = ci == 0 ? n.count0 : n.count1;
+      float tn = ci == 0 ? tn0 : tn1;
+      if (count > 0) {
+        if (!(tn <= best->t)) continue;  // best may have shrunk since the box test
+        if (c) c->tris += count;
+        for (uint32_t i = 0; i < count; ++i) {
+          const Tri& tr = tris[child + i];
+          float t, u, v;
+          if (!tri_test(r, tr, &t, &u, &v)) continue;
+          if (ANY) {
+            if (t > r.tmin && t < tmax) { best->t = t; best->prim = tr.id; best->u = u; best->v = v; return true; }
+          } else {
+            if (t > r.tmin && (t < best->t || (t == best->t && tr.id < best->prim))) { best->t = t; best->u = u; best->v = v; best->prim = tr.id; }
+          }
+        }
+      } else {
+        if (next == kAbsent) next = child; else stack[sp++] = child;
+      }
+    }
+    if (next == kAbsent) {
+      if (sp == 0) break;
+      next = stack[--sp];
+    }
+    cur = next;
+  }
+  return best->prim != ORC_NONE;
+}
+
+Hit trace_closest(const Node* nodes, const Tri* tris, V3 o, V3 d, float tmin, float tmax, Counters* c) {
+  RayPre r = make_ray(o, d, tmin);
+  Hit h;
+  if (!traverse<false>(nodes, tris, r, tmax, &h, c)) { h.t = -1.0f; h.u = 0.0f; h.v = 0.0f; h.prim = ORC_NONE; }
+  return h;
+}
+bool trace_any(const Node* nodes, const Tri* tris, V3 o, V3 d, float tmin, float tmax, Counters* c) {
+  RayPre r = make_ray(o, d, tmin);
+  Hit h;
+  return traverse<true>(nodes, tris, r, tmax, &h, c);
+}
+}  // namespace orc
+
+static void trace_batch(const Node* nodes, const Tri* tris, const orc_ray* rays, orc_hit* hits, uint32_t count, int mode, uint64_t* counters) {
+  uint64_t cn = 0, ct = 0;
+#pragma omp parallel for schedule(dynamic, 4096) reduction(+ : cn, ct)
+  for (int64_t i = 0; i < (int64_t)count; ++i) {
+    const orc_ray& r = rays[i];
+    Counters c;
+    V3 o = v3(r.origin[0], r.origin[1], r.origin[2]), d = v3(r.direction[0], r.direction[1], r.direction[2]);
+    if (mode == 0) {
+      Hit h = trace_closest(nodes, tris, o, d, r.tmin, r.tmax, &c);
+      hits[i].t = h.t; hits[i].u = h.u; hits[i].v = h.v; hits[i].prim = h.prim;
+    } else {
+      bool occ = trace_any(nodes, tris, o, d, r.tmin, r.tmax, &c);
+      hits[i].t = occ ? 1.0f : -1.0f; hits[i].u = 0.0f; hits[i].v = 0.0f; hits[i].prim = ORC_NONE;
+    }
+    cn += c.nodes; ct += c.tris;
+  }
+  if (counters) { counters[0] += cn; counters[1] += ct; }
+}
+
+extern "C" void orc_trace_rays(const orc_scene* s, const orc_ray* rays, orc_hit* hits, uint32_t count, int mode, uint64_t* counters) {
+  trace_batch(s->nodes.data(), s->tris.data(), rays, hits, count, mode, counters);
+}
+extern "C" void orc_trace_rays_on_bvh(const void* nodes64, uint32_t, const void* tris48, uint32_t, const orc_ray* rays,
+                                      orc_hit* hits, uint32_t count, int mode, uint64_t* counters) {
+  trace_batch((const Node*)nodes64, (const Tri*)tris48, rays, hits, count, mode, counters);
+}
+
+extern "C" void orc_trace_rays_brute(const orc_scene* s, const orc_ray* rays, orc_hit* hits, uint32_t count, int mode) {
+#pragma omp parallel for schedule(dynamic, 256)
+  for (int64_t i = 0; i < (int64_t)count; ++i) {
+    const orc_ray& ry = rays[i];
+    RayPre r = make_ray(v3(ry.origin[0], ry.origin[1], ry.origin[2]), v3(ry.direction[0], ry.direction[1], ry.direction[2]), ry.tmin);
+    Hit best{ry.tmax, 0.0f, 0.0f, ORC_NONE};
+    bool any = false;
+    for (const Tri& tr : s->tris_by_id) {
+      float t, u, v;
+      if (!tri_test(r, tr, &t, &u, &v)) continue;
+      if (mode == 1) { if (t > r.tmin && t < ry.tmax) { any = true; break; } }
+      else if (t > r.tmin && (t < best.t || (t == best.t && tr.id < best.prim))) best = Hit{t, u, v, tr.id};
+    }
+    if (mode == 1) hits[i] = orc_hit{any ? 1.0f : -1.0f, 0.0f, 0.0f, ORC_NONE};
+    else if (best.prim == ORC_NONE) hits[i] = orc_hit{-1.0f, 0.0f, 0.0f, ORC_NONE};
+    else hits[i] = orc_hit{best.t, best.u, best.v, best.prim};
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// structural validation of a product-built BVH
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int orc_validate_bvh(const void* nodes64, uint32_t node_count, const void* tris48, uint32_t tri_count,
+                                const float* ref9, uint32_t* max_depth) {
+  const Node* nodes = (const Node*)nodes64;
+  const Tri* tris = (const Tri*)tris48;
+  if (max_depth) *max_depth = 0;
+  if (node_count == 0) return 1;
+  std::vector<uint8_t> seen_tri(tri_count, 0), seen_node(node_count, 0), seen_slot(tri_count, 0);
+  struct Item { uint32_t node, depth; };
+  std::vector<Item> st{{0, 1}};
+  uint32_t md = 0;
+  while (!st.empty()) {
+    Item it = st.back(); st.pop_back();
+    if (it.node >= node_count) return 2;
+    if (seen_node[it.node]) return 3;  // cycle / shared node
+    seen_node[it.node] = 1;
+    md = std::max(md, it.depth);
+    const Node& n = nodes[it.node];
+    for (int ci = 0; ci < 2; ++ci) {
+      uint32_t child = ci ? n.child1 : n.child0, count = ci ? n.count1 : n.count0;
+      const float* mn = ci ? n.c1min : n.c0min; const float* mx = ci ? n.c1max : n.c0max;
+      if (count == 0 && child == kAbsent) continue;
+      if (count == 0) {
+        // child node's two boxes must lie inside this child box
+        if (child >= node_count) return 2;
+        const Node& cn = nodes[child];
+        for (int cj = 0; cj < 2; ++cj) {
+          uint32_t gc = cj ? cn.child1 : cn.child0, gcount = cj ? cn.count1 : cn.count0;
+          if (gcount == 0 && gc == kAbsent) continue;
+          const float* gmn = cj ? cn.c1min : cn.c0min; const float* gmx = cj ? cn.c1max : cn.c0max;
+          for (int k = 0; k < 3; ++k) if (gmn[k] < mn[k] || gmx[k] > mx[k]) return 4;
+        }
+        st.push_back({child, it.depth + 1});
+      } else {
+        if ((uint64_t)child + count > tri_count) return 5;
+        for (uint32_t i = 0; i < count; ++i) {
+          if (seen_slot[child + i]) return 6;
+          seen_slot[child + i] = 1;
+          const Tri& tr = tris[child + i];
+          if (tr.id >= tri_count || seen_tri[tr.id]) return 7;
+          seen_tri[tr.id] = 1;
+          float v[3][3];
+          for (int k = 0; k < 3; ++k) { v[0][k] = tr.v0[k]; v[1][k] = tr.v0[k] + tr.e1[k]; v[2][k] = tr.v0[k] + tr.e2[k]; }
+          if (ref9) {
+            const float* rv = ref9 + 9 * (size_t)tr.id;
+            // v0 and the edge vectors must be the bit-exact flattening of RENDER_SPEC §3
+            for (int k = 0; k < 3; ++k) {
+              if (tr.v0[k] != rv[k]) return 8;
+              if (tr.e1[k] != rv[3 + k] - rv[k]) return 8;
+              if (tr.e2[k] != rv[6 + k] - rv[k]) return 8;
+            }
+          }
+          for (int c = 0; c < 3; ++c) {
+            const float* pv = ref9 ? ref9 + 9 * (size_t)tr.id + 3 * c : v[c];
+            for (int k = 0; k < 3; ++k) if (pv[k] < mn[k] || pv[k] > mx[k]) return 9;
+          }
+        }
+      }
+    }
+  }
+  for (uint32_t i = 0; i < tri_count; ++i) if (!seen_tri[i]) return 10;
+  if (max_depth) *max_depth = md;
+  return 0;
+}

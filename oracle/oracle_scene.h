@@ -1,0 +1,71 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see spec_math.h).
+// oracle_scene.h — the flattened world-space scene + BVH2 the CPU integrator works on (RENDER_SPEC §3, §4).
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "oracle_api.h"
+#include "spec_math.h"
+
+namespace orc {
+
+// RENDER_SPEC §4.1 — 64-B node: two child boxes, two child refs, two counts.
+// count == 0: `child` is a node index; count > 0: `child` is the first triangle (BVH order) of a leaf.
+// An absent child has an inverted box (min = +inf, max = -inf), child = 0, count = 0 and is never entered.
+struct Node {
+  float c0min[3], c0max[3], c1min[3], c1max[3];
+  uint32_t child0, child1, count0, count1;
+};
+static_assert(sizeof(Node) == 64, "node is 64 B");
+
+// RENDER_SPEC §4.1 — 48-B triangle: v0 | global id, e1 = v1 - v0 | 0, e2 = v2 - v0 | 0
+struct Tri {
+  float v0[3]; uint32_t id;
+  float e1[3]; uint32_t pad1;
+  float e2[3]; uint32_t pad2;
+};
+static_assert(sizeof(Tri) == 48, "triangle is 48 B");
+
+struct Instance {
+  float transform[16];
+  uint32_t material_index;
+  uint32_t first_triangle;  // global id of its first triangle
+  const orc_vertex* vertices;
+  const uint32_t* indices;
+};
+
+struct EnvMap {
+  uint32_t width = 0, height = 0;
+  std::vector<float> pixels;  // RGBA32F
+  float total_sum = 0.0f;
+  std::vector<float> marginal, conditional;
+};
+
+}  // namespace orc
+
+struct orc_scene {
+  std::vector<orc::Instance> instances;
+  std::vector<uint32_t> tri_instance;  // global triangle id -> instance
+  std::vector<orc::Tri> tris_by_id;    // world-space, indexed by global id
+  std::vector<float> tri_verts9;       // world-space v0,v1,v2 per global id (RENDER_SPEC §3)
+  std::vector<orc::Tri> tris;          // BVH order
+  std::vector<orc::Node> nodes;
+  float bounds_min[3], bounds_max[3];
+  float ray_eps;
+  std::vector<orc_gpu_material> materials;
+  orc_gpu_camera cameras[8]; int camera_count = 0;
+  orc_gpu_light lights[32]; int light_count = 0;
+  // owned copies of the caller's vertex / index arrays
+  std::vector<std::vector<orc_vertex>> owned_vertices;
+  std::vector<std::vector<uint32_t>> owned_indices;
+  orc::EnvMap env;
+};
+
+namespace orc {
+struct Counters { uint64_t nodes = 0, tris = 0; };
+struct Hit { float t, u, v; uint32_t prim; };
+// RENDER_SPEC §4: closest / any traversal over (nodes, tris).
+Hit trace_closest(const Node* nodes, const Tri* tris, V3 o, V3 d, float tmin, float tmax, Counters* c);
+bool trace_any(const Node* nodes, const Tri* tris, V3 o, V3 d, float tmin, float tmax, Counters* c);
+V3 tonemap_select(V3 color, int enable_tonemap, int enable_aces, int use_simple_aces);
+}  // namespace orc

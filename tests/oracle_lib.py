@@ -1,0 +1,258 @@
+"""ctypes binding of oracle/_build/liboracle.so — TEST INFRASTRUCTURE (the checker), never the product.
+
+Used by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg only.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+import hala_renderer_amd as H
+from hala_renderer_amd import _abi as A
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB = os.path.join(ORACLE_DIR, "_build", "liboracle.so")
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+
+
+class RenderParams(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("max_depth", C.c_uint32), ("rr_depth", C.c_uint32),
+                ("ground_color", C.c_float * 4), ("sky_color", C.c_float * 4), ("env_rotation_degrees", C.c_float),
+                ("env_intensity", C.c_float), ("exposure_value", C.c_float), ("enable_tonemap", C.c_int),
+                ("enable_aces", C.c_int), ("use_simple_aces", C.c_int), ("num_threads", C.c_int)]
+
+
+class RenderStats(C.Structure):
+    _fields_ = [("rays_closest", C.c_uint64), ("rays_shadow", C.c_uint64), ("nodes_visited", C.c_uint64),
+                ("triangles_tested", C.c_uint64)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            build()
+        _lib = C.CDLL(LIB)
+        _lib.orc_scene_create.restype = C.c_void_p
+        _lib.orc_scene_triangle_count.restype = C.c_uint32
+        _lib.orc_scene_node_count.restype = C.c_uint32
+        _lib.orc_pfm_bytes.restype = C.c_size_t
+    return _lib
+
+
+def fptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def envmap_build_distribution(rgba):
+    rgba = np.ascontiguousarray(rgba, dtype=np.float32)
+    h, w, _ = rgba.shape
+    total = C.c_float()
+    marg = np.empty(h, dtype=np.float32)
+    cond = np.empty((h, w), dtype=np.float32)
+    lib().orc_envmap_build_distribution(fptr(rgba), C.c_uint32(w), C.c_uint32(h), C.byref(total), fptr(marg), fptr(cond))
+    return np.float32(total.value), marg, cond
+
+
+def envmap_validate(px):
+    px = np.ascontiguousarray(px, dtype=np.float32)
+    h, w, ch = px.shape
+    return lib().orc_envmap_validate(fptr(px), C.c_uint32(ch), C.c_uint32(w), C.c_uint32(h))
+
+
+def world_transforms(scene: H.HalaScene):
+    holder = scene.to_desc()
+    out = np.empty((len(scene.nodes), 16), dtype=np.float32)
+    lib().orc_update_node_hierarchies(holder.ptr(), fptr(out))
+    return out
+
+
+def pack_material(m: H.HalaMaterial) -> A.GpuMaterial:
+    s = H.HalaScene(materials=[m])
+    holder = s.to_desc()
+    out = A.GpuMaterial()
+    lib().orc_pack_material(holder.desc.materials, C.byref(out))
+    return out
+
+
+def pack_cameras(scene):
+    holder = scene.to_desc()
+    out = (A.GpuCamera * 8)()
+    n = lib().orc_pack_cameras(holder.ptr(), out)
+    return None if n < 0 else list(out[:n])
+
+
+def pack_lights(scene):
+    holder = scene.to_desc()
+    out = (A.GpuLight * 32)()
+    bb = (A.Aabb * 32)()
+    n = lib().orc_pack_lights(holder.ptr(), out, bb)
+    return list(out[:n]), list(bb[:n])
+
+
+def pack_instances(scene, capacity=65536):
+    holder = scene.to_desc()
+    t = np.zeros((capacity, 12), dtype=np.float32)
+    md = (A.GpuMeshData * capacity)()
+    n = lib().orc_pack_instances(holder.ptr(), fptr(t), md, C.c_uint32(capacity))
+    return t[:n], list(md[:n])
+
+
+def primitive_bounds(vertices):
+    v = np.ascontiguousarray(vertices, dtype=A.VERTEX_DTYPE)
+    c = (C.c_float * 3)()
+    e = (C.c_float * 3)()
+    lib().orc_primitive_bounds(C.c_void_p(v.ctypes.data), C.c_uint32(v.size), c, e)
+    return np.array(c[:], dtype=np.float32), np.array(e[:], dtype=np.float32)
+
+
+def tonemap_pixels(rgba, enable_tonemap, enable_aces, use_simple_aces):
+    out = np.ascontiguousarray(rgba, dtype=np.float32).copy()
+    lib().orc_tonemap_pixels(fptr(out), C.c_size_t(out.size // 4), C.c_int(enable_tonemap), C.c_int(enable_aces), C.c_int(use_simple_aces))
+    return out
+
+
+def pfm_bytes(rgba):
+    rgba = np.ascontiguousarray(rgba, dtype=np.float32)
+    h, w, _ = rgba.shape
+    buf = (C.c_uint8 * (64 + 12 * w * h))()
+    n = lib().orc_pfm_bytes(fptr(rgba), C.c_uint32(w), C.c_uint32(h), buf, C.c_size_t(len(buf)))
+    return bytes(buf[:n])
+
+
+class OracleScene:
+    def __init__(self, scene: H.HalaScene, envmap=None):
+        holder = scene.to_desc()
+        self._h = C.c_void_p(lib().orc_scene_create(holder.ptr()))
+        if not self._h:
+            raise RuntimeError("orc_scene_create failed")
+        self.has_env = False
+        if envmap is not None:
+            self.set_envmap(envmap)
+
+    def set_envmap(self, rgba):
+        px = np.ascontiguousarray(rgba, dtype=np.float32)
+        h, w, ch = px.shape
+        if ch == 3:
+            px = np.concatenate([px, np.ones((h, w, 1), np.float32)], -1)
+        lib().orc_scene_set_envmap(self._h, fptr(px), C.c_uint32(w), C.c_uint32(h))
+        self.has_env = True
+
+    def close(self):
+        if self._h:
+            lib().orc_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def triangle_count(self):
+        return lib().orc_scene_triangle_count(self._h)
+
+    @property
+    def node_count(self):
+        return lib().orc_scene_node_count(self._h)
+
+    def bounds(self):
+        mn = (C.c_float * 3)(); mx = (C.c_float * 3)()
+        lib().orc_scene_bounds(self._h, mn, mx)
+        return np.array(mn[:], np.float32), np.array(mx[:], np.float32)
+
+    def triangles(self):
+        out = np.empty((self.triangle_count, 9), dtype=np.float32)
+        lib().orc_scene_get_triangles(self._h, fptr(out))
+        return out
+
+    def trace(self, rays, mode=0, count_steps=False, brute=False):
+        rays = np.ascontiguousarray(rays, dtype=A.RAY_DTYPE)
+        hits = np.empty(rays.shape[0], dtype=A.HIT_DTYPE)
+        if brute:
+            lib().orc_trace_rays_brute(self._h, C.c_void_p(rays.ctypes.data), C.c_void_p(hits.ctypes.data), C.c_uint32(rays.shape[0]), C.c_int(mode))
+            return hits
+        ctr = (C.c_uint64 * 2)(0, 0)
+        lib().orc_trace_rays(self._h, C.c_void_p(rays.ctypes.data), C.c_void_p(hits.ctypes.data), C.c_uint32(rays.shape[0]), C.c_int(mode), ctr)
+        return (hits, (ctr[0], ctr[1])) if count_steps else hits
+
+    def camera_rays(self, width, height, frame_index=0):
+        rays = np.empty(width * height, dtype=A.RAY_DTYPE)
+        lib().orc_generate_camera_rays(self._h, C.c_uint32(width), C.c_uint32(height), C.c_uint32(frame_index), C.c_void_p(rays.ctypes.data))
+        return rays
+
+    def render(self, width, height, frames=1, first_frame=0, max_depth=5, rr_depth=3, images=None, rect=None,
+               ground=(1, 1, 1, 1), sky=(0.5, 0.7, 1.0, 1.0), env_rotation=0.0, env_intensity=1.0, exposure=1.0,
+               tonemap=(False, False, False), threads=0):
+        p = RenderParams()
+        p.width, p.height, p.max_depth, p.rr_depth = width, height, max_depth, rr_depth
+        p.ground_color = (C.c_float * 4)(*ground); p.sky_color = (C.c_float * 4)(*sky)
+        p.env_rotation_degrees, p.env_intensity, p.exposure_value = env_rotation, env_intensity, exposure
+        p.enable_tonemap, p.enable_aces, p.use_simple_aces = [int(x) for x in tonemap]
+        p.num_threads = threads
+        if images is None:
+            images = [np.zeros((height, width, 4), dtype=np.float32) for _ in range(4)]
+        accum, albedo, normal, final = images
+        x0, y0, x1, y1 = rect if rect else (0, 0, width, height)
+        st = RenderStats()
+        lib().orc_render(self._h, C.byref(p), C.c_uint32(first_frame), C.c_uint32(frames), C.c_uint32(x0), C.c_uint32(y0),
+                         C.c_uint32(x1), C.c_uint32(y1), fptr(accum), fptr(albedo), fptr(normal), fptr(final), C.byref(st))
+        return images, st
+
+
+def trace_on_bvh(nodes_u32, tris_u32, rays, mode=0):
+    rays = np.ascontiguousarray(rays, dtype=A.RAY_DTYPE)
+    hits = np.empty(rays.shape[0], dtype=A.HIT_DTYPE)
+    ctr = (C.c_uint64 * 2)(0, 0)
+    lib().orc_trace_rays_on_bvh(C.c_void_p(nodes_u32.ctypes.data), C.c_uint32(nodes_u32.size // 16), C.c_void_p(tris_u32.ctypes.data),
+                                C.c_uint32(tris_u32.size // 12), C.c_void_p(rays.ctypes.data), C.c_void_p(hits.ctypes.data),
+                                C.c_uint32(rays.shape[0]), C.c_int(mode), ctr)
+    return hits, (ctr[0], ctr[1])
+
+
+def validate_bvh(nodes_u32, tris_u32, ref_triangles9):
+    md = C.c_uint32()
+    ref = np.ascontiguousarray(ref_triangles9, dtype=np.float32)
+    rc = lib().orc_validate_bvh(C.c_void_p(nodes_u32.ctypes.data), C.c_uint32(nodes_u32.size // 16), C.c_void_p(tris_u32.ctypes.data),
+                                C.c_uint32(tris_u32.size // 12), fptr(ref), C.byref(md))
+    return rc, md.value
+
+
+def tile_assignment(tiles_x, tiles_y, world):
+    n = tiles_x * tiles_y
+    owner = np.empty(n, dtype=np.uint32); slot = np.empty(n, dtype=np.uint32)
+    lib().orc_tile_assignment(C.c_uint32(tiles_x), C.c_uint32(tiles_y), C.c_uint32(world), C.c_void_p(owner.ctypes.data), C.c_void_p(slot.ctypes.data))
+    return owner, slot
+
+
+def probe_sincos_2pi(u):
+    u = np.ascontiguousarray(u, dtype=np.float32); s = np.empty_like(u); c = np.empty_like(u)
+    lib().orc_probe_sincos_2pi(fptr(u), fptr(s), fptr(c), C.c_size_t(u.size))
+    return s, c
+
+
+def probe_acos(x):
+    x = np.ascontiguousarray(x, dtype=np.float32); o = np.empty_like(x)
+    lib().orc_probe_acos(fptr(x), fptr(o), C.c_size_t(x.size))
+    return o
+
+
+def probe_atan2(y, x):
+    y = np.ascontiguousarray(y, dtype=np.float32); x = np.ascontiguousarray(x, dtype=np.float32); o = np.empty_like(x)
+    lib().orc_probe_atan2(fptr(y), fptr(x), fptr(o), C.c_size_t(x.size))
+    return o
+
+
+def probe_rng(pixel_id, frame_index, n):
+    o = np.empty(n, dtype=np.float32)
+    lib().orc_probe_rng(C.c_uint32(pixel_id), C.c_uint32(frame_index), fptr(o), C.c_size_t(n))
+    return o
