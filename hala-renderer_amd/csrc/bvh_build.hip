@@ -1,0 +1,390 @@
+// bvh_build.hip — K1/K3/K4 of SURVEY.md §2.1: what the reference hands to the Vulkan driver through
+// HalaAccelerationStructure::new (src/scene/loader/gpu_uploader.rs:784-811 BLAS per primitive, :937-959 TLAS),
+// done here on the GPU for gfx950:
+//   flatten   every instance (node x primitive, in the reference's instance order gpu_uploader.rs:843-875) is
+//             transformed to world space once -> one triangle soup, one BVH (288 GB of HBM make the copy free and
+//             single-level traversal needs no per-instance ray transform)
+//   build     63-bit Morton codes -> rocPRIM radix sort -> Karras 2012 hierarchy -> bottom-up AABB fit with
+//             arrival counters -> subtrees of <= leaf_max triangles collapsed into leaves -> compacted 64-B nodes
+//   refit     (north_star; the reference only rebuilds) re-flatten + bottom-up fit on the frozen topology
+// Results are validated against the oracle through traversal results and a structural check, never topology.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include <vector>
+
+#include "kernels.h"
+#include "rt_math.h"
+
+namespace rt {
+
+namespace {
+
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess) return std::string(#expr) + ": " + hipGetErrorString(_e);            \
+  } while (0)
+
+struct Box6 {
+  float mn[3], mx[3];
+};
+
+RT_DI uint32_t f2ord(float f) {
+  uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ inline float ord2f(uint32_t u) {
+  u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+// RENDER_SPEC §3: p' = fma(m8,z, fma(m4,y, m0*x)) + m12
+RT_DI f3 transform_point(const float* m, f3 p) {
+  return mk3(__fmaf_rn(m[8], p.z, __fmaf_rn(m[4], p.y, m[0] * p.x)) + m[12], __fmaf_rn(m[9], p.z, __fmaf_rn(m[5], p.y, m[1] * p.x)) + m[13],
+             __fmaf_rn(m[10], p.z, __fmaf_rn(m[6], p.y, m[2] * p.x)) + m[14]);
+}
+
+// one thread per global triangle id
+__global__ void __launch_bounds__(256) k_flatten(const hala_gpu_mesh_data* __restrict__ prims, const uint32_t* __restrict__ first_tri,
+                                                  uint32_t inst_count, uint32_t n, Tri* __restrict__ tris_by_id,
+                                                  uint32_t* __restrict__ tri_instance, Box6* __restrict__ tri_box,
+                                                  uint32_t* __restrict__ scene_ord /* [6] min xyz, max xyz */) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  uint32_t lo = 0, hi = inst_count;  // last instance with first_tri <= g
+  while (hi - lo > 1u) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (first_tri[mid] <= g) lo = mid; else hi = mid;
+  }
+  const hala_gpu_mesh_data& md = prims[lo];
+  const uint32_t lt = g - first_tri[lo];
+  const uint32_t* idx = reinterpret_cast<const uint32_t*>(md.indices) + 3 * (size_t)lt;
+  const hala_vertex* vb = reinterpret_cast<const hala_vertex*>(md.vertices);
+  f3 v[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) v[c] = transform_point(md.transform, ld3(vb[idx[c]].position));
+  const f3 e1 = v[1] - v[0], e2 = v[2] - v[0];
+  float4* out = reinterpret_cast<float4*>(tris_by_id + g);
+  out[0] = make_float4(v[0].x, v[0].y, v[0].z, __uint_as_float(g));
+  out[1] = make_float4(e1.x, e1.y, e1.z, 0.0f);
+  out[2] = make_float4(e2.x, e2.y, e2.z, 0.0f);
+  tri_instance[g] = lo;
+  Box6 b;
+  b.mn[0] = fminf(v[0].x, fminf(v[1].x, v[2].x)); b.mx[0] = fmaxf(v[0].x, fmaxf(v[1].x, v[2].x));
+  b.mn[1] = fminf(v[0].y, fminf(v[1].y, v[2].y)); b.mx[1] = fmaxf(v[0].y, fmaxf(v[1].y, v[2].y));
+  b.mn[2] = fminf(v[0].z, fminf(v[1].z, v[2].z)); b.mx[2] = fmaxf(v[0].z, fmaxf(v[1].z, v[2].z));
+  tri_box[g] = b;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    atomicMin(&scene_ord[k], f2ord(b.mn[k]));
+    atomicMax(&scene_ord[3 + k], f2ord(b.mx[k]));
+  }
+}
+
+RT_DI unsigned long long spread21(uint32_t v) {  // 21 bits -> every third bit
+  unsigned long long x = v & 0x1fffffull;
+  x = (x | x << 32) & 0x1f00000000ffffull;
+  x = (x | x << 16) & 0x1f0000ff0000ffull;
+  x = (x | x << 8) & 0x100f00f00f00f00full;
+  x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+  x = (x | x << 2) & 0x1249249249249249ull;
+  return x;
+}
+__global__ void __launch_bounds__(256) k_morton(const Box6* __restrict__ tri_box, uint32_t n, const uint32_t* __restrict__ scene_ord,
+                                                 unsigned long long* __restrict__ keys, uint32_t* __restrict__ ids) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  const Box6 b = tri_box[g];
+  uint32_t q[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float lo = ord2f(scene_ord[k]), hi = ord2f(scene_ord[3 + k]);
+    const float c = 0.5f * (b.mn[k] + b.mx[k]);
+    const float ext = hi - lo;
+    float t = ext > 0.0f ? (c - lo) / ext : 0.0f;
+    t = fminf(fmaxf(t, 0.0f), 1.0f);
+    q[k] = min((uint32_t)(t * 2097152.0f), 2097151u);
+  }
+  keys[g] = (spread21(q[0]) << 2) | (spread21(q[1]) << 1) | spread21(q[2]);
+  ids[g] = g;
+}
+
+// ---- Karras 2012 ------------------------------------------------------------------------------------------
+RT_DI int delta(const unsigned long long* keys, int n, int i, int j) {
+  if (j < 0 || j >= n) return -1;
+  const unsigned long long a = keys[i], b = keys[j];
+  if (a == b) return 64 + __clz((uint32_t)i ^ (uint32_t)j);
+  return __clzll((long long)(a ^ b));
+}
+// child reference in the build tree: bit 31 set = leaf (sorted position), else internal node index
+constexpr uint32_t kLeafBit = 0x80000000u;
+
+__global__ void __launch_bounds__(256) k_hierarchy(const unsigned long long* __restrict__ keys, int n, uint32_t* __restrict__ left,
+                                                    uint32_t* __restrict__ right, uint32_t* __restrict__ first, uint32_t* __restrict__ last,
+                                                    uint32_t* __restrict__ node_parent, uint32_t* __restrict__ leaf_parent) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n - 1) return;
+  const int d = (delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+  const int dmin = delta(keys, n, i, i - d);
+  int lmax = 2;
+  while (delta(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
+  int l = 0;
+  for (int t = lmax / 2; t >= 1; t /= 2)
+    if (delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+  const int j = i + l * d;
+  const int dnode = delta(keys, n, i, j);
+  int s = 0, t = l;
+  do {
+    t = (t + 1) >> 1;
+    if (delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+  } while (t > 1);
+  const int gamma = i + s * d + min(d, 0);
+  const int lo = min(i, j), hi = max(i, j);
+  const uint32_t lc = (lo == gamma) ? (kLeafBit | (uint32_t)gamma) : (uint32_t)gamma;
+  const uint32_t rc = (hi == gamma + 1) ? (kLeafBit | (uint32_t)(gamma + 1)) : (uint32_t)(gamma + 1);
+  left[i] = lc; right[i] = rc; first[i] = (uint32_t)lo; last[i] = (uint32_t)hi;
+  if (lc & kLeafBit) leaf_parent[gamma] = (uint32_t)i; else node_parent[gamma] = (uint32_t)i;
+  if (rc & kLeafBit) leaf_parent[gamma + 1] = (uint32_t)i; else node_parent[gamma + 1] = (uint32_t)i;
+  if (i == 0) node_parent[0] = kAbsent;
+}
+
+__global__ void __launch_bounds__(256) k_leaf_boxes(const Box6* __restrict__ tri_box, const uint32_t* __restrict__ sorted_ids, uint32_t n,
+                                                     Box6* __restrict__ leaf_box, const Tri* __restrict__ tris_by_id, Tri* __restrict__ tris) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const uint32_t id = sorted_ids[k];
+  leaf_box[k] = tri_box[id];
+  const float4* src = reinterpret_cast<const float4*>(tris_by_id + id);
+  float4* dst = reinterpret_cast<float4*>(tris + k);
+  dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+}
+
+RT_DI Box6 box_union(const Box6& a, const Box6& b) {
+  Box6 r;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { r.mn[k] = fminf(a.mn[k], b.mn[k]); r.mx[k] = fmaxf(a.mx[k], b.mx[k]); }
+  return r;
+}
+// bottom-up fit: the second thread to arrive at a node owns it.  Producer: stores -> __threadfence (agent release)
+// -> atomic arrival; consumer: atomic arrival -> __threadfence (agent acquire) -> loads.
+__global__ void __launch_bounds__(256) k_fit(const uint32_t* __restrict__ left, const uint32_t* __restrict__ right,
+                                              const uint32_t* __restrict__ node_parent, const uint32_t* __restrict__ leaf_parent,
+                                              const Box6* __restrict__ leaf_box, Box6* node_box, uint32_t* arrivals, uint32_t n) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  uint32_t p = leaf_parent[k];
+  while (p != kAbsent) {
+    __threadfence();
+    const uint32_t old = atomicAdd(&arrivals[p], 1u);
+    if (old == 0u) return;
+    __threadfence();
+    const uint32_t lc = left[p], rc = right[p];
+    const volatile Box6* lb = (lc & kLeafBit) ? &leaf_box[lc & ~kLeafBit] : &node_box[lc];
+    const volatile Box6* rb = (rc & kLeafBit) ? &leaf_box[rc & ~kLeafBit] : &node_box[rc];
+    Box6 a, b;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { a.mn[c] = lb->mn[c]; a.mx[c] = lb->mx[c]; b.mn[c] = rb->mn[c]; b.mx[c] = rb->mx[c]; }
+    const Box6 u = box_union(a, b);
+    volatile Box6* o = &node_box[p];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { o->mn[c] = u.mn[c]; o->mx[c] = u.mx[c]; }
+    p = node_parent[p];
+  }
+}
+
+__global__ void __launch_bounds__(256) k_keep_flags(const uint32_t* __restrict__ first, const uint32_t* __restrict__ last, uint32_t n_internal,
+                                                     uint32_t leaf_max, uint32_t* __restrict__ keep) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_internal) return;
+  keep[i] = (last[i] - first[i] + 1u) > leaf_max ? 1u : 0u;
+}
+
+__global__ void __launch_bounds__(256) k_emit(const uint32_t* __restrict__ left, const uint32_t* __restrict__ right,
+                                               const uint32_t* __restrict__ first, const uint32_t* __restrict__ last,
+                                               const uint32_t* __restrict__ keep, const uint32_t* __restrict__ new_index,
+                                               const Box6* __restrict__ leaf_box, const Box6* __restrict__ node_box, uint32_t n_internal,
+                                               BvhNode* __restrict__ nodes) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_internal || !keep[i]) return;
+  BvhNode nd;
+  uint32_t refs[2] = {left[i], right[i]};
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const uint32_t r = refs[c];
+    Box6 b;
+    uint32_t child, count;
+    if (r & kLeafBit) { b = leaf_box[r & ~kLeafBit]; child = r & ~kLeafBit; count = 1u; }
+    else {
+      b = node_box[r];
+      if (keep[r]) { child = new_index[r]; count = 0u; }
+      else { child = first[r]; count = last[r] - first[r] + 1u; }
+    }
+    float* mn = c == 0 ? nd.c0min : nd.c1min;
+    float* mx = c == 0 ? nd.c0max : nd.c1max;
+    for (int k = 0; k < 3; ++k) { mn[k] = b.mn[k]; mx[k] = b.mx[k]; }
+    if (c == 0) { nd.child0 = child; nd.count0 = count; } else { nd.child1 = child; nd.count1 = count; }
+  }
+  nodes[new_index[i]] = nd;
+}
+
+// scene of <= leaf_max triangles: one root node with a single leaf child
+__global__ void k_emit_single(const Box6* __restrict__ leaf_box, uint32_t n, BvhNode* __restrict__ nodes) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  BvhNode nd{};
+  Box6 b{};
+  if (n > 0) {
+    b = leaf_box[0];
+    for (uint32_t k = 1; k < n; ++k) b = box_union(b, leaf_box[k]);
+    nd.child0 = 0; nd.count0 = n;
+  } else { nd.child0 = kAbsent; nd.count0 = 0; }
+  for (int k = 0; k < 3; ++k) { nd.c0min[k] = b.mn[k]; nd.c0max[k] = b.mx[k]; nd.c1min[k] = 0.0f; nd.c1max[k] = 0.0f; }
+  nd.child1 = kAbsent; nd.count1 = 0;
+  nodes[0] = nd;
+}
+
+__global__ void __launch_bounds__(256) k_depth(const uint32_t* __restrict__ node_parent, const uint32_t* __restrict__ keep, uint32_t n_internal,
+                                                uint32_t* __restrict__ max_depth) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_internal || !keep[i]) return;
+  uint32_t d = 1, p = node_parent[i];
+  while (p != kAbsent) { ++d; p = node_parent[p]; }
+  atomicMax(max_depth, d);
+}
+
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  std::string alloc(size_t bytes) { HIP_TRY(hipMalloc(&p, bytes ? bytes : 16)); return ""; }
+  template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+inline uint32_t nblk(uint32_t n) { return (n + 255u) / 256u; }
+
+}  // namespace
+
+// Persistent topology kept for refit.
+struct BvhTopology {
+  uint32_t n = 0, leaf_max = 0;
+  DevBuf left, right, first, last, node_parent, leaf_parent, keep, new_index, sorted_ids, tri_box, leaf_box, node_box, arrivals, scene_ord;
+};
+
+static std::string flatten_and_bounds(BvhBuffers& b, BvhTopology& t, hipStream_t s) {
+  const uint32_t n = b.tri_count;
+  static const uint32_t init_ord[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+  HIP_TRY(hipMemcpyAsync(t.scene_ord.p, init_ord, sizeof(init_ord), hipMemcpyHostToDevice, s));
+  if (n) hipLaunchKernelGGL(k_flatten, dim3(nblk(n)), dim3(256), 0, s, b.primitives, b.inst_first_tri, b.instance_count, n, b.tris_by_id,
+                            b.tri_instance, t.tri_box.as<Box6>(), t.scene_ord.as<uint32_t>());
+  uint32_t ord[6];
+  HIP_TRY(hipMemcpyAsync(ord, t.scene_ord.p, sizeof(ord), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  for (int k = 0; k < 3; ++k) {
+    b.scene_min[k] = n ? ord2f(ord[k]) : 0.0f;
+    b.scene_max[k] = n ? ord2f(ord[3 + k]) : 0.0f;
+  }
+  return "";
+}
+
+static std::string fit_and_emit(BvhBuffers& b, BvhTopology& t, hipStream_t s) {
+  const uint32_t n = b.tri_count;
+  if (n) hipLaunchKernelGGL(k_leaf_boxes, dim3(nblk(n)), dim3(256), 0, s, t.tri_box.as<Box6>(), t.sorted_ids.as<uint32_t>(), n,
+                            t.leaf_box.as<Box6>(), b.tris_by_id, b.tris);
+  if (n <= t.leaf_max || n < 2) {
+    hipLaunchKernelGGL(k_emit_single, dim3(1), dim3(64), 0, s, t.leaf_box.as<Box6>(), n, b.nodes);
+    b.node_count = 1;
+    b.max_depth = 1;
+    HIP_TRY(hipStreamSynchronize(s));
+    return "";
+  }
+  const uint32_t ni = n - 1;
+  HIP_TRY(hipMemsetAsync(t.arrivals.p, 0, (size_t)ni * 4, s));
+  hipLaunchKernelGGL(k_fit, dim3(nblk(n)), dim3(256), 0, s, t.left.as<uint32_t>(), t.right.as<uint32_t>(), t.node_parent.as<uint32_t>(),
+                     t.leaf_parent.as<uint32_t>(), t.leaf_box.as<Box6>(), t.node_box.as<Box6>(), t.arrivals.as<uint32_t>(), n);
+  hipLaunchKernelGGL(k_emit, dim3(nblk(ni)), dim3(256), 0, s, t.left.as<uint32_t>(), t.right.as<uint32_t>(), t.first.as<uint32_t>(),
+                     t.last.as<uint32_t>(), t.keep.as<uint32_t>(), t.new_index.as<uint32_t>(), t.leaf_box.as<Box6>(), t.node_box.as<Box6>(), ni,
+                     b.nodes);
+  HIP_TRY(hipStreamSynchronize(s));
+  HIP_TRY(hipGetLastError());
+  return "";
+}
+
+void bvh_free_topology(void* topo) { delete static_cast<BvhTopology*>(topo); }
+
+std::string bvh_build(BvhBuffers& b, uint32_t leaf_max, hipStream_t s) {
+  const uint32_t n = b.tri_count;
+  if (b.topology) { bvh_free_topology(b.topology); b.topology = nullptr; }
+  BvhTopology* tp = new BvhTopology();
+  b.topology = tp;
+  BvhTopology& t = *tp;
+  t.n = n; t.leaf_max = leaf_max;
+  std::string e;
+  const size_t ni = n > 1 ? n - 1 : 1;
+#define ALLOC(buf, bytes) if (!(e = t.buf.alloc(bytes)).empty()) return e
+  ALLOC(left, ni * 4); ALLOC(right, ni * 4); ALLOC(first, ni * 4); ALLOC(last, ni * 4); ALLOC(node_parent, ni * 4);
+  ALLOC(leaf_parent, (size_t)n * 4); ALLOC(keep, ni * 4); ALLOC(new_index, ni * 4); ALLOC(sorted_ids, (size_t)n * 4);
+  ALLOC(tri_box, (size_t)n * sizeof(Box6)); ALLOC(leaf_box, (size_t)n * sizeof(Box6)); ALLOC(node_box, ni * sizeof(Box6));
+  ALLOC(arrivals, ni * 4); ALLOC(scene_ord, 6 * 4);
+#undef ALLOC
+  if (!(e = flatten_and_bounds(b, t, s)).empty()) return e;
+  if (n >= 2) {
+    DevBuf keys_in, keys_out, ids_in, tmp;
+    if (!(e = keys_in.alloc((size_t)n * 8)).empty()) return e;
+    if (!(e = keys_out.alloc((size_t)n * 8)).empty()) return e;
+    if (!(e = ids_in.alloc((size_t)n * 4)).empty()) return e;
+    hipLaunchKernelGGL(k_morton, dim3(nblk(n)), dim3(256), 0, s, t.tri_box.as<Box6>(), n, t.scene_ord.as<uint32_t>(),
+                       keys_in.as<unsigned long long>(), ids_in.as<uint32_t>());
+    size_t tmp_bytes = 0;
+    HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in.as<unsigned long long>(), keys_out.as<unsigned long long>(),
+                                      ids_in.as<uint32_t>(), t.sorted_ids.as<uint32_t>(), n, 0, 64, s));
+    if (!(e = tmp.alloc(tmp_bytes)).empty()) return e;
+    HIP_TRY(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, keys_in.as<unsigned long long>(), keys_out.as<unsigned long long>(),
+                                      ids_in.as<uint32_t>(), t.sorted_ids.as<uint32_t>(), n, 0, 64, s));
+    hipLaunchKernelGGL(k_hierarchy, dim3(nblk(n - 1)), dim3(256), 0, s, keys_out.as<unsigned long long>(), (int)n, t.left.as<uint32_t>(),
+                       t.right.as<uint32_t>(), t.first.as<uint32_t>(), t.last.as<uint32_t>(), t.node_parent.as<uint32_t>(),
+                       t.leaf_parent.as<uint32_t>());
+    hipLaunchKernelGGL(k_keep_flags, dim3(nblk(n - 1)), dim3(256), 0, s, t.first.as<uint32_t>(), t.last.as<uint32_t>(), n - 1, leaf_max,
+                       t.keep.as<uint32_t>());
+    DevBuf tmp2;
+    size_t tmp2_bytes = 0;
+    HIP_TRY(rocprim::exclusive_scan(nullptr, tmp2_bytes, t.keep.as<uint32_t>(), t.new_index.as<uint32_t>(), 0u, n - 1, rocprim::plus<uint32_t>(), s));
+    if (!(e = tmp2.alloc(tmp2_bytes)).empty()) return e;
+    HIP_TRY(rocprim::exclusive_scan(tmp2.p, tmp2_bytes, t.keep.as<uint32_t>(), t.new_index.as<uint32_t>(), 0u, n - 1, rocprim::plus<uint32_t>(), s));
+    // node count = new_index[last] + keep[last]; depth over kept nodes
+    DevBuf md;
+    if (!(e = md.alloc(4)).empty()) return e;
+    HIP_TRY(hipMemsetAsync(md.p, 0, 4, s));
+    hipLaunchKernelGGL(k_depth, dim3(nblk(n - 1)), dim3(256), 0, s, t.node_parent.as<uint32_t>(), t.keep.as<uint32_t>(), n - 1, md.as<uint32_t>());
+    uint32_t last_idx = 0, last_keep = 0, depth = 0;
+    HIP_TRY(hipMemcpyAsync(&last_idx, t.new_index.as<uint32_t>() + (n - 2), 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&last_keep, t.keep.as<uint32_t>() + (n - 2), 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&depth, md.p, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    b.node_count = last_idx + last_keep;
+    b.max_depth = depth;
+    if (n <= leaf_max) { b.node_count = 1; b.max_depth = 1; }
+  } else if (n == 1) {
+    static const uint32_t zero = 0;
+    HIP_TRY(hipMemcpyAsync(t.sorted_ids.p, &zero, 4, hipMemcpyHostToDevice, s));
+  }
+  if (!(e = fit_and_emit(b, t, s)).empty()) return e;
+  return "";
+}
+
+std::string bvh_refit(BvhBuffers& b, hipStream_t s) {
+  if (!b.topology) return "bvh_refit: no BVH has been built";
+  BvhTopology& t = *static_cast<BvhTopology*>(b.topology);
+  if (t.n != b.tri_count) return "bvh_refit: triangle count changed, rebuild required";
+  std::string e;
+  if (!(e = flatten_and_bounds(b, t, s)).empty()) return e;
+  const uint32_t nc = b.node_count, md = b.max_depth;
+  if (!(e = fit_and_emit(b, t, s)).empty()) return e;
+  if (b.tri_count > t.leaf_max && b.tri_count >= 2) { b.node_count = nc; b.max_depth = md; }
+  return "";
+}
+
+}  // namespace rt

@@ -1,0 +1,116 @@
+// hala_types.h — record layouts shared by the host code and the HIP kernels of libhalart.so.
+//
+// The hala_* records are the reference's #[repr(C)] device structs (cited in include/halart.h); the
+// static_asserts pin the byte sizes SURVEY.md §8a verified.  The rt:: records are this library's own
+// HBM formats (DESIGN.md "Data layout in HBM").
+#pragma once
+#include <hip/hip_vector_types.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "../../include/halart.h"
+
+static_assert(sizeof(hala_vertex) == 44, "HalaVertex is 44 B (src/scene/vertex.rs:2-9)");
+static_assert(sizeof(hala_gpu_camera) == 80, "gpu::HalaCamera is 80 B (src/scene/gpu/camera.rs:10-20)");
+static_assert(offsetof(hala_gpu_camera, forward) == 48 && offsetof(hala_gpu_camera, yfov) == 60 && offsetof(hala_gpu_camera, type) == 72, "HalaCamera offsets");
+static_assert(sizeof(hala_gpu_light) == 80, "gpu::HalaLight is 80 B (src/scene/gpu/light.rs:7-32)");
+static_assert(offsetof(hala_gpu_light, v) == 48 && offsetof(hala_gpu_light, radius) == 60 && offsetof(hala_gpu_light, type) == 68, "HalaLight offsets");
+static_assert(sizeof(hala_aabb) == 24, "HalaAABB is 24 B");
+static_assert(sizeof(hala_gpu_material) == 144, "gpu::HalaMaterial is 144 B (src/scene/gpu/material.rs:6-48)");
+static_assert(offsetof(hala_gpu_material, base_color) == 32 && offsetof(hala_gpu_material, ior) == 112 && offsetof(hala_gpu_material, type) == 140, "HalaMaterial offsets");
+static_assert(sizeof(hala_gpu_mesh_data) == 96, "gpu::HalaMeshData is 96 B (src/scene/gpu/mesh.rs:32-39)");
+static_assert(offsetof(hala_gpu_mesh_data, material_index) == 64 && offsetof(hala_gpu_mesh_data, vertices) == 72 && offsetof(hala_gpu_mesh_data, indices) == 80, "HalaMeshData offsets");
+static_assert(sizeof(hala_global_uniform) == 112, "HalaGlobalUniform is 112 B (src/rt_renderer.rs:44-65)");
+static_assert(offsetof(hala_global_uniform, resolution) == 32 && offsetof(hala_global_uniform, frame_index) == 48 && offsetof(hala_global_uniform, env_total_sum) == 68 && offsetof(hala_global_uniform, num_of_lights) == 96, "HalaGlobalUniform offsets");
+static_assert(sizeof(hala_ray) == 32 && sizeof(hala_hit) == 16, "ray batch records");
+
+namespace rt {
+
+constexpr uint32_t kAbsent = 0xffffffffu;
+constexpr float kTMax = 3.402823466e+38f;
+
+// 64-B BVH2 node (docs/RENDER_SPEC.md §4.1): both child boxes, two child refs, two counts.
+// count == 0 -> `child` is a node index; count > 0 -> `child` is the first triangle of a leaf (BVH order);
+// child == kAbsent && count == 0 -> no child.
+struct alignas(16) BvhNode {
+  float c0min[3], c0max[3], c1min[3], c1max[3];
+  uint32_t child0, child1, count0, count1;
+};
+static_assert(sizeof(BvhNode) == 64, "BVH node is 64 B");
+
+// 48-B triangle (RENDER_SPEC §4.1): v0|global id, e1 = v1-v0, e2 = v2-v0 in world space.
+struct alignas(16) Tri {
+  float v0[3]; uint32_t id;
+  float e1[3]; uint32_t pad1;
+  float e2[3]; uint32_t pad2;
+};
+static_assert(sizeof(Tri) == 48, "triangle is 48 B");
+
+// What every kernel of one update() sees (the "descriptor sets" of src/rt_renderer.rs:141-209, :671-745 as
+// plain device pointers).
+struct SceneView {
+  const BvhNode* nodes;
+  const Tri* tris;             // BVH order
+  const Tri* tris_by_id;       // global-id order (for shading)
+  const uint32_t* tri_instance;  // global id -> instance
+  const uint32_t* inst_first_tri;
+  const hala_gpu_mesh_data* primitives;  // set 1 binding 4
+  const hala_gpu_material* materials;    // set 1 binding 3
+  const hala_gpu_light* lights;          // set 1 binding 2
+  const hala_gpu_camera* cameras;        // set 1 binding 1
+  const float* env_pixels;       // RGBA32F (set 0 binding 6)
+  const float* env_marginal;     // set 0 binding 7[0]
+  const float* env_conditional;  // set 0 binding 7[1]
+  uint32_t node_count, tri_count, lds_nodes, lds_tris;
+  float ray_eps;
+};
+
+// per-update constants derived on the host from HalaGlobalUniform + camera 0 (RENDER_SPEC §5)
+struct FrameConst {
+  hala_global_uniform u;  // the 112-B record itself (src/rt_renderer.rs:408-427)
+  float aspect, tan_half;
+  uint32_t width, height;
+  // pixel-tile sharding (RENDER_SPEC §9)
+  uint32_t tile_size, tiles_x, tiles_y, world, rank, tiles_per_rank, perm_a, perm_b;
+  uint32_t slot_count;  // number of pixel slots this rank renders
+};
+
+// device control block: queue sizes and work counters of the wavefront loop.  One slot per bounce, so a single
+// hipMemsetAsync per update() resets everything and no kernel has to clear a counter another one still reads.
+constexpr uint32_t kMaxDepth = 64;
+struct Control {
+  uint32_t n_active[kMaxDepth + 1];  // ray-queue size entering bounce d
+  uint32_t n_shadow[kMaxDepth];      // shadow work items produced by bounce d
+  uint32_t work_closest[kMaxDepth];  // persistent-kernel work counters
+  uint32_t work_shadow[kMaxDepth];
+  uint32_t work_batch;               // work counter of the stand-alone ray-batch operator
+  uint32_t pad[2];
+  unsigned long long rays_closest, rays_shadow;   // totals of this update
+  unsigned long long nodes_visited, tris_tested;  // only filled by counting launches
+};
+
+// wavefront path state, SoA, indexed by pixel slot
+struct PathState {
+  float4* throughput_pdf;  // T.xyz, pdf of the last BSDF sample
+  float4* radiance_rng;    // L.xyz, rng counter (bits)
+  float4* albedo;          // first-hit AOVs of this sample
+  float4* normal;
+};
+
+struct ShadowEntry {  // 64 B: one NEE connection
+  hala_ray ray;
+  float contrib[3];
+  uint32_t slot;
+  uint32_t pad[4];
+};
+
+struct Queues {
+  hala_ray* rays[2];
+  uint32_t* slots[2];
+  hala_hit* hits;
+  ShadowEntry* shadow;  // 2 per path slot: [2*q] light, [2*q+1] environment (ray.tmax < 0: unused)
+  uint32_t* shadow_list;  // compact list of path-queue indices q that own >= 1 shadow ray
+};
+
+}  // namespace rt

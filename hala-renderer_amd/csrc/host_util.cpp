@@ -1,0 +1,288 @@
+// host_util.cpp — error channel, JSON reader, and the host half of save_images / set_envmap:
+// tonemap operators and PFM writer (src/rt_renderer.rs:1256-1334), Radiance .hdr / .pfm decoding for
+// EnvMap::new_with_file (src/envmap.rs:48-60; the reference decodes through the `image` crate).
+#include "host_util.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "hala_types.h"
+#include "host_image.h"
+
+namespace rt {
+
+static thread_local std::string g_last_error;
+void set_last_error(const std::string& msg) { g_last_error = msg; }
+const char* get_last_error() { return g_last_error.c_str(); }
+
+// ---- JSON ---------------------------------------------------------------------------------------------------
+namespace {
+struct JsonParser {
+  const char* s;
+  size_t i = 0;
+  std::string err;
+  void ws() { while (s[i] == ' ' || s[i] == '\t' || s[i] == '\n' || s[i] == '\r') ++i; }
+  bool fail(const std::string& m) { if (err.empty()) err = m + " at byte " + std::to_string(i); return false; }
+  bool parse_string(std::string* out) {
+    if (s[i] != '"') return fail("expected string");
+    ++i;
+    out->clear();
+    while (s[i] && s[i] != '"') {
+      if (s[i] == '\\') {
+        ++i;
+        switch (s[i]) {
+          case '"': out->push_back('"'); break;
+          case '\\': out->push_back('\\'); break;
+          case '/': out->push_back('/'); break;
+          case 'b': out->push_back('\b'); break;
+          case 'f': out->push_back('\f'); break;
+          case 'n': out->push_back('\n'); break;
+          case 'r': out->push_back('\r'); break;
+          case 't': out->push_back('\t'); break;
+          case 'u': {
+            unsigned cp = 0;
+            for (int k = 1; k <= 4; ++k) {
+              char c = s[i + k];
+              cp <<= 4;
+              if (c >= '0' && c <= '9') cp |= c - '0';
+              else if (c >= 'a' && c <= 'f') cp |= c - 'a' + 10;
+              else if (c >= 'A' && c <= 'F') cp |= c - 'A' + 10;
+              else return fail("bad \\u escape");
+            }
+            i += 4;
+            if (cp < 0x80) out->push_back((char)cp);
+            else if (cp < 0x800) { out->push_back((char)(0xC0 | (cp >> 6))); out->push_back((char)(0x80 | (cp & 0x3F))); }
+            else { out->push_back((char)(0xE0 | (cp >> 12))); out->push_back((char)(0x80 | ((cp >> 6) & 0x3F))); out->push_back((char)(0x80 | (cp & 0x3F))); }
+            break;
+          }
+          default: return fail("bad escape");
+        }
+        ++i;
+      } else out->push_back(s[i++]);
+    }
+    if (s[i] != '"') return fail("unterminated string");
+    ++i;
+    return true;
+  }
+  bool parse_value(JsonValue* v, int depth) {
+    if (depth > 64) return fail("nesting too deep");
+    ws();
+    const char c = s[i];
+    if (c == '{') {
+      v->kind = JsonValue::Object;
+      ++i; ws();
+      if (s[i] == '}') { ++i; return true; }
+      for (;;) {
+        ws();
+        std::string key;
+        if (!parse_string(&key)) return false;
+        ws();
+        if (s[i] != ':') return fail("expected ':'");
+        ++i;
+        JsonValue child;
+        if (!parse_value(&child, depth + 1)) return false;
+        v->members.emplace_back(std::move(key), std::move(child));
+        ws();
+        if (s[i] == ',') { ++i; continue; }
+        if (s[i] == '}') { ++i; return true; }
+        return fail("expected ',' or '}'");
+      }
+    }
+    if (c == '[') {
+      v->kind = JsonValue::Array;
+      ++i; ws();
+      if (s[i] == ']') { ++i; return true; }
+      for (;;) {
+        JsonValue child;
+        if (!parse_value(&child, depth + 1)) return false;
+        v->items.push_back(std::move(child));
+        ws();
+        if (s[i] == ',') { ++i; continue; }
+        if (s[i] == ']') { ++i; return true; }
+        return fail("expected ',' or ']'");
+      }
+    }
+    if (c == '"') { v->kind = JsonValue::String; return parse_string(&v->str); }
+    if (!strncmp(s + i, "true", 4)) { v->kind = JsonValue::Bool; v->b = true; i += 4; return true; }
+    if (!strncmp(s + i, "false", 5)) { v->kind = JsonValue::Bool; v->b = false; i += 5; return true; }
+    if (!strncmp(s + i, "null", 4)) { v->kind = JsonValue::Null; i += 4; return true; }
+    if (c == '-' || (c >= '0' && c <= '9')) {
+      char* end = nullptr;
+      v->num = strtod(s + i, &end);
+      if (end == s + i) return fail("bad number");
+      v->kind = JsonValue::Number;
+      i = (size_t)(end - s);
+      return true;
+    }
+    return fail("unexpected character");
+  }
+};
+}  // namespace
+
+std::string json_parse(const char* text, JsonValue* out) {
+  JsonParser p{text};
+  if (!p.parse_value(out, 0)) return p.err;
+  p.ws();
+  if (text[p.i] != 0) return "trailing characters at byte " + std::to_string(p.i);
+  return "";
+}
+
+// ---- tonemap: src/rt_renderer.rs:1256-1316 (host side, applied by save_images to the accum read-back) --------------
+namespace {
+struct C3 { float x, y, z; };
+inline float lum709(C3 c) { return 0.212671f * c.x + 0.715160f * c.y + 0.072169f * c.z; }  // :1257-1259
+inline float clamp01f(float v) { return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); }
+inline C3 clamp01(C3 c) { return C3{clamp01f(c.x), clamp01f(c.y), clamp01f(c.z)}; }
+inline C3 mat3(const float c0[3], const float c1[3], const float c2[3], C3 v) {  // glam Mat3 * Vec3
+  return C3{c0[0] * v.x + c1[0] * v.y + c2[0] * v.z, c0[1] * v.x + c1[1] * v.y + c2[1] * v.z, c0[2] * v.x + c1[2] * v.y + c2[2] * v.z};
+}
+inline float fit1(float v) {  // rrt_odt_fit :1260-1264, per channel
+  const float a = v * (v + 0.0245786f) - 0.000090537f;
+  const float b = v * (0.983729f * v + 0.432951f) + 0.238081f;
+  return a / b;
+}
+inline C3 aces_fitted(C3 c) {  // :1265-1281
+  static const float i0[3] = {0.59719f, 0.07600f, 0.02840f}, i1[3] = {0.35458f, 0.90834f, 0.13383f}, i2[3] = {0.04823f, 0.01566f, 0.83777f};
+  static const float o0[3] = {1.60475f, -0.10208f, -0.00327f}, o1[3] = {-0.53108f, 1.10813f, -0.07276f}, o2[3] = {-0.07367f, -0.00605f, 1.07602f};
+  c = mat3(i0, i1, i2, c);
+  c = C3{fit1(c.x), fit1(c.y), fit1(c.z)};
+  c = mat3(o0, o1, o2, c);
+  return clamp01(c);
+}
+inline float aces1(float c) {  // :1282-1291, per channel
+  return (c * (2.51f * c + 0.03f)) / (c * (2.43f * c + 0.59f) + 0.14f);
+}
+}  // namespace
+
+void tonemap_pixels(float* rgba, size_t count, int enable_tonemap, int enable_aces, int use_simple_aces) {
+  if (!enable_tonemap) return;  // :1299-1311
+  for (size_t i = 0; i < count; ++i) {
+    C3 c{rgba[4 * i], rgba[4 * i + 1], rgba[4 * i + 2]};
+    if (enable_aces) {
+      if (use_simple_aces) c = clamp01(C3{aces1(c.x), aces1(c.y), aces1(c.z)});
+      else c = aces_fitted(c);
+    } else {
+      const float d = 1.0f + lum709(c) / 1.5f;  // tonemap(c, 1.5) = c * 1.0 / (1.0 + luminance(c) / limit)  :1292-1294
+      c = C3{(c.x * 1.0f) / d, (c.y * 1.0f) / d, (c.z * 1.0f) / d};
+    }
+    rgba[4 * i] = c.x; rgba[4 * i + 1] = c.y; rgba[4 * i + 2] = c.z;
+  }
+}
+
+// ---- PFM writer: src/rt_renderer.rs:1318-1334 ------------------------------------------------------------------------
+std::string write_pfm(const char* path, const float* rgba, uint32_t width, uint32_t height) {
+  FILE* f = fopen(path, "wb");
+  if (!f) return std::string("Failed to create the image file: \"") + path + "\"";
+  fprintf(f, "PF\n%u %u\n-1.0\n", width, height);  // writeln!("PF\n{} {}\n-1.0")
+  std::vector<float> row((size_t)width * 3);
+  for (uint32_t y = height; y-- > 0;) {  // rows bottom-to-top (.rev())
+    for (uint32_t x = 0; x < width; ++x) memcpy(&row[3 * (size_t)x], rgba + 4 * ((size_t)y * width + x), 12);  // little-endian host
+    if (fwrite(row.data(), 4, row.size(), f) != row.size()) { fclose(f); return std::string("Failed to write the image file: \"") + path + "\""; }
+  }
+  if (fclose(f) != 0) return std::string("Failed to flush the image file: \"") + path + "\"";
+  return "";
+}
+
+// ---- decoders for set_envmap_file ---------------------------------------------------------------------------------------
+static bool read_line(FILE* f, std::string* line) {
+  line->clear();
+  int c;
+  while ((c = fgetc(f)) != EOF) {
+    if (c == '\n') return true;
+    line->push_back((char)c);
+    if (line->size() > 4096) return false;
+  }
+  return !line->empty();
+}
+
+static std::string load_pfm(FILE* f, HostImage* img) {
+  std::string l1, l2, l3;
+  if (!read_line(f, &l1) || !read_line(f, &l2) || !read_line(f, &l3)) return "truncated PFM header";
+  const int ch = l1 == "PF" ? 3 : (l1 == "Pf" ? 1 : 0);
+  if (!ch) return "not a PFM file";
+  unsigned w = 0, h = 0;
+  if (sscanf(l2.c_str(), "%u %u", &w, &h) != 2 || !w || !h) return "bad PFM dimensions";
+  const double scale = atof(l3.c_str());
+  if (scale >= 0.0) return "big-endian PFM is not supported";
+  img->width = w; img->height = h; img->channels = 3;
+  img->pixels.assign((size_t)w * h * 3, 0.0f);
+  std::vector<float> row((size_t)w * ch);
+  for (unsigned y = h; y-- > 0;) {  // PFM stores rows bottom-to-top
+    if (fread(row.data(), 4, row.size(), f) != row.size()) return "truncated PFM data";
+    for (unsigned x = 0; x < w; ++x)
+      for (int c = 0; c < 3; ++c) img->pixels[((size_t)y * w + x) * 3 + c] = row[(size_t)x * ch + (ch == 3 ? c : 0)];
+  }
+  return "";
+}
+
+static std::string load_hdr(FILE* f, HostImage* img) {
+  std::string line;
+  bool fmt_ok = false;
+  if (!read_line(f, &line) || (line.rfind("#?", 0) != 0)) return "not a Radiance HDR file";
+  for (;;) {
+    if (!read_line(f, &line)) { if (feof(f)) return "truncated HDR header"; }
+    if (line.empty()) break;
+    if (line == "FORMAT=32-bit_rle_rgbe") fmt_ok = true;
+  }
+  if (!fmt_ok) return "unsupported HDR pixel format";
+  if (!read_line(f, &line)) return "missing HDR resolution line";
+  int w = 0, h = 0;
+  if (sscanf(line.c_str(), "-Y %d +X %d", &h, &w) != 2 || w <= 0 || h <= 0) return "unsupported HDR orientation";
+  img->width = (uint32_t)w; img->height = (uint32_t)h; img->channels = 3;
+  img->pixels.assign((size_t)w * h * 3, 0.0f);
+  std::vector<unsigned char> scan((size_t)w * 4);
+  for (int y = 0; y < h; ++y) {
+    unsigned char hd[4];
+    if (fread(hd, 1, 4, f) != 4) return "truncated HDR data";
+    if (hd[0] == 2 && hd[1] == 2 && !(hd[2] & 0x80) && ((hd[2] << 8) | hd[3]) == w && w >= 8 && w < 32768) {
+      for (int c = 0; c < 4; ++c) {  // new-style RLE, channel-planar per scanline
+        int x = 0;
+        while (x < w) {
+          int cnt = fgetc(f);
+          if (cnt == EOF) return "truncated HDR data";
+          if (cnt > 128) {
+            cnt -= 128;
+            const int val = fgetc(f);
+            if (val == EOF || x + cnt > w) return "corrupt HDR run";
+            while (cnt--) scan[(size_t)(x++) * 4 + c] = (unsigned char)val;
+          } else {
+            if (cnt == 0 || x + cnt > w) return "corrupt HDR run";
+            while (cnt--) { const int val = fgetc(f); if (val == EOF) return "truncated HDR data"; scan[(size_t)(x++) * 4 + c] = (unsigned char)val; }
+          }
+        }
+      }
+    } else {  // flat scanline
+      memcpy(scan.data(), hd, 4);
+      if (w > 1 && fread(scan.data() + 4, 4, (size_t)w - 1, f) != (size_t)w - 1) return "truncated HDR data";
+    }
+    for (int x = 0; x < w; ++x) {
+      const unsigned char* p = &scan[(size_t)x * 4];
+      float* o = &img->pixels[((size_t)y * w + x) * 3];
+      if (p[3] == 0) { o[0] = o[1] = o[2] = 0.0f; }
+      else {
+        const float sc = std::ldexp(1.0f, (int)p[3] - (128 + 8));  // image-rs hdr decoder: mantissa * 2^(e-136)
+        o[0] = (float)p[0] * sc; o[1] = (float)p[1] * sc; o[2] = (float)p[2] * sc;
+      }
+    }
+  }
+  return "";
+}
+
+std::string load_float_image(const char* path, HostImage* img) {
+  FILE* f = fopen(path, "rb");
+  if (!f) return std::string("Failed to open image \"") + path + "\".";  // src/envmap.rs:49
+  unsigned char magic[2] = {0, 0};
+  const size_t got = fread(magic, 1, 2, f);
+  rewind(f);
+  std::string e;
+  if (got == 2 && magic[0] == 'P' && (magic[1] == 'F' || magic[1] == 'f')) e = load_pfm(f, img);
+  else if (got == 2 && magic[0] == '#' && magic[1] == '?') e = load_hdr(f, img);
+  else e = "unrecognised format";
+  fclose(f);
+  if (!e.empty()) return std::string("Failed to decode image \"") + path + "\". (" + e + ")";  // src/envmap.rs:53
+  return "";
+}
+
+}  // namespace rt

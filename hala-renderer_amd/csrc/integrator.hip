@@ -1,0 +1,378 @@
+// integrator.hip — the wavefront path tracer of libhalart.so: everything the reference gets from
+// `trace_rays(width, height, 1)` (src/rt_renderer.rs:458-464), as HIP kernels for gfx950.
+//
+// One update() = one sample per pixel =
+//   raygen -> for each bounce { traverse_closest -> shade (+ballot compaction) -> traverse_shadow } -> resolve
+// All queue sizes live in a device control block; nothing returns to the host inside a frame.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "kernels.h"
+#include "shading.h"
+#include "traverse.h"
+
+namespace rt {
+
+// wave64 helpers ------------------------------------------------------------------------------------------
+RT_DI uint32_t lane_id() { return threadIdx.x & 63u; }
+// Ordered compaction inside one wave: returns this lane's output index (base comes from one atomic per wave).
+RT_DI uint32_t wave_compact(bool keep, uint32_t* counter) {
+  const unsigned long long mask = __ballot(keep);
+  const uint32_t total = (uint32_t)__popcll(mask);
+  uint32_t base = 0;
+  if (total) {
+    if (lane_id() == 0u) base = atomicAdd(counter, total);
+    base = (uint32_t)__shfl((int)base, 0);
+  }
+  const uint32_t before = (uint32_t)__popcll(mask & ((1ull << lane_id()) - 1ull));
+  return base + before;
+}
+RT_DI uint32_t wave_sum(uint32_t v) {
+  for (int off = 32; off > 0; off >>= 1) v += (uint32_t)__shfl_down((int)v, off);
+  return v;  // valid in lane 0
+}
+
+extern __shared__ __attribute__((aligned(16))) unsigned char g_smem[];
+
+// ---------------------------------------------------------------------------------------------------------
+// K5a: persistent closest-hit traversal over a compact ray queue (coalesced 32-B ray reads, 16-B hit writes)
+// ---------------------------------------------------------------------------------------------------------
+template <bool ANY, bool COUNT>
+__global__ void __launch_bounds__(kTraverseThreads)
+k_trace_batch(SceneView sv, const hala_ray* __restrict__ rays, hala_hit* __restrict__ hits, const uint32_t* __restrict__ n_ptr,
+              uint32_t n_imm, uint32_t* __restrict__ work, uint32_t* __restrict__ spill_base, Control* __restrict__ ctl, int account) {
+  const TraverseLds lds = stage_bvh(sv, g_smem);
+  const uint32_t n = n_ptr ? *n_ptr : n_imm;
+  uint32_t* spill = spill_base ? spill_base + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * kStackSpill : nullptr;
+  uint32_t cn = 0, ct = 0;
+  if (account && blockIdx.x == 0 && threadIdx.x == 0) {
+    if (ANY) ctl->rays_shadow += n; else ctl->rays_closest += n;
+  }
+  for (;;) {
+    uint32_t base = 0;
+    if (lane_id() == 0u) base = atomicAdd(work, 64u);
+    base = (uint32_t)__shfl((int)base, 0);
+    if (base >= n) break;
+    const uint32_t i = base + lane_id();
+    if (i < n) {
+      const float4* rp = reinterpret_cast<const float4*>(rays + i);
+      const float4 ro = rp[0], rd = rp[1];
+      const RayPre r = make_ray(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w);
+      HitRec h;
+      const bool found = traverse<ANY, COUNT>(sv, lds, spill, r, rd.w, h, cn, ct);
+      float4 out;
+      if (ANY) out = make_float4(found ? 1.0f : -1.0f, 0.0f, 0.0f, __uint_as_float(kAbsent));
+      else out = found ? make_float4(h.t, h.u, h.v, __uint_as_float(h.prim)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(kAbsent));
+      reinterpret_cast<float4*>(hits)[i] = out;
+    }
+  }
+  if (COUNT) {
+    cn = wave_sum(cn); ct = wave_sum(ct);
+    if (lane_id() == 0u) { atomicAdd(&ctl->nodes_visited, (unsigned long long)cn); atomicAdd(&ctl->tris_tested, (unsigned long long)ct); }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K5c: shadow traversal of the NEE connections of one bounce; unoccluded contributions are added to the
+// path's radiance in the fixed order light, environment (RENDER_SPEC §6)
+// ---------------------------------------------------------------------------------------------------------
+template <bool COUNT>
+__global__ void __launch_bounds__(kTraverseThreads)
+k_trace_shadow(SceneView sv, Queues q, PathState ps, Control* __restrict__ ctl, uint32_t depth, uint32_t* __restrict__ spill_base) {
+  const TraverseLds lds = stage_bvh(sv, g_smem);
+  const uint32_t n = ctl->n_shadow[depth];
+  uint32_t* spill = spill_base ? spill_base + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * kStackSpill : nullptr;
+  uint32_t cn = 0, ct = 0;
+  for (;;) {
+    uint32_t base = 0;
+    if (lane_id() == 0u) base = atomicAdd(&ctl->work_shadow[depth], 64u);
+    base = (uint32_t)__shfl((int)base, 0);
+    if (base >= n) break;
+    const uint32_t i = base + lane_id();
+    if (i < n) {
+      const uint32_t qi = q.shadow_list[i];
+#pragma unroll 1
+      for (int k = 0; k < 2; ++k) {
+        const float4* e = reinterpret_cast<const float4*>(q.shadow + 2 * (size_t)qi + k);
+        const float4 ro = e[0], rd = e[1];
+        if (!(rd.w >= 0.0f)) continue;  // unused connection
+        const float4 cs = e[2];
+        const RayPre r = make_ray(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w);
+        HitRec h;
+        const bool occluded = traverse<true, COUNT>(sv, lds, spill, r, rd.w, h, cn, ct);
+        if (!occluded) {
+          const uint32_t slot = __float_as_uint(cs.w);
+          float4 lr = ps.radiance_rng[slot];
+          lr.x = lr.x + cs.x; lr.y = lr.y + cs.y; lr.z = lr.z + cs.z;
+          ps.radiance_rng[slot] = lr;
+        }
+      }
+    }
+  }
+  if (COUNT) {
+    cn = wave_sum(cn); ct = wave_sum(ct);
+    if (lane_id() == 0u) { atomicAdd(&ctl->nodes_visited, (unsigned long long)cn); atomicAdd(&ctl->tris_tested, (unsigned long long)ct); }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// raygen: one camera ray per pixel slot (RENDER_SPEC §5)
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_raygen(FrameConst fc, SceneView sv, Queues q, PathState ps, Control* __restrict__ ctl) {
+  const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t px = 0, py = 0;
+  const bool valid = slot < fc.slot_count && slot_to_pixel(fc, slot, &px, &py);
+  f3 o = splat3(0.0f), d = mk3(0.0f, 0.0f, 1.0f);
+  uint32_t rng = 0;
+  if (valid) {
+    rng = rng_init(py * fc.width + px, fc.u.frame_index);
+    camera_ray(fc, sv.cameras[fc.u.camera_index], px, py, rng, &o, &d);
+  }
+  if (slot < fc.slot_count) {
+    ps.throughput_pdf[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+    ps.radiance_rng[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(rng));
+    ps.albedo[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    ps.normal[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  }
+  const uint32_t qi = wave_compact(valid, &ctl->n_active[0]);
+  if (valid) {
+    float4* rp = reinterpret_cast<float4*>(q.rays[0] + qi);
+    rp[0] = make_float4(o.x, o.y, o.z, 0.0f);
+    rp[1] = make_float4(d.x, d.y, d.z, kTMax);
+    q.slots[0][qi] = slot;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// shade: closest-hit + miss + light/env NEE + BSDF sampling + Russian roulette for one bounce (RENDER_SPEC §6)
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_shade(FrameConst fc, SceneView sv, Queues q, PathState ps, Control* __restrict__ ctl, uint32_t depth) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t n = ctl->n_active[depth];
+  if ((i & ~63u) >= n) return;  // whole wave beyond the queue
+  const bool active = i < n;
+  const uint32_t in = depth & 1u, out = in ^ 1u;
+  bool alive = false, has_shadow = false;
+  uint32_t n_shadow_rays = 0;
+  f3 no = splat3(0.0f), nd = splat3(0.0f);
+  uint32_t slot = 0;
+  if (active) {
+    slot = q.slots[in][i];
+    const float4* rp = reinterpret_cast<const float4*>(q.rays[in] + i);
+    const float4 ro = rp[0], rd = rp[1];
+    const float4 hv = reinterpret_cast<const float4*>(q.hits)[i];
+    const f3 o = mk3(ro.x, ro.y, ro.z), d = mk3(rd.x, rd.y, rd.z);
+    const float4 tp = ps.throughput_pdf[slot];
+    float4 lr = ps.radiance_rng[slot];
+    f3 T = mk3(tp.x, tp.y, tp.z), L = mk3(lr.x, lr.y, lr.z);
+    float prev_pdf = tp.w;
+    uint32_t rng = __float_as_uint(lr.w);
+    const uint32_t hit_prim = __float_as_uint(hv.w);
+    const uint32_t nl = fc.u.num_of_lights;
+    const float t_surf = hit_prim != kAbsent ? hv.x : kTMax;
+    // unused connections by default
+    float4* se = reinterpret_cast<float4*>(q.shadow + 2 * (size_t)i);
+    se[1].w = -1.0f;
+    se[4 + 1].w = -1.0f;
+
+    int hit_light = -1;
+    float t_light = t_surf, light_pdf = 0.0f;
+    for (uint32_t k = 0; k < nl; ++k) {
+      float lp;
+      const float tl = intersect_light(sv.lights[k], o, d, &lp);
+      if (tl > 0.0f && tl < t_light) { t_light = tl; hit_light = (int)k; light_pdf = lp; }
+    }
+    if (hit_light >= 0) {
+      const f3 le = ld3(sv.lights[hit_light].intensity);
+      float w = 1.0f;
+      if (depth > 0u) w = power_heuristic(prev_pdf, light_pdf * (1.0f / (float)nl));
+      L = L + T * le * w;
+      if (depth == 0u) ps.albedo[slot] = make_float4(minf(le.x, 1.0f), minf(le.y, 1.0f), minf(le.z, 1.0f), 1.0f);
+    } else if (hit_prim == kAbsent) {
+      f3 env;
+      float w = 1.0f;
+      if (fc.u.env_type == 1u) {
+        env = env_map_eval(fc, sv, d);
+        if (depth > 0u) w = power_heuristic(prev_pdf, env_map_pdf(fc, sv, d));
+      } else env = sky_eval(fc, d);
+      L = L + T * env * w;
+      if (depth == 0u) ps.albedo[slot] = make_float4(minf(env.x, 1.0f), minf(env.y, 1.0f), minf(env.z, 1.0f), 1.0f);
+    } else {
+      const Surface sf = make_surface(sv, o, d, hv.x, hv.y, hv.z, hit_prim);
+      if (depth == 0u) {
+        ps.albedo[slot] = make_float4(sf.mat.base.x, sf.mat.base.y, sf.mat.base.z, 1.0f);
+        ps.normal[slot] = make_float4(sf.ns.x, sf.ns.y, sf.ns.z, 1.0f);
+      }
+      const f3 em = sf.mat.emission;
+      if (em.x > 0.0f || em.y > 0.0f || em.z > 0.0f) L = L + T * em;
+      const f3 wo = -d;
+      if (nl > 0u) {  // NEE: one light
+        const float rl = rng_next(rng), r1 = rng_next(rng), r2 = rng_next(rng);
+        const uint32_t idx = min((uint32_t)(rl * (float)nl), nl - 1u);
+        const LightSample ls = sample_light(sv.lights[idx], sf.P, r1, r2);
+        if (ls.valid) {
+          f3 fb; float pdf_b;
+          bsdf_eval(sf.mat, wo, ls.wi, sf.ns, &fb, &pdf_b);
+          if (pdf_b > 0.0f) {
+            const float side = dot3(ls.wi, sf.ng) >= 0.0f ? sv.ray_eps : -sv.ray_eps;
+            const f3 so = madd3(sf.ng, side, sf.P);
+            const float tmax = ls.dist >= kTMax ? kTMax : maxf(ls.dist - 2.0f * sv.ray_eps, 0.0f);
+            const float cosl = dot3(sf.ns, ls.wi);
+            f3 contrib;
+            if (ls.delta) contrib = fb * ls.le * (cosl * (float)nl);
+            else {
+              const float pl = ls.pdf * (1.0f / (float)nl);
+              const float w = power_heuristic(pl, pdf_b);
+              contrib = fb * ls.le * (cosl * w / pl);
+            }
+            const f3 tc = T * contrib;
+            se[0] = make_float4(so.x, so.y, so.z, 0.0f);
+            se[1] = make_float4(ls.wi.x, ls.wi.y, ls.wi.z, tmax);
+            se[2] = make_float4(tc.x, tc.y, tc.z, __uint_as_float(slot));
+            has_shadow = true; n_shadow_rays++;
+          }
+        }
+      }
+      if (fc.u.env_type == 1u) {  // NEE: environment map
+        const float r1 = rng_next(rng), r2 = rng_next(rng);
+        f3 wi; float pdf_e;
+        if (env_map_sample(fc, sv, r1, r2, &wi, &pdf_e)) {
+          f3 fb; float pdf_b;
+          bsdf_eval(sf.mat, wo, wi, sf.ns, &fb, &pdf_b);
+          if (pdf_b > 0.0f) {
+            const float side = dot3(wi, sf.ng) >= 0.0f ? sv.ray_eps : -sv.ray_eps;
+            const f3 so = madd3(sf.ng, side, sf.P);
+            const float cosl = dot3(sf.ns, wi);
+            const float w = power_heuristic(pdf_e, pdf_b);
+            const f3 col = env_map_eval(fc, sv, wi);
+            const f3 tc = T * (fb * col * (cosl * w / pdf_e));
+            se[4 + 0] = make_float4(so.x, so.y, so.z, 0.0f);
+            se[4 + 1] = make_float4(wi.x, wi.y, wi.z, kTMax);
+            se[4 + 2] = make_float4(tc.x, tc.y, tc.z, __uint_as_float(slot));
+            has_shadow = true; n_shadow_rays++;
+          }
+        }
+      }
+      // continue the path
+      const float r1 = rng_next(rng), r2 = rng_next(rng), r3 = rng_next(rng);
+      f3 wi, fb; float pdf_b;
+      if (bsdf_sample(sf.mat, wo, sf.ns, r1, r2, r3, &wi, &fb, &pdf_b)) {
+        T = T * fb * (fabsf(dot3(sf.ns, wi)) / pdf_b);
+        prev_pdf = pdf_b;
+        alive = true;
+        if (depth >= fc.u.rr_depth) {
+          const float qq = minf(max3f(T), 0.95f);
+          const float rr = rng_next(rng);
+          if (!(rr < qq)) alive = false; else T = T * (1.0f / qq);
+        }
+        if (depth + 1u >= fc.u.max_depth) alive = false;
+        if (alive) {
+          const float side = dot3(wi, sf.ng) >= 0.0f ? sv.ray_eps : -sv.ray_eps;
+          no = madd3(sf.ng, side, sf.P);
+          nd = wi;
+          ps.throughput_pdf[slot] = make_float4(T.x, T.y, T.z, prev_pdf);
+        }
+      }
+    }
+    ps.radiance_rng[slot] = make_float4(L.x, L.y, L.z, __uint_as_float(rng));
+  }
+  // ballot compaction of the surviving paths and of the paths that own shadow rays
+  const uint32_t qo = wave_compact(alive, &ctl->n_active[depth + 1u]);
+  if (alive) {
+    float4* rp = reinterpret_cast<float4*>(q.rays[out] + qo);
+    rp[0] = make_float4(no.x, no.y, no.z, 0.0f);
+    rp[1] = make_float4(nd.x, nd.y, nd.z, kTMax);
+    q.slots[out][qo] = slot;
+  }
+  const uint32_t so = wave_compact(has_shadow, &ctl->n_shadow[depth]);
+  if (has_shadow) q.shadow_list[so] = i;
+  const uint32_t ns = wave_sum(n_shadow_rays);
+  if (lane_id() == 0u && ns) atomicAdd(&ctl->rays_shadow, (unsigned long long)ns);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// resolve: fold this sample into the running means and write the tonemapped final image (RENDER_SPEC §8)
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_resolve(FrameConst fc, PathState ps, float4* __restrict__ accum, float4* __restrict__ albedo,
+                                                  float4* __restrict__ normal, float4* __restrict__ final_img) {
+  const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= fc.slot_count) return;
+  const float4 lr = ps.radiance_rng[slot];
+  f3 L = mk3(lr.x, lr.y, lr.z);
+  if (!(isfinite(L.x) && isfinite(L.y) && isfinite(L.z))) L = splat3(0.0f);
+  const uint32_t fi = fc.u.frame_index;
+  const float4 a0 = accum[slot], b0 = albedo[slot], n0 = normal[slot];
+  const float4 sa = ps.albedo[slot], sn = ps.normal[slot];
+  const float4 a1 = make_float4(fold_mean(a0.x, L.x, fi), fold_mean(a0.y, L.y, fi), fold_mean(a0.z, L.z, fi), 1.0f);
+  accum[slot] = a1;
+  albedo[slot] = make_float4(fold_mean(b0.x, sa.x, fi), fold_mean(b0.y, sa.y, fi), fold_mean(b0.z, sa.z, fi), 1.0f);
+  normal[slot] = make_float4(fold_mean(n0.x, sn.x, fi), fold_mean(n0.y, sn.y, fi), fold_mean(n0.z, sn.z, fi), 1.0f);
+  const f3 c = tonemap_select(mk3(a1.x, a1.y, a1.z) * fc.u.exposure_value, fc.u.enable_tonemap, fc.u.enable_aces, fc.u.use_simple_aces);
+  final_img[slot] = make_float4(c.x, c.y, c.z, 1.0f);
+}
+
+// tile-major gathered buffer [world][tiles_per_rank][ts][ts] -> row-major full image (RENDER_SPEC §9)
+__global__ void __launch_bounds__(256) k_scatter_tiles(FrameConst fc, const float4* __restrict__ gathered, float4* __restrict__ full) {
+  const uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t per_rank = fc.tiles_per_rank * fc.tile_size * fc.tile_size;
+  if (gi >= per_rank * fc.world) return;
+  FrameConst f2 = fc;
+  f2.rank = gi / per_rank;
+  uint32_t px, py;
+  if (!slot_to_pixel(f2, gi - f2.rank * per_rank, &px, &py)) return;
+  full[(size_t)py * fc.width + px] = gathered[gi];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------------------
+static inline uint32_t blocks_for(uint32_t n, uint32_t per) { return (n + per - 1) / per; }
+
+size_t traverse_stack_bytes() { return (size_t)kStackLds * kTraverseThreads * 4; }
+uint32_t traverse_stack_lds_levels() { return kStackLds; }
+uint32_t traverse_stack_spill_levels() { return kStackSpill; }
+uint32_t traverse_blocks_per_cu(size_t dynamic_lds_bytes) {
+  int a = 0, b = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_batch<false, false>, kTraverseThreads, dynamic_lds_bytes) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_trace_shadow<false>, kTraverseThreads, dynamic_lds_bytes) != hipSuccess) return 0;
+  return (uint32_t)std::max(0, std::min(a, b));
+}
+
+void launch_trace_batch(const LaunchCfg& lc, const SceneView& sv, const hala_ray* rays, hala_hit* hits, const uint32_t* n_ptr,
+                        uint32_t n_imm, uint32_t* work, Control* ctl, bool any, bool count, bool account, hipStream_t s) {
+  const size_t smem = (size_t)sv.lds_nodes * 64 + (size_t)sv.lds_tris * 48 + (size_t)kStackLds * kTraverseThreads * 4;
+  dim3 grid(lc.persistent_blocks), block(kTraverseThreads);
+  const int acc = account ? 1 : 0;
+  if (any) {
+    if (count) hipLaunchKernelGGL((k_trace_batch<true, true>), grid, block, smem, s, sv, rays, hits, n_ptr, n_imm, work, lc.spill, ctl, acc);
+    else hipLaunchKernelGGL((k_trace_batch<true, false>), grid, block, smem, s, sv, rays, hits, n_ptr, n_imm, work, lc.spill, ctl, acc);
+  } else {
+    if (count) hipLaunchKernelGGL((k_trace_batch<false, true>), grid, block, smem, s, sv, rays, hits, n_ptr, n_imm, work, lc.spill, ctl, acc);
+    else hipLaunchKernelGGL((k_trace_batch<false, false>), grid, block, smem, s, sv, rays, hits, n_ptr, n_imm, work, lc.spill, ctl, acc);
+  }
+}
+
+void launch_trace_shadow(const LaunchCfg& lc, const SceneView& sv, const Queues& q, const PathState& ps, Control* ctl, uint32_t depth,
+                         bool count, hipStream_t s) {
+  const size_t smem = (size_t)sv.lds_nodes * 64 + (size_t)sv.lds_tris * 48 + (size_t)kStackLds * kTraverseThreads * 4;
+  dim3 grid(lc.persistent_blocks), block(kTraverseThreads);
+  if (count) hipLaunchKernelGGL((k_trace_shadow<true>), grid, block, smem, s, sv, q, ps, ctl, depth, lc.spill);
+  else hipLaunchKernelGGL((k_trace_shadow<false>), grid, block, smem, s, sv, q, ps, ctl, depth, lc.spill);
+}
+
+void launch_raygen(const FrameConst& fc, const SceneView& sv, const Queues& q, const PathState& ps, Control* ctl, hipStream_t s) {
+  hipLaunchKernelGGL(k_raygen, dim3(blocks_for(fc.slot_count, 256)), dim3(256), 0, s, fc, sv, q, ps, ctl);
+}
+void launch_shade(const FrameConst& fc, const SceneView& sv, const Queues& q, const PathState& ps, Control* ctl, uint32_t depth, hipStream_t s) {
+  hipLaunchKernelGGL(k_shade, dim3(blocks_for(fc.slot_count, 256)), dim3(256), 0, s, fc, sv, q, ps, ctl, depth);
+}
+void launch_resolve(const FrameConst& fc, const PathState& ps, float4* accum, float4* albedo, float4* normal, float4* final_img, hipStream_t s) {
+  hipLaunchKernelGGL(k_resolve, dim3(blocks_for(fc.slot_count, 256)), dim3(256), 0, s, fc, ps, accum, albedo, normal, final_img);
+}
+void launch_scatter_tiles(const FrameConst& fc, const float4* gathered, float4* full, hipStream_t s) {
+  const uint32_t n = fc.tiles_per_rank * fc.tile_size * fc.tile_size * fc.world;
+  hipLaunchKernelGGL(k_scatter_tiles, dim3(blocks_for(n, 256)), dim3(256), 0, s, fc, gathered, full);
+}
+
+}  // namespace rt

@@ -1,0 +1,59 @@
+// kernels.h — host-callable launchers of the HIP kernels of libhalart.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "hala_types.h"
+
+namespace rt {
+
+struct LaunchCfg {
+  uint32_t persistent_blocks;  // grid of the persistent traversal kernels
+  uint32_t* spill;             // global stack spill area or nullptr (tree depth <= kStackLds)
+};
+
+// integrator.hip
+size_t traverse_stack_bytes();          // LDS bytes of the per-lane traversal stacks of one workgroup
+uint32_t traverse_stack_lds_levels();   // stack levels kept in LDS
+uint32_t traverse_stack_spill_levels(); // deeper levels spilled to global scratch
+uint32_t traverse_blocks_per_cu(size_t dynamic_lds_bytes);  // resident workgroups per CU (occupancy query)
+void launch_trace_batch(const LaunchCfg& lc, const SceneView& sv, const hala_ray* rays, hala_hit* hits, const uint32_t* n_ptr,
+                        uint32_t n_imm, uint32_t* work, Control* ctl, bool any, bool count, bool account, hipStream_t s);
+void launch_trace_shadow(const LaunchCfg& lc, const SceneView& sv, const Queues& q, const PathState& ps, Control* ctl, uint32_t depth,
+                         bool count, hipStream_t s);
+void launch_raygen(const FrameConst& fc, const SceneView& sv, const Queues& q, const PathState& ps, Control* ctl, hipStream_t s);
+void launch_shade(const FrameConst& fc, const SceneView& sv, const Queues& q, const PathState& ps, Control* ctl, uint32_t depth, hipStream_t s);
+void launch_resolve(const FrameConst& fc, const PathState& ps, float4* accum, float4* albedo, float4* normal, float4* final_img, hipStream_t s);
+void launch_scatter_tiles(const FrameConst& fc, const float4* gathered, float4* full, hipStream_t s);
+
+// bvh_build.hip — K1/K3/K4: flatten instances to world space, LBVH build, refit
+struct BvhBuffers {
+  // inputs (device)
+  const hala_gpu_mesh_data* primitives;  // per instance
+  const uint32_t* inst_first_tri;        // [instance_count + 1] prefix of triangle counts
+  uint32_t instance_count;
+  uint32_t tri_count;
+  // outputs (device, allocated by the caller)
+  Tri* tris_by_id;         // [tri_count]
+  Tri* tris;               // [tri_count] BVH order
+  uint32_t* tri_instance;  // [tri_count]
+  BvhNode* nodes;          // [max(tri_count,2)-1 .. ] capacity >= max(tri_count - 1, 1)
+  void* topology = nullptr;  // builder state kept for refit (freed with bvh_free_topology)
+  // results
+  uint32_t node_count;
+  uint32_t max_depth;
+  float scene_min[3], scene_max[3];
+};
+// Builds everything; returns "" on success or an error message.  Synchronises the stream before returning.
+std::string bvh_build(BvhBuffers& b, uint32_t leaf_max, hipStream_t s);
+// Re-flattens (instance transforms / vertices may have changed) and refits the existing topology bottom-up.
+std::string bvh_refit(BvhBuffers& b, hipStream_t s);
+void bvh_free_topology(void* topology);
+
+// envmap.hip — A1: EnvMap::build_distribution_maps (src/envmap.rs:239-388) on the GPU
+// d_rgba: W*H float4; outputs device pointers: total_sum[1], marginal[H], conditional[W*H]
+std::string envmap_build_distribution(const float4* d_rgba, uint32_t width, uint32_t height, float* d_total_sum, float* d_marginal,
+                                      float* d_conditional, hipStream_t s);
+
+}  // namespace rt

@@ -1,0 +1,864 @@
+// renderer.hip — HalaRenderer (src/rt_renderer.rs:568-1353) re-designed for one MI355X: the C++ object behind the
+// C ABI of include/halart.h.  Descriptor sets become a struct of device pointers (rt::SceneView), trace_rays becomes the
+// wavefront kernel sequence of integrator.hip, timestamp queries become HIP events, staging buffers become
+// hipMemcpyAsync from the caller's memory.  Everything that computes runs on the GPU; this file only orchestrates.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <sys/stat.h>
+#include <vector>
+
+#include "hala_types.h"
+#include "host_image.h"
+#include "host_scene.h"
+#include "host_util.h"
+#include "kernels.h"
+
+using namespace rt;
+
+namespace {
+
+constexpr uint32_t kLeafMax = 4;
+constexpr size_t kLdsStageBudget = 40 * 1024;  // bytes of BVH top staged per workgroup next to the 24-KB stack
+constexpr int kStatRing = 16;
+
+// ---- RENDER_SPEC §2.2 on the host (for tan(yfov/2); same polynomials as rt_math.h) ---------------------------
+float h_sin_poly(float a) {
+  float a2 = a * a;
+  float p = -2.50521083854417187751e-8f;
+  p = std::fmaf(p, a2, 2.75573192239858906526e-6f);
+  p = std::fmaf(p, a2, -1.98412698412698412698e-4f);
+  p = std::fmaf(p, a2, 8.33333333333333333333e-3f);
+  p = std::fmaf(p, a2, -1.66666666666666666667e-1f);
+  p = std::fmaf(p, a2, 1.0f);
+  return a * p;
+}
+float h_cos_poly(float a) {
+  float a2 = a * a;
+  float p = 2.08767569878680989792e-9f;
+  p = std::fmaf(p, a2, -2.75573192239858906526e-7f);
+  p = std::fmaf(p, a2, 2.48015873015873015873e-5f);
+  p = std::fmaf(p, a2, -1.38888888888888888889e-3f);
+  p = std::fmaf(p, a2, 4.16666666666666666667e-2f);
+  p = std::fmaf(p, a2, -0.5f);
+  p = std::fmaf(p, a2, 1.0f);
+  return p;
+}
+void h_sincos_rad(float a, float* s, float* c) {
+  float t = a * 0.15915494309189533577f;
+  t = t - std::floor(t);
+  if (t >= 1.0f) t = 0.0f;
+  float x = t * 4.0f;
+  int q = (int)x;
+  float f = x - (float)q;
+  float ang = f * 1.57079632679489661923f;
+  float sa = h_sin_poly(ang), ca = h_cos_poly(ang);
+  switch (q & 3) {
+    case 0: *s = sa; *c = ca; break;
+    case 1: *s = ca; *c = -sa; break;
+    case 2: *s = -sa; *c = -ca; break;
+    default: *s = -ca; *c = sa; break;
+  }
+}
+
+uint32_t gcd_u32(uint32_t a, uint32_t b) { while (b) { uint32_t t = a % b; a = b; b = t; } return a; }
+uint32_t mod_inverse(uint32_t a, uint32_t n) {  // a^-1 mod n (a, n coprime); n == 1 -> 0
+  long long t = 0, nt = 1, r = n, nr = a % n;
+  while (nr != 0) { long long q = r / nr; long long tmp = t - q * nt; t = nt; nt = tmp; tmp = r - q * nr; r = nr; nr = tmp; }
+  if (t < 0) t += n;
+  return (uint32_t)t;
+}
+
+struct TraceEvents {
+  std::vector<hipEvent_t> ev;  // pairs
+  size_t used = 0;
+  hipEvent_t frame_begin = nullptr, frame_end = nullptr;
+  bool pending = false, counted = false;
+  unsigned long long* host_counts = nullptr;  // pinned: rays_closest, rays_shadow, nodes, tris
+};
+
+}  // namespace
+
+struct hala_rt_renderer {
+  std::string name;
+  uint32_t width = 0, height = 0;
+  int device = 0;
+  uint32_t max_depth = 0, rr_depth = 0;
+  bool enable_tonemap = false, enable_aces = false, use_simple_aces = false;
+  uint64_t max_frames = 0;
+  hipStream_t stream = nullptr;
+  uint32_t cu_count = 256;
+
+  float ground[4] = {1.0f, 1.0f, 1.0f, 1.0f};  // src/rt_renderer.rs:799
+  float sky[4] = {0.5f, 0.7f, 1.0f, 1.0f};     // :800
+  float env_intensity = 1.0f, exposure = 1.0f, env_rotation = 0.0f;  // :798-803
+
+  uint32_t n_raygen = 0, n_miss = 0, n_callable = 0, n_hit = 0;
+  DeviceArray<uint8_t> blue_noise;
+  uint32_t blue_w = 0, blue_h = 0;
+
+  bool has_scene = false, committed = false;
+  HostScene hs;
+  DeviceArray<hala_vertex> d_vertices;
+  DeviceArray<uint32_t> d_indices;
+  std::vector<size_t> prim_vertex_offset, prim_index_offset;
+  DeviceArray<hala_gpu_camera> d_cameras;
+  DeviceArray<hala_gpu_light> d_lights;
+  DeviceArray<hala_gpu_material> d_materials;
+  DeviceArray<hala_gpu_mesh_data> d_instances;
+  DeviceArray<uint32_t> d_inst_first_tri;
+
+  BvhBuffers bvh{};
+  DeviceArray<Tri> d_tris_by_id, d_tris;
+  DeviceArray<uint32_t> d_tri_instance;
+  DeviceArray<BvhNode> d_nodes;
+  uint32_t lds_nodes = 0, lds_tris = 0;
+  float ray_eps = 0.0f;
+  DeviceArray<uint32_t> d_spill;
+  LaunchCfg lcfg{};
+
+  bool has_env = false;
+  uint32_t env_w = 0, env_h = 0;
+  DeviceArray<float4> d_env;
+  DeviceArray<float> d_env_total, d_marginal, d_conditional;
+  float env_total_sum = 0.0f;
+
+  // tile shard (RENDER_SPEC §9)
+  uint32_t rank = 0, world = 1, tile_size = 32, tiles_x = 0, tiles_y = 0, tiles_per_rank = 0, perm_a_inv = 0, perm_b = 7;
+  uint32_t slot_count = 0;
+
+  DeviceArray<float4> img_local[4];  // accum, albedo, normal, final (slot order)
+  DeviceArray<float4> img_full[4];   // row-major, only after scatter_gathered_tiles (world > 1)
+  bool full_valid[4] = {false, false, false, false};
+  DeviceArray<float4> ps_tp, ps_lr, ps_alb, ps_nrm;
+  DeviceArray<hala_ray> q_rays[2];
+  DeviceArray<uint32_t> q_slots[2], q_shadow_list;
+  DeviceArray<hala_hit> q_hits;
+  DeviceArray<ShadowEntry> q_shadow;
+  DeviceArray<Control> d_ctl;
+  DeviceArray<uint32_t> d_batch_work;
+
+  uint64_t total_frames = 0;
+  bool counting = false;
+  hala_global_uniform last_uniform{};
+  TraceEvents ring[kStatRing];
+  int ring_pos = 0;
+  hala_rt_statistics stats{};
+
+  ~hala_rt_renderer() {
+    if (device >= 0) (void)hipSetDevice(device);
+    if (stream) (void)hipStreamSynchronize(stream);
+    for (auto& t : ring) {
+      for (auto e : t.ev) (void)hipEventDestroy(e);
+      if (t.frame_begin) (void)hipEventDestroy(t.frame_begin);
+      if (t.frame_end) (void)hipEventDestroy(t.frame_end);
+      if (t.host_counts) (void)hipHostFree(t.host_counts);
+    }
+    // images first, then everything else (src/rt_renderer.rs:620-633)
+    for (auto& i : img_local) i.release();
+    for (auto& i : img_full) i.release();
+    if (bvh.topology) bvh_free_topology(bvh.topology);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+
+  SceneView view() const {
+    SceneView sv{};
+    sv.nodes = d_nodes.ptr; sv.tris = d_tris.ptr; sv.tris_by_id = d_tris_by_id.ptr; sv.tri_instance = d_tri_instance.ptr;
+    sv.inst_first_tri = d_inst_first_tri.ptr; sv.primitives = d_instances.ptr; sv.materials = d_materials.ptr;
+    sv.lights = d_lights.ptr; sv.cameras = d_cameras.ptr;
+    sv.env_pixels = reinterpret_cast<const float*>(d_env.ptr); sv.env_marginal = d_marginal.ptr; sv.env_conditional = d_conditional.ptr;
+    sv.node_count = bvh.node_count; sv.tri_count = bvh.tri_count; sv.lds_nodes = lds_nodes; sv.lds_tris = lds_tris;
+    sv.ray_eps = ray_eps;
+    return sv;
+  }
+  Queues queues() const {
+    Queues q{};
+    q.rays[0] = q_rays[0].ptr; q.rays[1] = q_rays[1].ptr; q.slots[0] = q_slots[0].ptr; q.slots[1] = q_slots[1].ptr;
+    q.hits = q_hits.ptr; q.shadow = q_shadow.ptr; q.shadow_list = q_shadow_list.ptr;
+    return q;
+  }
+  PathState path_state() const { return PathState{ps_tp.ptr, ps_lr.ptr, ps_alb.ptr, ps_nrm.ptr}; }
+
+  FrameConst frame_const(const hala_global_uniform& u) const {
+    FrameConst fc{};
+    fc.u = u;
+    fc.aspect = u.resolution[0] / u.resolution[1];
+    float sn = 0.0f, cs = 1.0f;
+    if (!hs.cameras.empty()) h_sincos_rad(0.5f * hs.cameras[0].yfov, &sn, &cs);
+    fc.tan_half = sn / cs;
+    fc.width = width; fc.height = height;
+    fc.tile_size = tile_size; fc.tiles_x = tiles_x; fc.tiles_y = tiles_y; fc.world = world; fc.rank = rank;
+    fc.tiles_per_rank = tiles_per_rank; fc.perm_a = perm_a_inv; fc.perm_b = perm_b; fc.slot_count = slot_count;
+    return fc;
+  }
+
+  void reset_accumulation() {  // statistics.reset() of the device-lost path (src/rt_renderer.rs:557)
+    total_frames = 0;
+    for (bool& v : full_valid) v = false;
+  }
+
+  // resolve one ring slot's events into the totals (the slot's work must have completed)
+  void resolve_slot(TraceEvents& t) {
+    if (!t.pending) return;
+    (void)hipEventSynchronize(t.frame_end);
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, t.frame_begin, t.frame_end) == hipSuccess) { stats.last_gpu_ms = ms; stats.gpu_ms_total += ms; }
+    double tr = 0.0;
+    for (size_t k = 0; k + 1 < t.used; k += 2) {
+      float m = 0.0f;
+      if (hipEventElapsedTime(&m, t.ev[k], t.ev[k + 1]) == hipSuccess) tr += m;
+    }
+    stats.traverse_ms_last_update = tr;
+    stats.traverse_ms_total += tr;
+    stats.traverse_launches_total += t.used / 2;
+    stats.updates_rendered += 1;
+    const unsigned long long rc = t.host_counts[0], rs = t.host_counts[1];
+    stats.rays_last_update = rc + rs;
+    stats.rays_total += rc + rs;
+    stats.rays_closest_total += rc;
+    stats.rays_shadow_total += rs;
+    if (t.counted) { stats.nodes_visited_total += t.host_counts[2]; stats.tris_tested_total += t.host_counts[3]; stats.rays_counted_total += rc + rs; }
+    t.pending = false;
+  }
+  hipEvent_t next_event(TraceEvents& t) {
+    if (t.used == t.ev.size()) { hipEvent_t e = nullptr; (void)hipEventCreate(&e); t.ev.push_back(e); }
+    return t.ev[t.used++];
+  }
+};
+
+namespace {
+
+int ensure_device(hala_rt_renderer* r) {
+  if (!r) RT_FAIL("The renderer handle is null!");
+  RT_HIP(hipSetDevice(r->device));
+  return HALA_OK;
+}
+
+void compute_tiling(hala_rt_renderer* r) {
+  if (r->world <= 1) {
+    r->slot_count = r->width * r->height;
+    r->tiles_x = r->tiles_y = r->tiles_per_rank = 0;
+    return;
+  }
+  r->tiles_x = (r->width + r->tile_size - 1) / r->tile_size;
+  r->tiles_y = (r->height + r->tile_size - 1) / r->tile_size;
+  const uint32_t n = r->tiles_x * r->tiles_y;
+  r->tiles_per_rank = (n + r->world - 1) / r->world;
+  uint32_t A = 0x9E3779B1u % n;  // RENDER_SPEC §9: perm(t) = (t*A + B) mod n, A coprime to n
+  if (A == 0) A = 1;
+  while (gcd_u32(A, n) != 1) ++A;
+  r->perm_a_inv = mod_inverse(A, n);
+  r->perm_b = 7;
+  r->slot_count = r->tiles_per_rank * r->tile_size * r->tile_size;
+}
+
+int alloc_frame_buffers(hala_rt_renderer* r) {
+  const size_t n = r->slot_count;
+  for (auto& i : r->img_local) { RT_HIP(i.resize(n)); RT_HIP(hipMemsetAsync(i.ptr, 0, n * sizeof(float4), r->stream)); }
+  RT_HIP(r->ps_tp.resize(n)); RT_HIP(r->ps_lr.resize(n)); RT_HIP(r->ps_alb.resize(n)); RT_HIP(r->ps_nrm.resize(n));
+  RT_HIP(r->q_rays[0].resize(n)); RT_HIP(r->q_rays[1].resize(n)); RT_HIP(r->q_slots[0].resize(n)); RT_HIP(r->q_slots[1].resize(n));
+  RT_HIP(r->q_hits.resize(n)); RT_HIP(r->q_shadow.resize(2 * n)); RT_HIP(r->q_shadow_list.resize(n));
+  RT_HIP(r->d_ctl.resize(1));
+  RT_HIP(hipMemsetAsync(r->d_ctl.ptr, 0, sizeof(Control), r->stream));
+  RT_HIP(r->d_batch_work.resize(1));
+  return HALA_OK;
+}
+
+int upload_packed(hala_rt_renderer* r) {
+  HostScene& hs = r->hs;
+  // one arena each for all vertex / index buffers (the reference creates one buffer pair per primitive,
+  // gpu_uploader.rs:421-456; device addresses per primitive are what matters to the shaders, :869-870)
+  size_t nv = 0, ni = 0;
+  r->prim_vertex_offset.clear(); r->prim_index_offset.clear();
+  for (const auto& p : hs.prims) {
+    r->prim_vertex_offset.push_back(nv); r->prim_index_offset.push_back(ni);
+    nv += p.vertices.size();
+    ni += (p.indices.size() + 3) & ~size_t(3);  // keep every index buffer 16-B aligned
+  }
+  RT_HIP(r->d_vertices.resize(nv)); RT_HIP(r->d_indices.resize(ni));
+  for (size_t k = 0; k < hs.prims.size(); ++k) {
+    const auto& p = hs.prims[k];
+    if (!p.vertices.empty()) RT_HIP(hipMemcpyAsync(r->d_vertices.ptr + r->prim_vertex_offset[k], p.vertices.data(), p.vertices.size() * sizeof(hala_vertex), hipMemcpyHostToDevice, r->stream));
+    if (!p.indices.empty()) RT_HIP(hipMemcpyAsync(r->d_indices.ptr + r->prim_index_offset[k], p.indices.data(), p.indices.size() * 4, hipMemcpyHostToDevice, r->stream));
+  }
+  for (size_t i = 0; i < hs.instances.size(); ++i) {
+    const uint32_t p = hs.instance_prim[i];
+    hs.instances[i].vertices = reinterpret_cast<uint64_t>(r->d_vertices.ptr + r->prim_vertex_offset[p]);  // get_device_address (:869)
+    hs.instances[i].indices = reinterpret_cast<uint64_t>(r->d_indices.ptr + r->prim_index_offset[p]);     // (:870)
+  }
+  RT_HIP(r->d_cameras.upload(hs.cameras.data(), hs.cameras.size(), r->stream));
+  RT_HIP(r->d_lights.upload(hs.lights.data(), hs.lights.size(), r->stream));
+  RT_HIP(r->d_materials.upload(hs.gpu_materials.data(), hs.gpu_materials.size(), r->stream));
+  RT_HIP(r->d_instances.upload(hs.instances.data(), hs.instances.size(), r->stream));
+  RT_HIP(r->d_inst_first_tri.upload(hs.inst_first_tri.data(), hs.inst_first_tri.size(), r->stream));
+  RT_HIP(hipStreamSynchronize(r->stream));
+  return HALA_OK;
+}
+
+int configure_traversal(hala_rt_renderer* r) {
+  const size_t nb = (size_t)r->bvh.node_count * 64, tb = (size_t)r->bvh.tri_count * 48;
+  if (nb + tb <= kLdsStageBudget) { r->lds_nodes = r->bvh.node_count; r->lds_tris = r->bvh.tri_count; }
+  else { r->lds_nodes = (uint32_t)std::min<size_t>(r->bvh.node_count, kLdsStageBudget / 64); r->lds_tris = 0; }
+  const size_t smem = (size_t)r->lds_nodes * 64 + (size_t)r->lds_tris * 48 + traverse_stack_bytes();
+  uint32_t per_cu = traverse_blocks_per_cu(smem);
+  if (per_cu == 0) RT_FAIL("The traversal kernel does not fit on a compute unit with the requested LDS staging.");
+  per_cu = std::min(per_cu, 8u);
+  r->lcfg.persistent_blocks = r->cu_count * per_cu;
+  r->lcfg.spill = nullptr;
+  if (r->bvh.max_depth > traverse_stack_lds_levels()) {
+    if (r->bvh.max_depth > traverse_stack_lds_levels() + traverse_stack_spill_levels())
+      RT_FAIL("The BVH is deeper than the traversal stack supports (" + std::to_string(r->bvh.max_depth) + " levels).");
+    RT_HIP(r->d_spill.resize((size_t)r->lcfg.persistent_blocks * 256 * traverse_stack_spill_levels()));
+    r->lcfg.spill = r->d_spill.ptr;
+  }
+  const float ex = r->bvh.scene_max[0] - r->bvh.scene_min[0], ey = r->bvh.scene_max[1] - r->bvh.scene_min[1], ez = r->bvh.scene_max[2] - r->bvh.scene_min[2];
+  r->ray_eps = std::sqrt(std::fmaf(ez, ez, std::fmaf(ey, ey, ex * ex))) * 1e-5f;  // RENDER_SPEC §3
+  return HALA_OK;
+}
+
+int build_bvh(hala_rt_renderer* r) {
+  const uint32_t n = r->hs.triangle_count;
+  RT_HIP(r->d_tris_by_id.resize(n)); RT_HIP(r->d_tris.resize(n)); RT_HIP(r->d_tri_instance.resize(n));
+  RT_HIP(r->d_nodes.resize(std::max<uint32_t>(n, 2) - 1));
+  r->bvh.primitives = r->d_instances.ptr; r->bvh.inst_first_tri = r->d_inst_first_tri.ptr;
+  r->bvh.instance_count = (uint32_t)r->hs.instances.size(); r->bvh.tri_count = n;
+  r->bvh.tris_by_id = r->d_tris_by_id.ptr; r->bvh.tris = r->d_tris.ptr; r->bvh.tri_instance = r->d_tri_instance.ptr; r->bvh.nodes = r->d_nodes.ptr;
+  const std::string e = bvh_build(r->bvh, kLeafMax, r->stream);
+  if (!e.empty()) RT_FAIL(e);
+  return configure_traversal(r);
+}
+
+std::string file_stem(const char* path) {
+  std::string p(path);
+  const size_t slash = p.find_last_of("/\\");
+  std::string base = slash == std::string::npos ? p : p.substr(slash + 1);
+  const size_t dot = base.find_last_of('.');
+  if (dot != std::string::npos && dot != 0) base = base.substr(0, dot);
+  return base;
+}
+
+int install_envmap(hala_rt_renderer* r, const float* pixels, uint32_t channels, uint32_t w, uint32_t h, float rotation,
+                   const float* cached_total, const float* cached_marginal, const float* cached_conditional) {
+  if (!pixels || w == 0 || h == 0 || (channels != 3 && channels != 4)) RT_FAIL("Unsupported color type for environment map.");  // src/envmap.rs:57-60
+  std::vector<float> data((size_t)w * h * 4);
+  for (size_t i = 0; i < (size_t)w * h; ++i) {  // src/envmap.rs:63-89
+    for (uint32_t c = 0; c < 3; ++c) {
+      const float v = pixels[i * channels + c];
+      if (std::isnan(v)) RT_FAIL("The pixel value is NaN!");
+      if (std::isinf(v)) RT_FAIL("The pixel value is infinite!");
+      data[4 * i + c] = v;
+    }
+    data[4 * i + 3] = 1.0f;  // :87
+  }
+  RT_HIP(r->d_env.upload(reinterpret_cast<const float4*>(data.data()), (size_t)w * h, r->stream));
+  RT_HIP(r->d_env_total.resize(1)); RT_HIP(r->d_marginal.resize(h)); RT_HIP(r->d_conditional.resize((size_t)w * h));
+  if (cached_total) {  // ./out/<stem>.dist_cache hit (src/envmap.rs:91-117)
+    RT_HIP(hipMemcpyAsync(r->d_env_total.ptr, cached_total, 4, hipMemcpyHostToDevice, r->stream));
+    RT_HIP(hipMemcpyAsync(r->d_marginal.ptr, cached_marginal, (size_t)h * 4, hipMemcpyHostToDevice, r->stream));
+    RT_HIP(hipMemcpyAsync(r->d_conditional.ptr, cached_conditional, (size_t)w * h * 4, hipMemcpyHostToDevice, r->stream));
+    RT_HIP(hipStreamSynchronize(r->stream));
+    r->env_total_sum = *cached_total;
+  } else {
+    const std::string e = envmap_build_distribution(r->d_env.ptr, w, h, r->d_env_total.ptr, r->d_marginal.ptr, r->d_conditional.ptr, r->stream);
+    if (!e.empty()) RT_FAIL(e);
+    RT_HIP(hipMemcpy(&r->env_total_sum, r->d_env_total.ptr, 4, hipMemcpyDeviceToHost));
+  }
+  r->env_w = w; r->env_h = h; r->has_env = true; r->env_rotation = rotation;  // src/rt_renderer.rs:1192
+  return HALA_OK;
+}
+
+}  // namespace
+
+// =================================================================================================================
+// C ABI
+// =================================================================================================================
+extern "C" {
+
+const char* hala_last_error_message(void) { return get_last_error(); }
+const char* hala_version(void) { return "halart 0.1 (gfx950)"; }
+
+int hala_rt_create(const char* name, uint32_t width, uint32_t height, int device_ordinal, uint32_t max_depth, uint32_t rr_depth,
+                   int enable_tonemap, int enable_aces, int use_simple_aces, uint64_t max_frames, hala_rt_renderer** out) {
+  if (!out) RT_FAIL("The output handle is null!");
+  *out = nullptr;
+  if (width == 0 || height == 0) RT_FAIL("The renderer resolution is zero!");
+  if (max_depth == 0 || max_depth > kMaxDepth) RT_FAIL("max_depth must be in 1.." + std::to_string(kMaxDepth) + ".");
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) RT_FAIL("No HIP device is available: libhalart has no CPU path.");
+  if (device_ordinal < 0 || device_ordinal >= count) RT_FAIL("The requested device ordinal does not exist.");
+  RT_HIP(hipSetDevice(device_ordinal));
+  std::unique_ptr<hala_rt_renderer> r(new hala_rt_renderer());
+  r->name = name ? name : "";
+  r->width = width; r->height = height; r->device = device_ordinal;
+  r->max_depth = max_depth; r->rr_depth = rr_depth;
+  r->enable_tonemap = enable_tonemap != 0; r->enable_aces = enable_aces != 0; r->use_simple_aces = use_simple_aces != 0;
+  r->max_frames = max_frames == 0 ? UINT64_MAX : max_frames;  // src/rt_renderer.rs:774
+  hipDeviceProp_t prop;
+  RT_HIP(hipGetDeviceProperties(&prop, device_ordinal));
+  r->cu_count = (uint32_t)prop.multiProcessorCount;
+  RT_HIP(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
+  compute_tiling(r.get());
+  // create_storage_images (src/rt_renderer.rs:818-917): final, accum, albedo, normal
+  if (alloc_frame_buffers(r.get()) != HALA_OK) return HALA_ERR;
+  RT_HIP(hipStreamSynchronize(r->stream));
+  *out = r.release();
+  return HALA_OK;
+}
+
+void hala_rt_destroy(hala_rt_renderer* r) { delete r; }
+
+int hala_rt_push_general_shader(hala_rt_renderer* r, const void* code, size_t code_size, int stage, const char*) {
+  if (!r) RT_FAIL("The renderer handle is null!");
+  if (!code || code_size == 0) RT_FAIL("The shader code is empty!");
+  if (stage == 0) r->n_raygen++; else if (stage == 1) r->n_miss++; else if (stage == 2) r->n_callable++; else RT_FAIL("Invalid general shader stage.");
+  return HALA_OK;
+}
+int hala_rt_push_general_shader_with_file(hala_rt_renderer* r, const char* file_path, int stage, const char* debug_name) {
+  if (!r) RT_FAIL("The renderer handle is null!");
+  struct stat st;
+  if (!file_path || stat(file_path, &st) != 0) RT_FAIL(std::string("Failed to load shader file \"") + (file_path ? file_path : "") + "\".");
+  static const char dummy = 0;
+  return hala_rt_push_general_shader(r, &dummy, 1, stage, debug_name);
+}
+int hala_rt_push_hit_shaders(hala_rt_renderer* r, const void* ch, size_t chs, const void* ah, size_t ahs, const void* is, size_t iss, const char*) {
+  if (!r) RT_FAIL("The renderer handle is null!");
+  if ((!ch || !chs) && (!ah || !ahs) && (!is || !iss)) RT_FAIL("The hit shader group is empty!");
+  r->n_hit++;
+  return HALA_OK;
+}
+int hala_rt_push_hit_shaders_with_file(hala_rt_renderer* r, const char* ch, const char* ah, const char* is, const char*) {
+  if (!r) RT_FAIL("The renderer handle is null!");
+  struct stat st;
+  for (const char* p : {ch, ah, is}) if (p && stat(p, &st) != 0) RT_FAIL(std::string("Failed to load shader file \"") + p + "\".");
+  if (!ch && !ah && !is) RT_FAIL("The hit shader group is empty!");
+  r->n_hit++;
+  return HALA_OK;
+}
+
+int hala_rt_load_blue_noise_pixels(hala_rt_renderer* r, const uint8_t* rgba8, uint32_t width, uint32_t height) {
+  if (ensure_device(r) != HALA_OK) return HALA_ERR;
+  if (!rgba8 || !width || !height) RT_FAIL("The blue noise texture is empty!");
+  RT_HIP(r->blue_noise.upload(rgba8, (size_t)width * height * 4, r->stream));
+  RT_HIP(hipStreamSynchronize(r->stream));
+  r->blue_w = width; r->blue_h = height;
+  return HALA_OK;
+}
+
+int hala_rt_set_scene(hala_rt_renderer* r, const hala_scene_desc* scene) {
+  if (ensure_device(r) != HALA_OK) return HALA_ERR;
+  RT_HIP(hipStreamSynchronize(r->stream));
+  r->has_scene = false; r->committed = false;  // "Release the old scene in the GPU." (src/rt_renderer.rs:1164)
+  const std::string e = r->hs.assign(scene);
+  if (!e.empty()) RT_FAIL(e);
+  for (const auto& m : r->hs.materials) if (m.type == 1u) RT_FAIL("DISNEY materials (type 1) are not implemented by this integrator yet (docs/RENDER_SPEC.md §7.1).");
+  if (upload_packed(r) != HALA_OK) return HALA_ERR;
+  r->has_scene = true;
+  return HALA_OK;
+}
+
+int hala_rt_set_envmap_pixels(hala_rt_renderer* r, const float* pixels, uint32_t channels, uint32_t width, uint32_t height, float rotation_degrees) {
+  if (ensure_device(r) != HALA_OK) return HALA_ERR;
+  RT_HIP(hipStreamSynchronize(r->stream));
+  return install_envmap(r, pixels, channels, width, height, rotation_degrees, nullptr, nullptr, nullptr);
+}
+
+int hala_rt_set_envmap_file(hala_rt_renderer* r, const char* path, float rotation_degrees) {
+  if (ensure_device(r) != HALA_OK) return HALA_ERR;
+  if (!path || !*path) RT_FAIL("The file name is none!");  // src/envmap.rs:45
+  HostImage img;
+  const std::string e = load_float_image(path, &img);
+  if (!e.empty()) RT_FAIL(e);
+  RT_HIP(hipStreamSynchronize(r->stream));
+  // ./out/<stem>.dist_cache: [f32 total_sum][f32 x H][f32 x W*H], native endian, no header (src/envmap.rs:90-142)
+  const std::string cache = "./out/" + file_stem(path) + ".dist_cache";
+  const size_t W = img.width, H = img.height;
+  std::vector<float> blob(1 + H + W * H);
+  FILE* f = fopen(cache.c_str(), "rb");
+  if (f) {
+    const size_t got = fread(blob.data(), 4, blob.size(), f);
+    fclose(f);
+    if (got != blob.size()) RT_FAIL("Failed to read from file.");  // :101, :107, :114
+    return install_envmap(r, img.pixels.data(), img.channels, img.width, img.height, rotation_degrees, &blob[0], &blob[1], &blob[1 + H]);
+  }
+  if (install_envmap(r, img.pixels.data(), img.channels, img.width, img.height, rotation_degrees, nullptr, nullptr, nullptr) != HALA_OK) return HALA_ERR;
+  blob[0] = r->env_total_sum;
+  RT_HIP(hipMemcpy(&blob[1], r->d_marginal.ptr, H * 4, hipMemcpyDeviceToHost));
+  RT_HIP(hipMemcpy(&blob[1 + H], r->d_conditional.ptr, W * H * 4, hipMemcpyDeviceToHost));
+  f = fopen(cache.c_str(), "wb");
+  if (!f) RT_FAIL("Failed to create file \"" + cache + "\".");  // :125 (the reference does not create ./out either)
+  const size_t put = fwrite(blob.data(), 4, blob.size(), f);
+  if (fclose(f) != 0 || put != blob.size()) RT_FAIL("Failed to write to file.");
+  return HALA_OK;
+}
+
+void hala_rt_set_ground_color(hala_rt_renderer* r, const float rgba[4]) { if (r && rgba) memcpy(r->ground, rgba, 16); }
+void hala_rt_set_sky_color(hala_rt_renderer* r, const float rgba[4]) { if (r && rgba) memcpy(r->sky, rgba, 16); }
+void hala_rt_set_env_intensity(hala_rt_renderer* r, float v) { if (r) r->env_intensity = v; }
+void hala_rt_set_exposure_value(hala_rt_renderer* r, float v) { if (r) r->exposure = v; }
+
+int hala_rt_commit(hala_rt_renderer* r) {
+  if (ensure_device(r) != HALA_OK) return HALA_ERR;
+  if (!r->has_scene) RT_FAIL("The scene in GPU is none!");  // src/rt_renderer.rs:138
+  if (r->hs.cameras.empty()) RT_FAIL("The scene has no camera.");
+  if (r->hs.instances.empty()) RT_FAIL("The scene has no mesh primitive.");  // `primitives[0]` panics in the reference (gpu_uploader.rs:888)
+  if (build_bvh(r) != HALA_OK) return HALA_ERR;
+  r->committed = true;
+  r->reset_accumulation();
+  return HALA_OK;
+}
+
+int hala_rt_update(hala_rt_renderer* r, double, uint32_t, uint32_t) {
+  if (ensure_device(r) != HALA_OK) return HALA_ERR;
+  if (!r->committed) RT_FAIL("The pipeline is none!");  // src/rt_renderer.rs:443
+  r->total_frames += 1;                                    // pre_update -> inc_total_frames (src/renderer.rs:278)
+  if (r->total_frames > r->max_frames) return HALA_OK;     // :394-396
+  hala_global_uniform u{};                                 // :408-427
+  memcpy(u.ground_color, r->ground, 16); memcpy(u.sky_color, r->sky, 16);
+  u.resolution[0] = (float)r->width; u.resolution[1] = (float)r->height;
+  u.max_depth = r->max_depth; u.rr_depth = r->rr_depth;
+  u.frame_index = (uint32_t)(r->total_frames - 1);
+  u.camera_index = 0;
+  u.env_type = r->has_env ? 1u : 0u;
+  u.env_map_width = r->has_env ? r->env_w : 0; u.env_map_height = r->has_env ? r->env_h : 0;
+  u.env_total_sum = r->has_env ? r->env_total_sum : 0.0f;
+  u.env_rotation = r->env_rotation / 360.0f;
+  u.env_intensity = r->env_intensity; u.exposure_value = r->exposure;
+  u.enable_tonemap = r->enable_tonemap; u.enable_aces = r->enable_aces; u.use_simple_aces = r->use_simple_aces;
+  u.num_of_lights = (uint32_t)r->hs.lights.size();
+  r->last_uniform = u;
+
+  TraceEvents& te = r->ring[r->ring_pos];
+  r->ring_pos = (r->ring_pos + 1) % kStatRing;
+  r->resolve_slot(te);
+  if (!te.frame_begin) { RT_HIP(hipEventCreate(&te.frame_begin)); RT_HIP(hipEventCreate(&te.frame_end)); RT_HIP(hipHostMalloc(reinterpret_cast<void**>(&te.host_counts), 4 * sizeof(unsigned long long), hipHostMallocDefault)); }
+  te.used = 0; te.counted = r->counting;
+
+  const FrameConst fc = r->frame_const(u);
+  const SceneView sv = r->view();
+  const Queues q = r->queues();
+  const PathState ps = r->path_state();
+  Control* ctl = r->d_ctl.ptr;
+  hipStream_t s = r->stream;
+  RT_HIP(hipEventRecord(te.frame_begin, s));
+  RT_HIP(hipMemsetAsync(ctl, 0, sizeof(Control), s));
+  launch_raygen(fc, sv, q, ps, ctl, s);
+  for (uint32_t depth = 0; depth < r->max_depth; ++depth) {
+    hipEvent_t a = r->next_event(te), b = r->next_event(te);
+    RT_HIP(hipEventRecord(a, s));
+    launch_trace_batch(r->lcfg, sv, q.rays[depth & 1u], q.hits, &ctl->n_active[depth], 0, &ctl->work_closest[depth], ctl, false, r->counting, true, s);
+    RT_HIP(hipEventRecord(b, s));
+    launch_shade(fc, sv, q, ps, ctl, depth, s);
+    hipEvent_t c = r->next_event(te), d = r->next_event(te);
+    RT_HIP(hipEventRecord(c, s));
+    launch_trace_shadow(r->lcfg, sv, q, ps, ctl, depth, r->counting, s);
+    RT_HIP(hipEventRecord(d, s));
+  }
+  launch_resolve(fc, ps, r->img_local[0].ptr, r->img_local[1].ptr, r->img_local[2].ptr, r->img_local[3].ptr, s);
+  RT_HIP(hipMemcpyAsync(te.host_counts, &ctl->rays_closest, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  RT_HIP(hipEventRecord(te.frame_end, s));
+  RT_HIP(hipGetLastError());
+  te.pending = true;
+  for (bool& v : r->full_valid) v = false;
+  return HALA_OK;
+}
+
+int hala_rt_render(hala_rt_renderer* r) {  // src/rt_renderer.rs:475-502: nothing to present; make the frame's work visible
+  if (ensure_device(r) != HALA_OK) return HALA_ERR;
+  if (r->total_frames > r->max_frames) return HALA_OK;  // :484-486
+  RT_HIP(hipStreamSynchronize(r->stream));
+  return HALA_OK;
+}
+int hala_rt_wait_idle(hala_rt_renderer* r) {
+  if (ensure_device(r) != HALA_OK) return HALA_ERR;
+  RT_HIP(hipStreamSynchronize(r->stream));
+  return HALA_OK;
+}
+
+int hala_rt_read_image(hala_rt_renderer* r, int which, float* dst) {
+  if (ensure_device(r) != HALA_OK) return HALA_ERR;
+  if (which < 0 || which > 3 || !dst) RT_FAIL("Invalid image selector.");
+  RT_HIP(hipStreamSynchronize(r->stream));  // wait_idle (src/rt_renderer.rs:1242)
+  const size_t bytes = (size_t)r->width * r->height * sizeof(float4);
+  if (r->world <= 1) { RT_HIP(hipMemcpy(dst, r->img_local[which].ptr, bytes, hipMemcpyDeviceToHost)); return HALA_OK; }
+  if (!r->full_valid[which]) RT_FAIL("The frame is sharded across ranks: gather the tiles (hala_rt_scatter_gathered_tiles) before reading the image.");
+  RT_HIP(hipMemcpy(dst, r->img_full[which].ptr, bytes, hipMemcpyDeviceToHost));
+  return HALA_OK;
+}
+
+int hala_rt_save_images(hala_rt_renderer* r, const char* path) {
+  if (ensure_device(r) != HALA_OK) return HALA_ERR;
+  if (!path || !*path) RT_FAIL("The file name is none!");  // src/rt_renderer.rs:1234
+  std::string p(path);
+  const size_t slash = p.find_last_of("/\\");
+  const std::string dir = slash == std::string::npos ? "" : p.substr(0, slash + 1);
+  const std::string stem = file_stem(path);
+  std::vector<float> px((size_t)r->width * r->height * 4);
+  static const char* suffix[3] = {"_color.pfm", "_albedo.pfm", "_normal.pfm"};  // :1235-1237
+  for (int which = 0; which < 3; ++which) {
+    if (hala_rt_read_image(r, which, px.data()) != HALA_OK) return HALA_ERR;
+    if (which == 0) tonemap_pixels(px.data(), (size_t)r->width * r->height, r->enable_tonemap, r->enable_aces, r->use_simple_aces);  // :1256-1316
+    const std::string e = write_pfm((dir + stem + suffix[which]).c_str(), px.data(), r->width, r->height);
+    if (!e.empty()) RT_FAIL(e);
+  }
+  return HALA_OK;
+}
+
+int hala_rt_get_info(hala_rt_renderer* r, hala_rt_info* out) {
+  if (!r || !out) RT_FAIL("The renderer handle is null!");
+  out->width = r->width; out->height = r->height;
+  return HALA_OK;
+}
+int hala_rt_get_statistics(hala_rt_renderer* r, hala_rt_statistics* out) {
+  if (ensure_device(r) != HALA_OK) return HALA_ERR;
+  if (!out) RT_FAIL("The output pointer is null!");
+  RT_HIP(hipStreamSynchronize(r->stream));
+  for (int k = 0; k < kStatRing; ++k) r->resolve_slot(r->ring[(r->ring_pos + k) % kStatRing]);  // oldest first
+  r->stats.total_frames = r->total_frames;
+  *out = r->stats;
+  return HALA_OK;
+}
+int hala_rt_set_counting(hala_rt_renderer* r, int enable) {
+  if (!r) RT_FAIL("The renderer handle is null!");
+  r->counting = enable != 0;
+  return HALA_OK;
+}
+int hala_rt_get_global_uniform(hala_rt_renderer* r, hala_global_uniform* out) {
+  if (!r || !out) RT_FAIL("The renderer handle is null!");
+  *out = r->last_uniform;
+  return HALA_OK;
+}
+
+#define RT_READBACK(dev, T, dst, cap, cnt)                                                               \
+  do {                                                                                                     \
+    *(cnt) = (uint32_t)(dev).count;                                                                        \
+    const size_t _n = std::min<size_t>((cap), (dev).count);                                                \
+    if ((dst) && _n) RT_HIP(hipMemcpy((dst), (dev).ptr, _n * sizeof(T), hipMemcpyDeviceToHost));           \
+  } while (0)
+
+int hala_rt_get_packed_cameras(hala_rt_renderer* r, hala_gpu_camera* dst, uint32_t capacity, uint32_t* count) {
+  if (ensure_device(r) != HALA_OK) return HALA_ERR;
+  if (!r->has_scene || !count) RT_FAIL("The scene in GPU is none!");
+  RT_READBACK(r->d_cameras, hala_gpu_camera, dst, capacity, count);
+  return HALA_OK;
+}
+int hala_rt_get_packed_lights(hala_rt_renderer* r, hala_gpu_light* dst, hala_aabb* bb, uint32_t capacity, uint32_t* count) {
+  if (ensure_device(r) != HALA_OK) return HALA_ERR;
+  if (!r->has_scene || !count) RT_FAIL("The scene in GPU is none!");
+  RT_READBACK(r->d_lights, hala_gpu_light, dst, capacity, count);
+  if (bb) memcpy(bb, r->hs.light_aabbs.data(), std::min<size_t>(capacity, r->hs.light_aabbs.size()) * sizeof(hala_aabb));
+  return HALA_OK;
+}
+int hala_rt_get_packed_materials(hala_rt_renderer* r, hala_gpu_material* dst, uint32_t capacity, uint32_t* count) {
+  if (ensure_device(r) != HALA_OK) return HALA_ERR;
+  if (!r->has_scene || !count) RT_FAIL("The scene in GPU is none!");
+  RT_READBACK(r->d_materials, hala_gpu_material, dst, capacity, count);
+  return HALA_OK;
+}
+int hala_rt_get_packed_primitives(hala_rt_renderer* r, hala_gpu_mesh_data* dst, float* t3x4, uint32_t capacity, uint32_t* count) {
+  if (ensure_device(r) != HALA_OK) return HALA_ERR;
+  if (!r->has_scene || !count) RT_FAIL("The scene in GPU is none!");
+  RT_READBACK(r->d_instances, hala_gpu_mesh_data, dst, capacity, count);
+  if (t3x4) memcpy(t3x4, r->hs.instance_3x4.data(), std::min<size_t>(capacity, r->hs.instances.size()) * 12 * sizeof(float));
+  return HALA_OK;
+}
+int hala_rt_get_env_distribution(hala_rt_renderer* r, float* total_sum, float* marginal, float* conditional) {
+  if (ensure_device(r) != HALA_OK) return HALA_ERR;
+  if (!r->has_env) RT_FAIL("The environment map is none!");
+  if (total_sum) *total_sum = r->env_total_sum;
+  if (marginal) RT_HIP(hipMemcpy(marginal, r->d_marginal.ptr, (size_t)r->env_h * 4, hipMemcpyDeviceToHost));
+  if (conditional) RT_HIP(hipMemcpy(conditional, r->d_conditional.ptr, (size_t)r->env_w * r->env_h * 4, hipMemcpyDeviceToHost));
+  return HALA_OK;
+}
+
+// ---- multi-GPU tiles ------------------------------------------------------------------------------------------------
+int hala_rt_set_tile_shard(hala_rt_renderer* r, uint32_t rank, uint32_t world, uint32_t tile_size) {
+  if (ensure_device(r) != HALA_OK) return HALA_ERR;
+  if (world == 0 || rank >= world) RT_FAIL("Invalid rank / world size.");
+  if (tile_size == 0 || tile_size > 256) RT_FAIL("Invalid tile size.");
+  RT_HIP(hipStreamSynchronize(r->stream));
+  r->rank = rank; r->world = world; r->tile_size = tile_size;
+  compute_tiling(r);
+  if (alloc_frame_buffers(r) != HALA_OK) return HALA_ERR;
+  RT_HIP(hipStreamSynchronize(r->stream));
+  r->reset_accumulation();
+  return HALA_OK;
+}
+int hala_rt_tile_buffer(hala_rt_renderer* r, int which, void** d_ptr, size_t* bytes) {
+  if (!r || which < 0 || which > 3 || !d_ptr || !bytes) RT_FAIL("Invalid argument.");
+  *d_ptr = r->img_local[which].ptr;
+  *bytes = (size_t)r->slot_count * sizeof(float4);
+  return HALA_OK;
+}
+int hala_rt_scatter_gathered_tiles(hala_rt_renderer* r, int which, const void* d_gathered, size_t bytes) {
+  if (ensure_device(r) != HALA_OK) return HALA_ERR;
+  if (which < 0 || which > 3 || !d_gathered) RT_FAIL("Invalid argument.");
+  if (r->world <= 1) RT_FAIL("The renderer is not sharded.");
+  if (bytes != (size_t)r->slot_count * r->world * sizeof(float4)) RT_FAIL("The gathered buffer has the wrong size.");
+  RT_HIP(r->img_full[which].resize((size_t)r->width * r->height));
+  hala_global_uniform u = r->last_uniform;
+  const FrameConst fc = r->frame_const(u);
+  launch_scatter_tiles(fc, static_cast<const float4*>(d_gathered), r->img_full[which].ptr, r->stream);
+  RT_HIP(hipStreamSynchronize(r->stream));
+  r->full_valid[which] = true;
+  return HALA_OK;
+}
+
+// ---- ray-batch operator ------------------------------------------------------------------------------------------------
+int hala_rt_trace_rays(hala_rt_renderer* r, const hala_ray* d_rays, hala_hit* d_hits, uint32_t count, int mode, uint64_t* d_counters, void* hip_stream) {
+  if (ensure_device(r) != HALA_OK) return HALA_ERR;
+  if (!r->committed) RT_FAIL("The top level acceleration structure is none!");  // src/rt_renderer.rs:284
+  if (mode != 0 && mode != 1) RT_FAIL("Invalid trace mode.");
+  if (count == 0) return HALA_OK;
+  if (!d_rays || !d_hits) RT_FAIL("The ray batch is null!");
+  hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : r->stream;
+  RT_HIP(hipMemsetAsync(r->d_batch_work.ptr, 0, 4, s));
+  // counters: the kernel accumulates into the control block's 64-bit fields; copy them out if requested
+  if (d_counters) RT_HIP(hipMemsetAsync(&r->d_ctl.ptr->nodes_visited, 0, 16, s));
+  launch_trace_batch(r->lcfg, r->view(), d_rays, d_hits, nullptr, count, r->d_batch_work.ptr, r->d_ctl.ptr, mode == 1, d_counters != nullptr, false, s);
+  if (d_counters) RT_HIP(hipMemcpyAsync(d_counters, &r->d_ctl.ptr->nodes_visited, 16, hipMemcpyDeviceToDevice, s));
+  RT_HIP(hipGetLastError());
+  return HALA_OK;
+}
+int hala_rt_trace_rays_indirect(hala_rt_renderer* r, const hala_ray* d_rays, hala_hit* d_hits, const uint32_t* d_indirect, int mode, void* hip_stream) {
+  if (ensure_device(r) != HALA_OK) return HALA_ERR;
+  if (!d_indirect) RT_FAIL("The indirect command address is null!");
+  hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : r->stream;
+  uint32_t whd[3] = {0, 0, 0};
+  RT_HIP(hipMemcpyAsync(whd, d_indirect, 12, hipMemcpyDeviceToHost, s));
+  RT_HIP(hipStreamSynchronize(s));
+  const uint64_t n = (uint64_t)whd[0] * whd[1] * whd[2];
+  if (n > 0xffffffffull) RT_FAIL("The indirect launch is too large.");
+  return hala_rt_trace_rays(r, d_rays, d_hits, (uint32_t)n, mode, nullptr, hip_stream);
+}
+int hala_rt_trace_rays_host(hala_rt_renderer* r, const hala_ray* rays, hala_hit* hits, uint32_t count, int mode, uint64_t counters[2]) {
+  if (ensure_device(r) != HALA_OK) return HALA_ERR;
+  if (count == 0) return HALA_OK;
+  DeviceArray<hala_ray> d_rays;
+  DeviceArray<hala_hit> d_hits;
+  DeviceArray<uint64_t> d_ctr;
+  RT_HIP(d_rays.upload(rays, count, r->stream));
+  RT_HIP(d_hits.resize(count));
+  if (counters) RT_HIP(d_ctr.resize(2));
+  if (hala_rt_trace_rays(r, d_rays.ptr, d_hits.ptr, count, mode, counters ? d_ctr.ptr : nullptr, r->stream) != HALA_OK) return HALA_ERR;
+  RT_HIP(hipMemcpyAsync(hits, d_hits.ptr, (size_t)count * sizeof(hala_hit), hipMemcpyDeviceToHost, r->stream));
+  if (counters) RT_HIP(hipMemcpyAsync(counters, d_ctr.ptr, 16, hipMemcpyDeviceToHost, r->stream));
+  RT_HIP(hipStreamSynchronize(r->stream));
+  return HALA_OK;
+}
+
+int hala_rt_get_bvh_info(hala_rt_renderer* r, hala_bvh_info* out) {
+  if (!r || !out) RT_FAIL("The renderer handle is null!");
+  if (!r->committed) RT_FAIL("The top level acceleration structure is none!");
+  out->node_count = r->bvh.node_count; out->triangle_count = r->bvh.tri_count; out->max_depth = r->bvh.max_depth; out->lds_node_count = r->lds_nodes;
+  memcpy(out->scene_min, r->bvh.scene_min, 12); memcpy(out->scene_max, r->bvh.scene_max, 12);
+  return HALA_OK;
+}
+int hala_rt_download_bvh(hala_rt_renderer* r, void* nodes_64B, void* triangles_48B) {
+  if (ensure_device(r) != HALA_OK) return HALA_ERR;
+  if (!r->committed) RT_FAIL("The top level acceleration structure is none!");
+  RT_HIP(hipStreamSynchronize(r->stream));
+  if (nodes_64B) RT_HIP(hipMemcpy(nodes_64B, r->d_nodes.ptr, (size_t)r->bvh.node_count * 64, hipMemcpyDeviceToHost));
+  if (triangles_48B && r->bvh.tri_count) RT_HIP(hipMemcpy(triangles_48B, r->d_tris.ptr, (size_t)r->bvh.tri_count * 48, hipMemcpyDeviceToHost));
+  return HALA_OK;
+}
+
+int hala_rt_update_node_transform(hala_rt_renderer* r, uint32_t node_index, const float local_transform[16]) {
+  if (!r || !local_transform) RT_FAIL("Invalid argument.");
+  if (!r->has_scene || node_index >= r->hs.nodes.size()) RT_FAIL("The node does not exist.");
+  memcpy(r->hs.nodes[node_index].local.m, local_transform, 64);
+  return HALA_OK;
+}
+int hala_rt_refit(hala_rt_renderer* r) {
+  if (ensure_device(r) != HALA_OK) return HALA_ERR;
+  if (!r->committed) RT_FAIL("The top level acceleration structure is none!");
+  RT_HIP(hipStreamSynchronize(r->stream));
+  r->hs.update_node_hierarchies();
+  const std::string e = r->hs.pack();
+  if (!e.empty()) RT_FAIL(e);
+  if (upload_packed(r) != HALA_OK) return HALA_ERR;
+  r->bvh.primitives = r->d_instances.ptr; r->bvh.inst_first_tri = r->d_inst_first_tri.ptr;
+  const std::string e2 = bvh_refit(r->bvh, r->stream);
+  if (!e2.empty()) RT_FAIL(e2);
+  if (configure_traversal(r) != HALA_OK) return HALA_ERR;
+  r->reset_accumulation();  // like the device-lost path: accumulation restarts (src/rt_renderer.rs:557)
+  return HALA_OK;
+}
+
+// ---- stand-alone pieces ---------------------------------------------------------------------------------------------------
+int hala_envmap_build_distribution(int device_ordinal, const float* rgba32f, uint32_t width, uint32_t height, float* total_sum, float* marginal, float* conditional) {
+  if (!rgba32f || !total_sum || !marginal || !conditional || !width || !height) RT_FAIL("Invalid argument.");
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) RT_FAIL("No HIP device is available: libhalart has no CPU path.");
+  RT_HIP(hipSetDevice(device_ordinal));
+  DeviceArray<float4> d_px;
+  DeviceArray<float> d_total, d_m, d_c;
+  const size_t n = (size_t)width * height;
+  RT_HIP(d_px.upload(reinterpret_cast<const float4*>(rgba32f), n, nullptr));
+  RT_HIP(d_total.resize(1)); RT_HIP(d_m.resize(height)); RT_HIP(d_c.resize(n));
+  const std::string e = envmap_build_distribution(d_px.ptr, width, height, d_total.ptr, d_m.ptr, d_c.ptr, nullptr);
+  if (!e.empty()) RT_FAIL(e);
+  RT_HIP(hipMemcpy(total_sum, d_total.ptr, 4, hipMemcpyDeviceToHost));
+  RT_HIP(hipMemcpy(marginal, d_m.ptr, (size_t)height * 4, hipMemcpyDeviceToHost));
+  RT_HIP(hipMemcpy(conditional, d_c.ptr, n * 4, hipMemcpyDeviceToHost));
+  return HALA_OK;
+}
+
+void hala_tonemap_pixels(float* rgba32f, size_t pixel_count, int enable_tonemap, int enable_aces, int use_simple_aces) {
+  if (rgba32f) tonemap_pixels(rgba32f, pixel_count, enable_tonemap, enable_aces, use_simple_aces);
+}
+int hala_write_pfm(const char* path, const float* rgba32f, uint32_t width, uint32_t height) {
+  if (!path || !rgba32f) RT_FAIL("Invalid argument.");
+  const std::string e = write_pfm(path, rgba32f, width, height);
+  if (!e.empty()) RT_FAIL(e);
+  return HALA_OK;
+}
+
+int hala_rtprog_parse_desc(const char* desc_json, hala_rtprog_desc_info* out) {
+  // serde field names and defaults of HalaRayTracingProgramDesc (src/raytracing_program.rs:33-55)
+  if (!desc_json || !out) RT_FAIL("Invalid argument.");
+  JsonValue root;
+  const std::string e = json_parse(desc_json, &root);
+  if (!e.empty()) RT_FAIL("Failed to parse the ray tracing program description: " + e);
+  if (root.kind != JsonValue::Object) RT_FAIL("The ray tracing program description is not an object.");
+  auto string_array = [&](const char* key, bool required, uint32_t* n) -> int {
+    const JsonValue* v = root.find(key);
+    if (!v) { if (required) RT_FAIL(std::string("missing field `") + key + "`"); *n = 0; return HALA_OK; }
+    if (v->kind != JsonValue::Array) RT_FAIL(std::string("field `") + key + "` is not an array");
+    for (const auto& it : v->items) if (it.kind != JsonValue::String) RT_FAIL(std::string("field `") + key + "` must hold strings");
+    *n = (uint32_t)v->items.size();
+    return HALA_OK;
+  };
+  memset(out, 0, sizeof(*out));
+  if (string_array("raygen_shader_file_paths", true, &out->raygen_count) != HALA_OK) return HALA_ERR;
+  if (string_array("miss_shader_file_paths", false, &out->miss_count) != HALA_OK) return HALA_ERR;
+  if (string_array("callable_shader_file_paths", false, &out->callable_count) != HALA_OK) return HALA_ERR;
+  if (string_array("bindings", false, &out->binding_count) != HALA_OK) return HALA_ERR;
+  const JsonValue* hits = root.find("hit_shader_file_paths");
+  if (!hits) RT_FAIL("missing field `hit_shader_file_paths`");
+  if (hits->kind != JsonValue::Array) RT_FAIL("field `hit_shader_file_paths` is not an array");
+  for (const auto& h : hits->items) {
+    if (h.kind != JsonValue::Object) RT_FAIL("a hit shader description is not an object");
+    for (const auto& m : h.members) {
+      if (m.first != "closest_hit_shader_file_path" && m.first != "any_hit_shader_file_path" && m.first != "intersection_shader_file_path") continue;
+      if (m.second.kind != JsonValue::String && m.second.kind != JsonValue::Null) RT_FAIL("field `" + m.first + "` must be a string or null");
+    }
+  }
+  out->hit_count = (uint32_t)hits->items.size();
+  auto u32_field = [&](const char* key, uint32_t def, uint32_t* dst) -> int {
+    const JsonValue* v = root.find(key);
+    if (!v) { *dst = def; return HALA_OK; }
+    if (v->kind != JsonValue::Number || v->num < 0 || v->num > 4294967295.0 || v->num != std::floor(v->num)) RT_FAIL(std::string("field `") + key + "` is not a u32");
+    *dst = (uint32_t)v->num;
+    return HALA_OK;
+  };
+  if (u32_field("push_constant_size", 0, &out->push_constant_size) != HALA_OK) return HALA_ERR;
+  if (u32_field("ray_recursion_depth", 1, &out->ray_recursion_depth) != HALA_OK) return HALA_ERR;  // default_ray_recursion_depth :53-55
+  return HALA_OK;
+}
+
+}  // extern "C"

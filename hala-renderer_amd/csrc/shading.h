@@ -1,0 +1,344 @@
+// shading.h — device code for what the reference's (absent) raygen / closest-hit / miss / callable shaders
+// do between two traversals (docs/RENDER_SPEC.md §5-§8).  The records consumed are exactly the reference's
+// bindings: HalaGlobalUniform (src/rt_renderer.rs:44-65), cameras/lights/materials/primitives
+// (src/rt_renderer.rs:141-181), vertex/index buffers by device address (gpu_uploader.rs:869-870) and the
+// env tables (src/envmap.rs:239-388).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "hala_types.h"
+#include "rt_math.h"
+
+namespace rt {
+
+// ---- §9 pixel slots -------------------------------------------------------------------------------------
+// world == 1: slot == pixel id (row-major).  world > 1: tile-major slots of this rank's tiles.
+RT_DI bool slot_to_pixel(const FrameConst& fc, uint32_t slot, uint32_t* px, uint32_t* py) {
+  if (fc.world <= 1u) {
+    *py = slot / fc.width;
+    *px = slot - *py * fc.width;
+    return true;
+  }
+  const uint32_t ts2 = fc.tile_size * fc.tile_size;
+  const uint32_t lt = slot / ts2, within = slot - lt * ts2;
+  const uint32_t ly = within / fc.tile_size, lx = within - ly * fc.tile_size;
+  const uint32_t n = fc.tiles_x * fc.tiles_y;
+  const uint32_t k = lt * fc.world + fc.rank;  // position in the dealing order
+  if (k >= n) return false;                    // padding tile
+  // tile t with (t * A + B) % n == k  ->  t = ((k + n - B % n) * A^-1) % n ; perm_a holds A^-1 here
+  const uint32_t t = (uint32_t)(((unsigned long long)((k + n - fc.perm_b % n) % n) * fc.perm_a) % n);
+  const uint32_t ty = t / fc.tiles_x, tx = t - ty * fc.tiles_x;
+  *px = tx * fc.tile_size + lx;
+  *py = ty * fc.tile_size + ly;
+  return *px < fc.width && *py < fc.height;
+}
+
+// ---- §5 camera ---------------------------------------------------------------------------------------------
+RT_DI void camera_ray(const FrameConst& fc, const hala_gpu_camera& cam, uint32_t px, uint32_t py, uint32_t& rng, f3* o, f3* d) {
+  float r1 = rng_next(rng), r2 = rng_next(rng), r3 = rng_next(rng), r4 = rng_next(rng);
+  float fx = ((float)px + r1) / fc.u.resolution[0];
+  float fy = ((float)py + r2) / fc.u.resolution[1];
+  float ndc_x = fx * 2.0f - 1.0f;
+  float ndc_y = 1.0f - fy * 2.0f;
+  f3 pos = ld3(cam.position), right = ld3(cam.right), up = ld3(cam.up), fwd = ld3(cam.forward);
+  if (cam.type == 0u) {
+    float dx = ndc_x * fc.aspect * fc.tan_half;
+    float dy = ndc_y * fc.tan_half;
+    f3 dir = normalize3(madd3(up, dy, madd3(right, dx, fwd)));
+    float aperture = cam.aperture_or_ymag;
+    if (aperture > 0.0f) {
+      float ft = cam.focal_distance_or_xmag / dot3(dir, fwd);
+      f3 focus = madd3(dir, ft, pos);
+      float r = aperture * sqrtf(r3);
+      float s, c;
+      sincos_2pi(r4, &s, &c);
+      f3 org = madd3(up, r * s, madd3(right, r * c, pos));
+      *o = org;
+      *d = normalize3(focus - org);
+    } else {
+      *o = pos;
+      *d = dir;
+    }
+  } else {
+    *o = madd3(up, ndc_y * cam.aperture_or_ymag, madd3(right, ndc_x * cam.focal_distance_or_xmag, pos));
+    *d = normalize3(fwd);
+  }
+}
+
+// ---- §7.3 environment ----------------------------------------------------------------------------------------
+RT_DI int wrapi(int i, int n) {
+  int m = i % n;
+  return m < 0 ? m + n : m;
+}
+RT_DI f3 env_texel(const SceneView& sv, int w, int x, int y) {
+  const float4 p = reinterpret_cast<const float4*>(sv.env_pixels)[(size_t)y * w + x];
+  return mk3(p.x, p.y, p.z);
+}
+RT_DI void env_dir_to_uv(const FrameConst& fc, f3 d, float* uu, float* vv) {
+  float theta = acos_poly(clampf(d.y, -1.0f, 1.0f));
+  float phi = atan2_poly(d.z, d.x);
+  *uu = (kPi + phi) * kInvTwoPi + fc.u.env_rotation;
+  *vv = theta * kInvPi;
+}
+RT_DI f3 env_map_eval(const FrameConst& fc, const SceneView& sv, f3 d) {
+  const int W = (int)fc.u.env_map_width, H = (int)fc.u.env_map_height;
+  float uu, vv;
+  env_dir_to_uv(fc, d, &uu, &vv);
+  float x = uu * (float)W - 0.5f, y = vv * (float)H - 0.5f;
+  float x0 = floorf(x), y0 = floorf(y);
+  float fx = x - x0, fy = y - y0;
+  int ix0 = wrapi((int)x0, W), iy0 = wrapi((int)y0, H);
+  int ix1 = wrapi(ix0 + 1, W), iy1 = wrapi(iy0 + 1, H);
+  f3 c00 = env_texel(sv, W, ix0, iy0), c10 = env_texel(sv, W, ix1, iy0), c01 = env_texel(sv, W, ix0, iy1), c11 = env_texel(sv, W, ix1, iy1);
+  f3 top = c00 * (1.0f - fx) + c10 * fx;
+  f3 bot = c01 * (1.0f - fx) + c11 * fx;
+  return (top * (1.0f - fy) + bot * fy) * fc.u.env_intensity;
+}
+RT_DI float env_map_pdf(const FrameConst& fc, const SceneView& sv, f3 d) {
+  const int W = (int)fc.u.env_map_width, H = (int)fc.u.env_map_height;
+  float uu, vv;
+  env_dir_to_uv(fc, d, &uu, &vv);
+  int ix = wrapi((int)floorf(uu * (float)W), W);
+  int iy = min((int)(vv * (float)H), H - 1);
+  float lum = luminance(env_texel(sv, W, ix, iy));
+  float st = sqrtf(maxf(0.0f, 1.0f - d.y * d.y));
+  if (!(st > 0.0f) || !(lum > 0.0f)) return 0.0f;
+  return (lum * (float)(fc.u.env_map_width * fc.u.env_map_height)) / (fc.u.env_total_sum * kTwoPiSq * st);
+}
+RT_DI bool env_map_sample(const FrameConst& fc, const SceneView& sv, float r1, float r2, f3* wi, float* pdf) {
+  const int W = (int)fc.u.env_map_width, H = (int)fc.u.env_map_height;
+  float fy = r1 * (float)H;
+  int iy = min((int)fy, H - 1);
+  float mv = sv.env_marginal[iy];
+  if (!(mv >= 0.0f)) mv = 0.0f;
+  int row = min((int)(mv * (float)H + 0.5f), H - 1);
+  float fxx = r2 * (float)W;
+  int ix = min((int)fxx, W - 1);
+  float cu = sv.env_conditional[(size_t)row * W + ix];
+  if (!(cu >= 0.0f)) cu = 0.0f;
+  int col = min((int)(cu * (float)W + 0.5f), W - 1);
+  float ju = fxx - (float)ix, jv = fy - (float)iy;
+  float uu = ((float)col + ju) / (float)W;
+  float vv = ((float)row + jv) / (float)H;
+  float t = uu - fc.u.env_rotation;
+  t = t - floorf(t);
+  if (t >= 1.0f) t = 0.0f;
+  float sp, cp, st, ct;
+  sincos_2pi(t, &sp, &cp);
+  sincos_2pi(vv * 0.5f, &st, &ct);
+  *wi = mk3(-st * cp, ct, -st * sp);
+  float lum = luminance(env_texel(sv, W, col, row));
+  if (!(st > 0.0f) || !(lum > 0.0f)) { *pdf = 0.0f; return false; }
+  *pdf = (lum * (float)(fc.u.env_map_width * fc.u.env_map_height)) / (fc.u.env_total_sum * kTwoPiSq * st);
+  return true;
+}
+RT_DI f3 sky_eval(const FrameConst& fc, f3 d) {
+  float t = 0.5f * (d.y + 1.0f);
+  f3 g = ld3(fc.u.ground_color), s = ld3(fc.u.sky_color);
+  return (g * (1.0f - t) + s * t) * fc.u.env_intensity;
+}
+
+// ---- §7.1 materials ----------------------------------------------------------------------------------------------
+struct MatView {
+  f3 base, emission;
+  float ax, ay;
+  uint32_t type;
+};
+RT_DI void bsdf_eval(const MatView& m, f3 wo, f3 wi, f3 n, f3* f, float* pdf) {
+  float nl = dot3(n, wi), nv = dot3(n, wo);
+  if (!(nl > 0.0f && nv > 0.0f)) { *f = splat3(0.0f); *pdf = 0.0f; return; }
+  float s = dot3(wi, wo) - nl * nv;
+  float tterm = maxf(0.0f, s) / maxf(nl, nv);
+  float k = kInvPi * (m.ax + m.ay * tterm);
+  *f = m.base * k;
+  *pdf = nl * kInvPi;
+}
+RT_DI bool bsdf_sample(const MatView& m, f3 wo, f3 n, float r1, float r2, float /*r3*/, f3* wi, f3* f, float* pdf) {
+  f3 t, b;
+  onb(n, &t, &b);
+  f3 l = cosine_hemisphere(r1, r2);
+  *wi = to_world(l, t, b, n);
+  bsdf_eval(m, wo, *wi, n, f, pdf);
+  return *pdf > 0.0f;
+}
+
+// ---- §7.2 lights --------------------------------------------------------------------------------------------------
+struct LightSample {
+  f3 wi, le;
+  float dist, pdf;
+  bool delta, valid;
+};
+RT_DI LightSample sample_light(const hala_gpu_light& l, f3 P, float r1, float r2) {
+  LightSample s;
+  s.valid = false; s.delta = true; s.pdf = 0.0f; s.dist = kTMax; s.le = splat3(0.0f); s.wi = mk3(0.0f, 1.0f, 0.0f);
+  f3 inten = ld3(l.intensity), pos = ld3(l.position);
+  if (l.type == 0u || l.type == 2u) {  // POINT, SPOT
+    f3 to = pos - P;
+    float d2 = dot3(to, to);
+    if (!(d2 > 0.0f)) return s;
+    float dist = sqrtf(d2);
+    s.wi = to * (1.0f / dist);
+    s.dist = dist;
+    s.le = inten * (1.0f / d2);
+    if (l.type == 2u) {
+      f3 axis = normalize3(ld3(l.u));
+      float cosang = -dot3(s.wi, axis);
+      float ci = l.v[0], co = l.v[1];
+      float t;
+      if (ci > co) t = clampf((cosang - co) / (ci - co), 0.0f, 1.0f); else t = cosang >= co ? 1.0f : 0.0f;
+      float sm = t * t * (3.0f - 2.0f * t);
+      s.le = s.le * sm;
+    }
+    s.valid = true;
+  } else if (l.type == 1u) {  // DIRECTIONAL
+    f3 axis = normalize3(-ld3(l.u));
+    float cosmax = l.v[0];
+    if (cosmax >= 1.0f) s.wi = axis;
+    else {
+      float ct = 1.0f - r1 * (1.0f - cosmax);
+      float st = sqrtf(maxf(0.0f, 1.0f - ct * ct));
+      float sp, cp;
+      sincos_2pi(r2, &sp, &cp);
+      f3 t, b;
+      onb(axis, &t, &b);
+      s.wi = to_world(mk3(st * cp, st * sp, ct), t, b, axis);
+    }
+    s.dist = kTMax;
+    s.le = inten;
+    s.valid = true;
+  } else if (l.type == 3u) {  // QUAD
+    f3 u = ld3(l.u), v = ld3(l.v);
+    f3 pt = madd3(v, r2, madd3(u, r1, pos));
+    f3 n = normalize3(cross3(u, v));
+    f3 to = pt - P;
+    float d2 = dot3(to, to);
+    if (!(d2 > 0.0f)) return s;
+    float dist = sqrtf(d2);
+    s.wi = to * (1.0f / dist);
+    float cosl = -dot3(s.wi, n);
+    if (!(cosl > 0.0f)) return s;
+    s.dist = dist; s.le = inten; s.pdf = d2 / (l.area * cosl); s.delta = false; s.valid = true;
+  } else if (l.type == 4u) {  // SPHERE
+    float z = 1.0f - 2.0f * r1;
+    float rr = sqrtf(maxf(0.0f, 1.0f - z * z));
+    float sp, cp;
+    sincos_2pi(r2, &sp, &cp);
+    f3 nl = mk3(rr * cp, rr * sp, z);
+    f3 pt = madd3(nl, l.radius, pos);
+    f3 to = pt - P;
+    float d2 = dot3(to, to);
+    if (!(d2 > 0.0f)) return s;
+    float dist = sqrtf(d2);
+    s.wi = to * (1.0f / dist);
+    float cosl = -dot3(s.wi, nl);
+    if (!(cosl > 0.0f)) return s;
+    s.dist = dist; s.le = inten; s.pdf = d2 / (l.area * cosl); s.delta = false; s.valid = true;
+  }
+  return s;
+}
+// analytic intersection of the hittable lights (the light BLAS of gpu_uploader.rs:818-840 + its intersection shader)
+RT_DI float intersect_light(const hala_gpu_light& l, f3 o, f3 d, float* pdf) {
+  f3 pos = ld3(l.position);
+  if (l.type == 3u) {
+    f3 u = ld3(l.u), v = ld3(l.v);
+    f3 n = normalize3(cross3(u, v));
+    float dn = dot3(d, n);
+    if (!(dn < 0.0f)) return -1.0f;
+    float t = dot3(pos - o, n) / dn;
+    if (!(t > 0.0f)) return -1.0f;
+    f3 hp = madd3(d, t, o) - pos;
+    float a = dot3(hp, u) / dot3(u, u), b = dot3(hp, v) / dot3(v, v);
+    if (!(a >= 0.0f && a <= 1.0f && b >= 0.0f && b <= 1.0f)) return -1.0f;
+    *pdf = (t * t) / (l.area * (-dn));
+    return t;
+  }
+  if (l.type == 4u) {
+    f3 oc = o - pos;
+    float b = dot3(oc, d);
+    float c = dot3(oc, oc) - l.radius * l.radius;
+    float disc = b * b - c;
+    if (!(disc > 0.0f)) return -1.0f;
+    float t = -b - sqrtf(disc);
+    if (!(t > 0.0f)) return -1.0f;
+    f3 nl = (madd3(d, t, o) - pos) * (1.0f / l.radius);
+    float cosl = -dot3(d, nl);
+    if (!(cosl > 0.0f)) return -1.0f;
+    *pdf = (t * t) / (l.area * cosl);
+    return t;
+  }
+  return -1.0f;
+}
+
+// ---- §6 surface reconstruction ------------------------------------------------------------------------------------------
+RT_DI f3 transform_normal(const float* m, f3 n) {
+  f3 c0 = mk3(m[0], m[1], m[2]), c1 = mk3(m[4], m[5], m[6]), c2 = mk3(m[8], m[9], m[10]);
+  f3 k0 = cross3(c1, c2), k1 = cross3(c2, c0), k2 = cross3(c0, c1);
+  float det = dot3(c0, k0);
+  f3 r = mk3(__fmaf_rn(k2.x, n.z, __fmaf_rn(k1.x, n.y, k0.x * n.x)), __fmaf_rn(k2.y, n.z, __fmaf_rn(k1.y, n.y, k0.y * n.x)),
+             __fmaf_rn(k2.z, n.z, __fmaf_rn(k1.z, n.y, k0.z * n.x)));
+  return det < 0.0f ? -r : r;
+}
+
+struct Surface {
+  f3 P, ns, ng;
+  MatView mat;
+};
+RT_DI Surface make_surface(const SceneView& sv, f3 o, f3 d, float t, float u, float v, uint32_t prim) {
+  Surface sf;
+  const float4* tp = reinterpret_cast<const float4*>(sv.tris_by_id + prim);
+  const float4 tb = tp[1], tc = tp[2];
+  const uint32_t inst = sv.tri_instance[prim];
+  const hala_gpu_mesh_data& md = sv.primitives[inst];
+  const uint32_t lt = prim - sv.inst_first_tri[inst];
+  const uint32_t* idx = reinterpret_cast<const uint32_t*>(md.indices) + 3 * (size_t)lt;
+  const hala_vertex* vb = reinterpret_cast<const hala_vertex*>(md.vertices);
+  const hala_vertex& a = vb[idx[0]];
+  const hala_vertex& b = vb[idx[1]];
+  const hala_vertex& c = vb[idx[2]];
+  float w0 = 1.0f - u - v;
+  f3 nl = madd3(ld3(c.normal), v, madd3(ld3(b.normal), u, ld3(a.normal) * w0));
+  sf.ns = normalize3(transform_normal(md.transform, nl));
+  sf.ng = normalize3(cross3(mk3(tb.x, tb.y, tb.z), mk3(tc.x, tc.y, tc.z)));
+  if (dot3(sf.ns, sf.ng) < 0.0f) sf.ng = -sf.ng;
+  if (dot3(sf.ng, d) > 0.0f) { sf.ns = -sf.ns; sf.ng = -sf.ng; }
+  sf.P = madd3(d, t, o);
+  const hala_gpu_material& m = sv.materials[md.material_index];
+  sf.mat.base = ld3(m.base_color);
+  sf.mat.emission = ld3(m.emission);
+  sf.mat.ax = m.ax; sf.mat.ay = m.ay; sf.mat.type = m.type;
+  return sf;
+}
+
+// §8 running mean
+RT_DI float fold_mean(float mean_old, float x, uint32_t frame_index) {
+  if (frame_index == 0u) return x;
+  return (mean_old * (float)frame_index + x) / (float)(frame_index + 1u);
+}
+
+// src/rt_renderer.rs:1256-1311 on the device (the raygen stage writes the tonemapped final image, :688)
+RT_DI f3 clamp01(f3 c) { return mk3(clampf(c.x, 0.0f, 1.0f), clampf(c.y, 0.0f, 1.0f), clampf(c.z, 0.0f, 1.0f)); }
+RT_DI f3 mat3_mul(f3 c0, f3 c1, f3 c2, f3 v) {
+  return mk3(c0.x * v.x + c1.x * v.y + c2.x * v.z, c0.y * v.x + c1.y * v.y + c2.y * v.z, c0.z * v.x + c1.z * v.y + c2.z * v.z);
+}
+RT_DI f3 tonemap_select(f3 color, uint32_t enable_tonemap, uint32_t enable_aces, uint32_t use_simple_aces) {
+  if (!enable_tonemap) return color;
+  if (enable_aces) {
+    if (use_simple_aces) {
+      const float A = 2.51f, B = 0.03f, Y = 2.43f, D = 0.59f, E = 0.14f;
+      f3 num = color * (color * A + splat3(B));
+      f3 den = color * (color * Y + splat3(D)) + splat3(E);
+      return clamp01(mk3(num.x / den.x, num.y / den.y, num.z / den.z));
+    }
+    f3 c = mat3_mul(mk3(0.59719f, 0.07600f, 0.02840f), mk3(0.35458f, 0.90834f, 0.13383f), mk3(0.04823f, 0.01566f, 0.83777f), color);
+    f3 a = c * (c + splat3(0.0245786f)) - splat3(0.000090537f);
+    f3 b = c * (c * 0.983729f + splat3(0.432951f)) + splat3(0.238081f);
+    c = mk3(a.x / b.x, a.y / b.y, a.z / b.z);
+    c = mat3_mul(mk3(1.60475f, -0.10208f, -0.00327f), mk3(-0.53108f, 1.10813f, -0.07276f), mk3(-0.07367f, -0.00605f, 1.07602f), c);
+    return clamp01(c);
+  }
+  float dd = 1.0f + luminance(color) / 1.5f;
+  f3 n = color * 1.0f;
+  return mk3(n.x / dd, n.y / dd, n.z / dd);
+}
+
+}  // namespace rt

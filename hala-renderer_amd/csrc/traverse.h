@@ -1,0 +1,152 @@
+// traverse.h — the BVH traversal device code of libhalart.so (docs/RENDER_SPEC.md §4): what
+// vkCmdTraceRaysKHR + the RT cores do in the reference (src/rt_renderer.rs:458-464).
+//
+// Shape on CDNA4: one ray per lane, 64-lane waves inside persistent 256-thread workgroups; every wave pulls
+// 64-ray batches from a global work counter until the queue is dry.  The top of the BVH (first `lds_nodes`
+// nodes and first `lds_tris` triangles, all of them for small scenes) is staged in LDS once per workgroup;
+// the per-lane traversal stack lives in LDS as [level][thread] (bank = thread, conflict-free), deeper levels
+// spill to a global scratch area.  No MFMA: this is branchy scalar-per-ray work.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "hala_types.h"
+#include "rt_math.h"
+
+namespace rt {
+
+constexpr int kTraverseThreads = 256;
+constexpr int kStackLds = 24;     // stack levels kept in LDS per lane
+constexpr int kStackSpill = 104;  // deeper levels, global scratch (max supported tree depth = 128)
+
+struct TraverseLds {
+  const float4* nodes;  // lds_nodes * 4
+  const float4* tris;   // lds_tris * 3
+  uint32_t* stack;      // kStackLds * kTraverseThreads
+};
+
+// cooperative staging of the BVH top into LDS (coalesced 16-B loads)
+RT_DI TraverseLds stage_bvh(const SceneView& sv, unsigned char* smem) {
+  float4* ln = reinterpret_cast<float4*>(smem);
+  float4* lt = ln + (size_t)sv.lds_nodes * 4;
+  uint32_t* st = reinterpret_cast<uint32_t*>(lt + (size_t)sv.lds_tris * 3);
+  const float4* gn = reinterpret_cast<const float4*>(sv.nodes);
+  const float4* gt = reinterpret_cast<const float4*>(sv.tris);
+  for (uint32_t i = threadIdx.x; i < sv.lds_nodes * 4; i += blockDim.x) ln[i] = gn[i];
+  for (uint32_t i = threadIdx.x; i < sv.lds_tris * 3; i += blockDim.x) lt[i] = gt[i];
+  __syncthreads();
+  return TraverseLds{ln, lt, st};
+}
+
+struct RayPre {
+  f3 o, d, idir, ood;
+  float tmin;
+};
+RT_DI RayPre make_ray(f3 o, f3 d, float tmin) {
+  RayPre r;
+  r.o = o; r.d = d; r.tmin = tmin;
+  r.idir = mk3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
+  r.ood = r.o * r.idir;
+  return r;
+}
+// §4.3 padded slab test
+RT_DI bool box_test(const RayPre& r, f3 mn, f3 mx, float tlimit, float* tnear) {
+  float x0 = __fmaf_rn(mn.x, r.idir.x, -r.ood.x), x1 = __fmaf_rn(mx.x, r.idir.x, -r.ood.x);
+  float y0 = __fmaf_rn(mn.y, r.idir.y, -r.ood.y), y1 = __fmaf_rn(mx.y, r.idir.y, -r.ood.y);
+  float z0 = __fmaf_rn(mn.z, r.idir.z, -r.ood.z), z1 = __fmaf_rn(mx.z, r.idir.z, -r.ood.z);
+  float tn = maxf(maxf(minf(x0, x1), minf(y0, y1)), maxf(minf(z0, z1), r.tmin));
+  float tf = minf(minf(maxf(x0, x1), maxf(y0, y1)), minf(maxf(z0, z1), tlimit));
+  *tnear = tn;
+  return tn <= tf * 1.0000004f;
+}
+// §4.2 Möller–Trumbore
+RT_DI bool tri_test(const RayPre& r, float4 a, float4 b, float4 c, float* t, float* u, float* v) {
+  f3 e1 = mk3(b.x, b.y, b.z), e2 = mk3(c.x, c.y, c.z);
+  f3 p = cross3(r.d, e2);
+  float det = dot3(e1, p);
+  if (det == 0.0f) return false;
+  float inv = 1.0f / det;
+  f3 tv = r.o - mk3(a.x, a.y, a.z);
+  float uu = dot3(tv, p) * inv;
+  if (!(uu >= 0.0f && uu <= 1.0f)) return false;
+  f3 q = cross3(tv, e1);
+  float vv = dot3(r.d, q) * inv;
+  if (!(vv >= 0.0f && uu + vv <= 1.0f)) return false;
+  *t = dot3(e2, q) * inv; *u = uu; *v = vv;
+  return true;
+}
+
+struct HitRec {
+  float t, u, v;
+  uint32_t prim;
+};
+
+// §4.4 traversal.  Returns true if something was hit (ANY: first hit inside (tmin,tmax) ends the walk).
+template <bool ANY, bool COUNT>
+RT_DI bool traverse(const SceneView& sv, const TraverseLds& lds, uint32_t* spill, const RayPre& r, float tmax, HitRec& best,
+                    uint32_t& n_nodes, uint32_t& n_tris) {
+  best.t = tmax; best.u = 0.0f; best.v = 0.0f; best.prim = kAbsent;
+  const float4* gnodes = reinterpret_cast<const float4*>(sv.nodes);
+  const float4* gtris = reinterpret_cast<const float4*>(sv.tris);
+  uint32_t* stack = lds.stack + threadIdx.x;
+  int sp = 0;
+  uint32_t cur = 0;
+  for (;;) {
+    float4 q0, q1, q2, q3;
+    if (cur < sv.lds_nodes) {
+      const float4* p = lds.nodes + (size_t)cur * 4;
+      q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
+    } else {
+      const float4* p = gnodes + (size_t)cur * 4;
+      q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
+    }
+    if (COUNT) n_nodes++;
+    const uint32_t child0 = __float_as_uint(q3.x), child1 = __float_as_uint(q3.y);
+    const uint32_t count0 = __float_as_uint(q3.z), count1 = __float_as_uint(q3.w);
+    float tn0 = 0.0f, tn1 = 0.0f;
+    const bool valid0 = !(count0 == 0u && child0 == kAbsent), valid1 = !(count1 == 0u && child1 == kAbsent);
+    const bool h0 = valid0 && box_test(r, mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), best.t, &tn0);
+    const bool h1 = valid1 && box_test(r, mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), best.t, &tn1);
+    const bool swp = h0 && h1 && tn1 < tn0;  // nearer entry first, ties -> child 0
+    uint32_t next = kAbsent;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const bool second = (k == 1) != swp;  // which child this step looks at
+      const bool h = second ? h1 : h0;
+      if (!h) continue;
+      const uint32_t child = second ? child1 : child0, count = second ? count1 : count0;
+      const float tn = second ? tn1 : tn0;
+      if (count > 0u) {
+        if (!(tn <= best.t)) continue;
+        if (COUNT) n_tris += count;
+        for (uint32_t i = 0; i < count; ++i) {
+          const uint32_t ti = child + i;
+          float4 a, b, c;
+          if (ti < sv.lds_tris) { const float4* p = lds.tris + (size_t)ti * 3; a = p[0]; b = p[1]; c = p[2]; }
+          else { const float4* p = gtris + (size_t)ti * 3; a = p[0]; b = p[1]; c = p[2]; }
+          float t, u, v;
+          if (!tri_test(r, a, b, c, &t, &u, &v)) continue;
+          const uint32_t id = __float_as_uint(a.w);
+          if (ANY) {
+            if (t > r.tmin && t < tmax) { best.t = t; best.u = u; best.v = v; best.prim = id; return true; }
+          } else if (t > r.tmin && (t < best.t || (t == best.t && id < best.prim))) {
+            best.t = t; best.u = u; best.v = v; best.prim = id;
+          }
+        }
+      } else if (next == kAbsent) {
+        next = child;
+      } else {
+        if (sp < kStackLds) stack[sp * kTraverseThreads] = child; else spill[sp - kStackLds] = child;
+        ++sp;
+      }
+    }
+    if (next == kAbsent) {
+      if (sp == 0) break;
+      --sp;
+      next = sp < kStackLds ? stack[sp * kTraverseThreads] : spill[sp - kStackLds];
+    }
+    cur = next;
+  }
+  return best.prim != kAbsent;
+}
+
+}  // namespace rt

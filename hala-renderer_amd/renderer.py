@@ -139,6 +139,10 @@ class HalaRenderer:
         self._check(self._lib.hala_rt_get_statistics(self._h, C.byref(s)))
         return s
 
+    def set_counting(self, enable: bool):
+        """count BVH nodes visited / triangles tested in update() (inputs of the algorithmic-bytes figure)"""
+        self._check(self._lib.hala_rt_set_counting(self._h, C.c_int(bool(enable))))
+
     # -- read-back used by tests and bench (what save_images downloads, :1239-1254) -------------------------------
     ACCUM, ALBEDO, NORMAL, FINAL = 0, 1, 2, 3
 

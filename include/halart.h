@@ -341,10 +341,23 @@ typedef struct hala_rt_statistics {
   double last_gpu_ms;          /* GPU time of the last update (get_gpu_frame_time, renderer.rs:275) */
   uint64_t rays_last_update;   /* closest-hit + shadow traversals launched by the last update */
   uint64_t rays_total;
-  double traverse_ms_last_update; /* time inside the traversal kernels only */
+  double traverse_ms_last_update; /* time inside the traversal kernels only (HIP events on the renderer's stream) */
+  /* totals since create / the last accumulation reset */
+  double gpu_ms_total;
+  double traverse_ms_total;
+  uint64_t traverse_launches_total;
+  uint64_t updates_rendered;
+  uint64_t rays_closest_total;
+  uint64_t rays_shadow_total;
+  uint64_t nodes_visited_total;   /* only counted while hala_rt_set_counting(r, 1) */
+  uint64_t tris_tested_total;
+  uint64_t rays_counted_total;    /* rays traced while counting was enabled */
 } hala_rt_statistics;
 int hala_rt_get_info(hala_rt_renderer* r, hala_rt_info* out);
 int hala_rt_get_statistics(hala_rt_renderer* r, hala_rt_statistics* out);
+/* enable = 1: update() launches the counting variants of the traversal kernels (BVH nodes visited and
+ * triangles tested per ray — the inputs of the algorithmic-bytes figure). Slower; off by default. */
+int hala_rt_set_counting(hala_rt_renderer* r, int enable);
 /* the 112-B record the last update uploaded (src/rt_renderer.rs:408-427) */
 int hala_rt_get_global_uniform(hala_rt_renderer* r, hala_global_uniform* out);
 

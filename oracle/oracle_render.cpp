@@ -363,7 +363,7 @@ static PixelOut trace_path(const Frame& f, uint32_t px, uint32_t py, uint32_t fr
         if (pdf_b > 0.0f) {
           float side = dot3(ls.wi, sf.ng) >= 0.0f ? s->ray_eps : -s->ray_eps;
           V3 so = madd3(sf.ng, side, sf.P);
-          float tmax = ls.dist >= kTMax ? kTMax : ls.dist - 2.0f * s->ray_eps;
+          float tmax = ls.dist >= kTMax ? kTMax : maxf(ls.dist - 2.0f * s->ray_eps, 0.0f);
           st->rays_shadow++;
           bool occ = trace_any(nodes, tris, so, ls.wi, 0.0f, tmax, ctr);
           if (!occ) {
