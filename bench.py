@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json's metric on BASELINE.json's config, one process per GPU.
+
+  metric   : Mrays/s (+ ms/frame) — rays = every BVH traversal: primary + bounce + shadow
+  workload : configs[1] — Cornell box (32 triangles), 1920x1080, 4 spp, diffuse-only closest hit, max_depth 5, rr_depth 3
+  step     : one frame = 4 x update() (the reference renders 1 spp per update, src/rt_renderer.rs:458-464)
+  N > 1    : weak scaling — every rank renders one 1920x1080-pixel share of a (1920*kx) x (1080*ky) frame (kx*ky = N),
+             cut into 32x32 tiles dealt to the ranks by a fixed permutation; after the 4 spp the three AOVs
+             (accum, albedo, normal) are all-gathered over RCCL and de-interleaved on every rank.
+
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (closest-hit traversal) with the
+algorithmic-bytes figure of DESIGN.md; `cpu_baseline` times the CPU oracle on the host cores (N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+BASE_W, BASE_H, SPP, MAX_DEPTH, RR_DEPTH, TILE = 1920, 1080, 4, 5, 3, 32
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def grid_for(n):
+    best = (n, 1)
+    for a in range(1, n + 1):
+        if n % a == 0 and a >= n // a:
+            best = (a, n // a)
+            break
+    return best  # (kx, ky) with kx >= ky, as square as the divisors allow
+
+
+class _DevBuf:
+    """zero-copy torch view of a device allocation owned by libhalart.so"""
+
+    def __init__(self, ptr, nfloats):
+        self.__cuda_array_interface__ = {"shape": (nfloats,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+
+
+def cpu_baseline(scene_fn):
+    """The oracle (CPU restatement of the same rendering spec) on this box's host cores: one 1920x1080 frame at 1 spp."""
+    import oracle_lib as O
+    osc = O.OracleScene(scene_fn())
+    threads = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    _, st = osc.render(BASE_W, BASE_H, frames=1, max_depth=MAX_DEPTH, rr_depth=RR_DEPTH, threads=threads)
+    dt = time.perf_counter() - t0
+    rays = st.rays_closest + st.rays_shadow
+    return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"oracle (oracle/oracle_render.cpp, OpenMP) on the same Cornell box, {BASE_W}x{BASE_H}, 1 spp = {rays} rays in {dt:.2f} s",
+            "ms_per_frame_4spp_est": round(dt * 1e3 * SPP, 1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if args.gpus != 1 or world != 1:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+
+    import numpy as np
+    import torch
+
+    import hala_renderer_amd as H
+    from hala_renderer_amd import scenes
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: libhalart has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    kx, ky = grid_for(world)
+    W, Hh = BASE_W * kx, BASE_H * ky
+    aspect = W / Hh
+
+    def scene_fn():
+        return scenes.cornell_box(aspect=BASE_W / BASE_H)
+
+    scene = scenes.cornell_box(aspect=aspect)
+    r = H.HalaRenderer("bench", W, Hh, MAX_DEPTH, RR_DEPTH, False, False, False, 0, device_ordinal=local_rank)
+    if world > 1:
+        r.set_tile_shard(rank, world, TILE)
+    r.set_scene(scene)
+    r.commit()
+
+    gather_bufs = []
+    if world > 1:
+        for which in (r.ACCUM, r.ALBEDO, r.NORMAL):
+            ptr, nbytes = r.tile_buffer(which)
+            src = torch.as_tensor(_DevBuf(ptr, nbytes // 4), device=f"cuda:{local_rank}")
+            dst = torch.empty(world * (nbytes // 4), dtype=torch.float32, device=f"cuda:{local_rank}")
+            gather_bufs.append((which, src, dst, nbytes))
+
+    def step():
+        # a frame restarts the accumulation: frame_index 0..SPP-1 (same work every step)
+        r.reset_accumulation()
+        for _ in range(SPP):
+            r.update(0.0, W, Hh)
+        if world > 1:
+            r.wait_idle()
+            for which, src, dst, nbytes in gather_bufs:
+                dist.all_gather_into_tensor(dst, src)
+            torch.cuda.synchronize()
+            for which, src, dst, nbytes in gather_bufs:
+                r.scatter_gathered_tiles(which, dst.data_ptr(), nbytes * world)
+        r.render()
+
+    def fence():
+        r.wait_idle()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    s0 = r.statistics()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    s1 = r.statistics()
+
+    rays_local = s1.rays_total - s0.rays_total
+    t_local = torch.tensor([dt, float(rays_local)], dtype=torch.float64, device=f"cuda:{local_rank}")
+    if dist is not None:
+        tmax = t_local.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        rsum = t_local.clone()
+        dist.all_reduce(rsum, op=dist.ReduceOp.SUM)
+        dt_all, rays_all = float(tmax[0]), float(rsum[1])
+    else:
+        dt_all, rays_all = dt, float(rays_local)
+
+    # ---- roofline of the dominant kernel: closest-hit traversal (rank 0's launches) ---------------------------
+    # algorithmic bytes per ray (DESIGN.md §"Kernels"): 32 B ray read + 16 B hit write + 64 B per BVH node visited
+    # + 48 B per triangle tested; node/triangle counts come from one extra frame with the counting kernels
+    # (identical traversal order; tests/test_gpu_parity.py pins those counts to the oracle's).
+    closest_ms = s1.traverse_closest_ms_total - s0.traverse_closest_ms_total
+    closest_launches = s1.traverse_closest_launches - s0.traverse_closest_launches
+    shadow_ms = s1.traverse_shadow_ms_total - s0.traverse_shadow_ms_total
+    rays_closest = s1.rays_closest_total - s0.rays_closest_total
+    rays_shadow = s1.rays_shadow_total - s0.rays_shadow_total
+    r.set_counting(True)
+    c0 = r.statistics()
+    step()
+    fence()
+    c1 = r.statistics()
+    r.set_counting(False)
+    nc = c1.rays_closest_counted - c0.rays_closest_counted
+    nodes_per_ray = (c1.nodes_closest_total - c0.nodes_closest_total) / max(nc, 1)
+    tris_per_ray = (c1.tris_closest_total - c0.tris_closest_total) / max(nc, 1)
+    ns = c1.rays_shadow_counted - c0.rays_shadow_counted
+    s_nodes_per_ray = (c1.nodes_shadow_total - c0.nodes_shadow_total) / max(ns, 1)
+    s_tris_per_ray = (c1.tris_shadow_total - c0.tris_shadow_total) / max(ns, 1)
+    bytes_per_ray = 32.0 + 16.0 + 64.0 * nodes_per_ray + 48.0 * tris_per_ray
+    avg_launch_ms = closest_ms / max(closest_launches, 1)
+    rays_per_launch = rays_closest / max(closest_launches, 1)
+    achieved = bytes_per_ray * rays_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_closest.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "Mrays/s", "value": round(rays_all / dt_all / 1e6, 2), "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt_all / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"configs[1]: procedural Cornell box (32 triangles), {W}x{Hh} ({BASE_W}x{BASE_H} pixels per GPU), {SPP} spp, diffuse-only closest hit",
+                       "resolution": [W, Hh], "spp": SPP, "max_depth": MAX_DEPTH, "rr_depth": RR_DEPTH,
+                       "parallelism": f"pixel-tile shard {TILE}x{TILE} over {world} rank(s)" + (", RCCL all-gather of 3 AOVs per frame" if world > 1 else ""),
+                       "rays_per_frame": int(rays_all / args.steps), "ms_per_frame": round(dt_all / args.steps * 1e3, 4)},
+            "roofline": {"bound": "hbm", "kernel": "rt::k_trace_batch<false,false> (closest-hit traversal)",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "bytes_per_ray": round(bytes_per_ray, 1), "nodes_per_ray": round(nodes_per_ray, 3),
+                         "tris_per_ray": round(tris_per_ray, 3), "avg_launch_ms": round(avg_launch_ms, 5),
+                         "launches": int(closest_launches), "rays_per_launch": round(rays_per_launch, 1),
+                         "grays_per_s_in_kernel": round(rays_closest / max(closest_ms, 1e-9) / 1e6, 3),
+                         "shadow_kernel": {"ms_total": round(shadow_ms, 3), "rays": int(rays_shadow),
+                                           "nodes_per_ray": round(s_nodes_per_ray, 3), "tris_per_ray": round(s_tris_per_ray, 3),
+                                           "grays_per_s_in_kernel": round(rays_shadow / max(shadow_ms, 1e-9) / 1e6, 3)}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(scene_fn)
+        else:
+            out["cpu_baseline"] = None
+    r.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

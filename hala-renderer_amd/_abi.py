@@ -142,11 +142,13 @@ class RtInfo(C.Structure):
 class RtStatistics(C.Structure):
     _fields_ = [("total_frames", C.c_uint64), ("last_gpu_ms", C.c_double), ("rays_last_update", C.c_uint64),
                 ("rays_total", C.c_uint64), ("traverse_ms_last_update", C.c_double),
-                ("gpu_ms_total", C.c_double), ("traverse_ms_total", C.c_double),
-                ("traverse_launches_total", C.c_uint64), ("updates_rendered", C.c_uint64),
+                ("gpu_ms_total", C.c_double), ("traverse_closest_ms_total", C.c_double),
+                ("traverse_shadow_ms_total", C.c_double), ("traverse_closest_launches", C.c_uint64),
+                ("traverse_shadow_launches", C.c_uint64), ("updates_rendered", C.c_uint64),
                 ("rays_closest_total", C.c_uint64), ("rays_shadow_total", C.c_uint64),
-                ("nodes_visited_total", C.c_uint64), ("tris_tested_total", C.c_uint64),
-                ("rays_counted_total", C.c_uint64)]
+                ("nodes_closest_total", C.c_uint64), ("tris_closest_total", C.c_uint64),
+                ("nodes_shadow_total", C.c_uint64), ("tris_shadow_total", C.c_uint64),
+                ("rays_closest_counted", C.c_uint64), ("rays_shadow_counted", C.c_uint64)]
 
 
 class BvhInfo(C.Structure):
@@ -176,7 +178,7 @@ EXPORTS = [
     "hala_rt_set_envmap_file", "hala_rt_set_ground_color", "hala_rt_set_sky_color",
     "hala_rt_set_env_intensity", "hala_rt_set_exposure_value", "hala_rt_commit", "hala_rt_update",
     "hala_rt_render", "hala_rt_wait_idle", "hala_rt_save_images", "hala_rt_read_image",
-    "hala_rt_get_info", "hala_rt_get_statistics", "hala_rt_set_counting", "hala_rt_get_global_uniform",
+    "hala_rt_get_info", "hala_rt_get_statistics", "hala_rt_set_counting", "hala_rt_reset_accumulation", "hala_rt_get_global_uniform",
     "hala_rt_get_packed_cameras", "hala_rt_get_packed_lights", "hala_rt_get_packed_materials",
     "hala_rt_get_packed_primitives", "hala_rt_get_env_distribution", "hala_rt_set_tile_shard",
     "hala_rt_tile_buffer", "hala_rt_scatter_gathered_tiles", "hala_rt_trace_rays",

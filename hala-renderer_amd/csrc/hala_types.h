@@ -86,8 +86,10 @@ struct Control {
   uint32_t work_shadow[kMaxDepth];
   uint32_t work_batch;               // work counter of the stand-alone ray-batch operator
   uint32_t pad[2];
-  unsigned long long rays_closest, rays_shadow;   // totals of this update
-  unsigned long long nodes_visited, tris_tested;  // only filled by counting launches
+  unsigned long long rays_closest, rays_shadow;  // totals of this update
+  // only filled by counting launches: steps[kind] = {nodes visited, triangles tested}; kind 0 closest-hit
+  // kernel, kind 1 shadow / any-hit kernel
+  unsigned long long steps[2][2];
 };
 
 // wavefront path state, SoA, indexed by pixel slot

@@ -69,7 +69,7 @@ k_trace_batch(SceneView sv, const hala_ray* __restrict__ rays, hala_hit* __restr
   }
   if (COUNT) {
     cn = wave_sum(cn); ct = wave_sum(ct);
-    if (lane_id() == 0u) { atomicAdd(&ctl->nodes_visited, (unsigned long long)cn); atomicAdd(&ctl->tris_tested, (unsigned long long)ct); }
+    if (lane_id() == 0u) { atomicAdd(&ctl->steps[ANY ? 1 : 0][0], (unsigned long long)cn); atomicAdd(&ctl->steps[ANY ? 1 : 0][1], (unsigned long long)ct); }
   }
 }
 
@@ -112,7 +112,7 @@ k_trace_shadow(SceneView sv, Queues q, PathState ps, Control* __restrict__ ctl, 
   }
   if (COUNT) {
     cn = wave_sum(cn); ct = wave_sum(ct);
-    if (lane_id() == 0u) { atomicAdd(&ctl->nodes_visited, (unsigned long long)cn); atomicAdd(&ctl->tris_tested, (unsigned long long)ct); }
+    if (lane_id() == 0u) { atomicAdd(&ctl->steps[1][0], (unsigned long long)cn); atomicAdd(&ctl->steps[1][1], (unsigned long long)ct); }
   }
 }
 

@@ -79,7 +79,7 @@ struct TraceEvents {
   size_t used = 0;
   hipEvent_t frame_begin = nullptr, frame_end = nullptr;
   bool pending = false, counted = false;
-  unsigned long long* host_counts = nullptr;  // pinned: rays_closest, rays_shadow, nodes, tris
+  unsigned long long* host_counts = nullptr;  // pinned: rays_closest, rays_shadow, steps[2][2]
 };
 
 }  // namespace
@@ -208,21 +208,27 @@ struct hala_rt_renderer {
     (void)hipEventSynchronize(t.frame_end);
     float ms = 0.0f;
     if (hipEventElapsedTime(&ms, t.frame_begin, t.frame_end) == hipSuccess) { stats.last_gpu_ms = ms; stats.gpu_ms_total += ms; }
-    double tr = 0.0;
+    double tr[2] = {0.0, 0.0};  // event pairs alternate: closest-hit launch, shadow launch
     for (size_t k = 0; k + 1 < t.used; k += 2) {
       float m = 0.0f;
-      if (hipEventElapsedTime(&m, t.ev[k], t.ev[k + 1]) == hipSuccess) tr += m;
+      if (hipEventElapsedTime(&m, t.ev[k], t.ev[k + 1]) == hipSuccess) tr[(k / 2) & 1] += m;
     }
-    stats.traverse_ms_last_update = tr;
-    stats.traverse_ms_total += tr;
-    stats.traverse_launches_total += t.used / 2;
+    stats.traverse_ms_last_update = tr[0] + tr[1];
+    stats.traverse_closest_ms_total += tr[0];
+    stats.traverse_shadow_ms_total += tr[1];
+    stats.traverse_closest_launches += t.used / 4;
+    stats.traverse_shadow_launches += t.used / 4;
     stats.updates_rendered += 1;
     const unsigned long long rc = t.host_counts[0], rs = t.host_counts[1];
     stats.rays_last_update = rc + rs;
     stats.rays_total += rc + rs;
     stats.rays_closest_total += rc;
     stats.rays_shadow_total += rs;
-    if (t.counted) { stats.nodes_visited_total += t.host_counts[2]; stats.tris_tested_total += t.host_counts[3]; stats.rays_counted_total += rc + rs; }
+    if (t.counted) {
+      stats.nodes_closest_total += t.host_counts[2]; stats.tris_closest_total += t.host_counts[3];
+      stats.nodes_shadow_total += t.host_counts[4]; stats.tris_shadow_total += t.host_counts[5];
+      stats.rays_closest_counted += rc; stats.rays_shadow_counted += rs;
+    }
     t.pending = false;
   }
   hipEvent_t next_event(TraceEvents& t) {
@@ -535,7 +541,7 @@ int hala_rt_update(hala_rt_renderer* r, double, uint32_t, uint32_t) {
   TraceEvents& te = r->ring[r->ring_pos];
   r->ring_pos = (r->ring_pos + 1) % kStatRing;
   r->resolve_slot(te);
-  if (!te.frame_begin) { RT_HIP(hipEventCreate(&te.frame_begin)); RT_HIP(hipEventCreate(&te.frame_end)); RT_HIP(hipHostMalloc(reinterpret_cast<void**>(&te.host_counts), 4 * sizeof(unsigned long long), hipHostMallocDefault)); }
+  if (!te.frame_begin) { RT_HIP(hipEventCreate(&te.frame_begin)); RT_HIP(hipEventCreate(&te.frame_end)); RT_HIP(hipHostMalloc(reinterpret_cast<void**>(&te.host_counts), 6 * sizeof(unsigned long long), hipHostMallocDefault)); }
   te.used = 0; te.counted = r->counting;
 
   const FrameConst fc = r->frame_const(u);
@@ -559,7 +565,7 @@ int hala_rt_update(hala_rt_renderer* r, double, uint32_t, uint32_t) {
     RT_HIP(hipEventRecord(d, s));
   }
   launch_resolve(fc, ps, r->img_local[0].ptr, r->img_local[1].ptr, r->img_local[2].ptr, r->img_local[3].ptr, s);
-  RT_HIP(hipMemcpyAsync(te.host_counts, &ctl->rays_closest, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  RT_HIP(hipMemcpyAsync(te.host_counts, &ctl->rays_closest, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
   RT_HIP(hipEventRecord(te.frame_end, s));
   RT_HIP(hipGetLastError());
   te.pending = true;
@@ -620,6 +626,11 @@ int hala_rt_get_statistics(hala_rt_renderer* r, hala_rt_statistics* out) {
   for (int k = 0; k < kStatRing; ++k) r->resolve_slot(r->ring[(r->ring_pos + k) % kStatRing]);  // oldest first
   r->stats.total_frames = r->total_frames;
   *out = r->stats;
+  return HALA_OK;
+}
+int hala_rt_reset_accumulation(hala_rt_renderer* r) {
+  if (!r) RT_FAIL("The renderer handle is null!");
+  r->reset_accumulation();
   return HALA_OK;
 }
 int hala_rt_set_counting(hala_rt_renderer* r, int enable) {
@@ -718,9 +729,9 @@ int hala_rt_trace_rays(hala_rt_renderer* r, const hala_ray* d_rays, hala_hit* d_
   hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : r->stream;
   RT_HIP(hipMemsetAsync(r->d_batch_work.ptr, 0, 4, s));
   // counters: the kernel accumulates into the control block's 64-bit fields; copy them out if requested
-  if (d_counters) RT_HIP(hipMemsetAsync(&r->d_ctl.ptr->nodes_visited, 0, 16, s));
+  if (d_counters) RT_HIP(hipMemsetAsync(&r->d_ctl.ptr->steps[mode][0], 0, 16, s));
   launch_trace_batch(r->lcfg, r->view(), d_rays, d_hits, nullptr, count, r->d_batch_work.ptr, r->d_ctl.ptr, mode == 1, d_counters != nullptr, false, s);
-  if (d_counters) RT_HIP(hipMemcpyAsync(d_counters, &r->d_ctl.ptr->nodes_visited, 16, hipMemcpyDeviceToDevice, s));
+  if (d_counters) RT_HIP(hipMemcpyAsync(d_counters, &r->d_ctl.ptr->steps[mode][0], 16, hipMemcpyDeviceToDevice, s));
   RT_HIP(hipGetLastError());
   return HALA_OK;
 }

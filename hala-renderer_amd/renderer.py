@@ -139,6 +139,10 @@ class HalaRenderer:
         self._check(self._lib.hala_rt_get_statistics(self._h, C.byref(s)))
         return s
 
+    def reset_accumulation(self):
+        """HalaRendererStatistics::reset (src/renderer.rs:168-174): the next update() renders frame_index 0"""
+        self._check(self._lib.hala_rt_reset_accumulation(self._h))
+
     def set_counting(self, enable: bool):
         """count BVH nodes visited / triangles tested in update() (inputs of the algorithmic-bytes figure)"""
         self._check(self._lib.hala_rt_set_counting(self._h, C.c_int(bool(enable))))

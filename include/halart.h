@@ -344,17 +344,24 @@ typedef struct hala_rt_statistics {
   double traverse_ms_last_update; /* time inside the traversal kernels only (HIP events on the renderer's stream) */
   /* totals since create / the last accumulation reset */
   double gpu_ms_total;
-  double traverse_ms_total;
-  uint64_t traverse_launches_total;
+  double traverse_closest_ms_total;   /* k_trace_batch<closest> launches, HIP events on the renderer's stream */
+  double traverse_shadow_ms_total;    /* k_trace_shadow launches */
+  uint64_t traverse_closest_launches;
+  uint64_t traverse_shadow_launches;
   uint64_t updates_rendered;
   uint64_t rays_closest_total;
   uint64_t rays_shadow_total;
-  uint64_t nodes_visited_total;   /* only counted while hala_rt_set_counting(r, 1) */
-  uint64_t tris_tested_total;
-  uint64_t rays_counted_total;    /* rays traced while counting was enabled */
+  /* only counted while hala_rt_set_counting(r, 1): BVH nodes visited / triangles tested per kernel, and the
+   * rays those counts belong to */
+  uint64_t nodes_closest_total, tris_closest_total, nodes_shadow_total, tris_shadow_total;
+  uint64_t rays_closest_counted, rays_shadow_counted;
 } hala_rt_statistics;
 int hala_rt_get_info(hala_rt_renderer* r, hala_rt_info* out);
 int hala_rt_get_statistics(hala_rt_renderer* r, hala_rt_statistics* out);
+/* HalaRendererStatistics::reset (src/renderer.rs:168-174), which the reference calls on the device-lost path
+ * (src/rt_renderer.rs:557): total_frames := 0, so the next update() renders frame_index 0 and the running
+ * means restart. */
+int hala_rt_reset_accumulation(hala_rt_renderer* r);
 /* enable = 1: update() launches the counting variants of the traversal kernels (BVH nodes visited and
  * triangles tested per ray — the inputs of the algorithmic-bytes figure). Slower; off by default. */
 int hala_rt_set_counting(hala_rt_renderer* r, int enable);
