@@ -31,6 +31,13 @@ def load_library():
         if not _os.path.exists(LIB_PATH):
             raise HalaRendererError(
                 f"{LIB_PATH} not found: build the HIP library first (python -c 'import __graft_entry__ as g; g.build()')")
+        # PyTorch-ROCm ships its own libamdhip64.so.7; whichever copy is loaded first serves the whole process.
+        # Importing torch first makes libhalart.so bind to that same HIP runtime, so device memory, streams and
+        # RCCL tensors can be shared with torch (loading the system runtime first leaves torch without a GPU).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _lib = _C.CDLL(LIB_PATH)
         _lib.hala_last_error_message.restype = _C.c_char_p
         _lib.hala_version.restype = _C.c_char_p

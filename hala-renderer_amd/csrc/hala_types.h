@@ -79,13 +79,23 @@ struct FrameConst {
 // device control block: queue sizes and work counters of the wavefront loop.  One slot per bounce, so a single
 // hipMemsetAsync per update() resets everything and no kernel has to clear a counter another one still reads.
 constexpr uint32_t kMaxDepth = 64;
+// Work distribution of the persistent traversal kernels: one returning atomic on a single word saturates at
+// ~88 dequeues/us on MI355X (guide: "dequeue" row), which a 2 M-ray launch of 64-ray batches would hit.  The ray range
+// is therefore cut into kWorkShards contiguous shards, each with its own counter on its own 128-B line; a wave starts
+// on shard (blockIdx & 15) — blocks b and b+8 share an XCD — and moves on to the next shard when its own is dry.
+constexpr uint32_t kWorkShards = 16;
+constexpr uint32_t kWorkStride = 32;  // uint32 words between shard counters (128 B)
+constexpr uint32_t kWorkBatch = 128;  // rays handed out per dequeue (two 64-lane passes)
+struct WorkCounters {
+  uint32_t c[kWorkShards * kWorkStride];
+  uint32_t dry[kWorkStride];  // dry[0]: bit s set once shard s has handed out all of its batches (own 128-B line)
+};
 struct Control {
   uint32_t n_active[kMaxDepth + 1];  // ray-queue size entering bounce d
   uint32_t n_shadow[kMaxDepth];      // shadow work items produced by bounce d
-  uint32_t work_closest[kMaxDepth];  // persistent-kernel work counters
-  uint32_t work_shadow[kMaxDepth];
-  uint32_t work_batch;               // work counter of the stand-alone ray-batch operator
-  uint32_t pad[2];
+  uint32_t pad[3];
+  WorkCounters work_closest;  // re-zeroed by the shade kernel of every bounce (it runs between two uses)
+  WorkCounters work_shadow;
   unsigned long long rays_closest, rays_shadow;  // totals of this update
   // only filled by counting launches: steps[kind] = {nodes visited, triangles tested}; kind 0 closest-hit
   // kernel, kind 1 shadow / any-hit kernel

@@ -33,6 +33,81 @@ RT_DI uint32_t wave_sum(uint32_t v) {
   return v;  // valid in lane 0
 }
 
+// Block-level compaction of up to two predicates at once: one atomic per workgroup and counter instead of one per
+// wave (a single counter word takes ~88 atomics/us; a 2 M-path launch of 64-lane waves would need 32 K of them).
+// All threads of the block must call it.  Returns this lane's output index for each predicate.
+constexpr int kShadeThreads = 512;
+struct BlockCompact {
+  uint32_t cnt[2][kShadeThreads / 64];
+  uint32_t base[2];
+  uint32_t extra[kShadeThreads / 64];
+};
+RT_DI void block_compact2(BlockCompact& sm, bool keep0, bool keep1, uint32_t* counter0, uint32_t* counter1, uint32_t extra,
+                          unsigned long long* extra_counter, uint32_t* out0, uint32_t* out1) {
+  const unsigned long long m0 = __ballot(keep0), m1 = __ballot(keep1);
+  const uint32_t w = threadIdx.x >> 6, l = lane_id();
+  const uint32_t ex = wave_sum(extra);
+  if (l == 0u) { sm.cnt[0][w] = (uint32_t)__popcll(m0); sm.cnt[1][w] = (uint32_t)__popcll(m1); sm.extra[w] = ex; }
+  __syncthreads();
+  const uint32_t nw = blockDim.x >> 6;
+  if (threadIdx.x < 2u) {
+    uint32_t total = 0;
+    for (uint32_t k = 0; k < nw; ++k) total += sm.cnt[threadIdx.x][k];
+    sm.base[threadIdx.x] = total ? atomicAdd(threadIdx.x == 0u ? counter0 : counter1, total) : 0u;
+  } else if (threadIdx.x == 64u && extra_counter) {
+    uint32_t total = 0;
+    for (uint32_t k = 0; k < nw; ++k) total += sm.extra[k];
+    if (total) atomicAdd(extra_counter, (unsigned long long)total);
+  }
+  __syncthreads();
+  uint32_t p0 = sm.base[0], p1 = sm.base[1];
+  for (uint32_t k = 0; k < w; ++k) { p0 += sm.cnt[0][k]; p1 += sm.cnt[1][k]; }
+  const unsigned long long below = (1ull << l) - 1ull;
+  *out0 = p0 + (uint32_t)__popcll(m0 & below);
+  *out1 = p1 + (uint32_t)__popcll(m1 & below);
+}
+
+// Sharded dequeue of ray batches for the persistent kernels (see WorkCounters).  Returns the first ray of a batch of
+// up to kWorkBatch rays inside [0, n), or kAbsent when every shard is dry.  Wave-uniform.
+struct WorkCursor {
+  uint32_t shard, per;
+};
+RT_DI WorkCursor work_begin(uint32_t n) {
+  WorkCursor c;
+  c.shard = blockIdx.x & (kWorkShards - 1u);
+  const uint32_t batches = (n + kWorkBatch - 1u) / kWorkBatch;
+  c.per = ((batches + kWorkShards - 1u) / kWorkShards) * kWorkBatch;  // rays per shard, a multiple of the batch
+  return c;
+}
+RT_DI uint32_t work_next(WorkCounters* wc, WorkCursor& c, uint32_t n, uint32_t* end) {
+  constexpr uint32_t kAll = (1u << kWorkShards) - 1u;
+  for (;;) {
+    uint32_t v = 0;
+    if (lane_id() == 0u) v = atomicAdd(&wc->c[c.shard * kWorkStride], kWorkBatch);
+    v = (uint32_t)__shfl((int)v, 0);
+    const unsigned long long lo = (unsigned long long)c.shard * c.per + v;
+    const unsigned long long hi = min((unsigned long long)(c.shard + 1u) * c.per, (unsigned long long)n);
+    if (v < c.per && lo < hi) {
+      *end = (uint32_t)min(lo + kWorkBatch, hi);
+      return (uint32_t)lo;
+    }
+    // this shard is dry: publish that (once) and move to a shard nobody has reported dry yet.  The mask only ever
+    // gains bits and a bit is set only after the shard's last batch was handed out, so a stale read costs at most an
+    // extra probe and "all dry" is never reported early.
+    uint32_t m = 0;
+    if (lane_id() == 0u) {
+      m = __hip_atomic_load(&wc->dry[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!(m & (1u << c.shard))) { atomicOr(&wc->dry[0], 1u << c.shard); m |= 1u << c.shard; }
+    }
+    m = (uint32_t)__shfl((int)m, 0);
+    if ((m & kAll) == kAll) return kAbsent;
+    const uint32_t avail = ~m & kAll;
+    const uint32_t rot = (c.shard + 1u) & (kWorkShards - 1u);
+    const uint32_t r = ((avail >> rot) | (avail << (kWorkShards - rot))) & kAll;  // bit k <-> shard rot + k
+    c.shard = (rot + (uint32_t)__ffs((int)r) - 1u) & (kWorkShards - 1u);
+  }
+}
+
 extern __shared__ __attribute__((aligned(16))) unsigned char g_smem[];
 
 // ---------------------------------------------------------------------------------------------------------
@@ -41,7 +116,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char g_smem[];
 template <bool ANY, bool COUNT>
 __global__ void __launch_bounds__(kTraverseThreads)
 k_trace_batch(SceneView sv, const hala_ray* __restrict__ rays, hala_hit* __restrict__ hits, const uint32_t* __restrict__ n_ptr,
-              uint32_t n_imm, uint32_t* __restrict__ work, uint32_t* __restrict__ spill_base, Control* __restrict__ ctl, int account) {
+              uint32_t n_imm, WorkCounters* __restrict__ work, uint32_t* __restrict__ spill_base, Control* __restrict__ ctl, int account) {
   const TraverseLds lds = stage_bvh(sv, g_smem);
   const uint32_t n = n_ptr ? *n_ptr : n_imm;
   uint32_t* spill = spill_base ? spill_base + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * kStackSpill : nullptr;
@@ -49,13 +124,12 @@ k_trace_batch(SceneView sv, const hala_ray* __restrict__ rays, hala_hit* __restr
   if (account && blockIdx.x == 0 && threadIdx.x == 0) {
     if (ANY) ctl->rays_shadow += n; else ctl->rays_closest += n;
   }
+  WorkCursor cur = work_begin(n);
   for (;;) {
-    uint32_t base = 0;
-    if (lane_id() == 0u) base = atomicAdd(work, 64u);
-    base = (uint32_t)__shfl((int)base, 0);
-    if (base >= n) break;
-    const uint32_t i = base + lane_id();
-    if (i < n) {
+    uint32_t end = 0;
+    const uint32_t first = work_next(work, cur, n, &end);
+    if (first == kAbsent) break;
+    for (uint32_t i = first + lane_id(); i < end; i += 64u) {
       const float4* rp = reinterpret_cast<const float4*>(rays + i);
       const float4 ro = rp[0], rd = rp[1];
       const RayPre r = make_ray(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w);
@@ -84,13 +158,12 @@ k_trace_shadow(SceneView sv, Queues q, PathState ps, Control* __restrict__ ctl, 
   const uint32_t n = ctl->n_shadow[depth];
   uint32_t* spill = spill_base ? spill_base + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * kStackSpill : nullptr;
   uint32_t cn = 0, ct = 0;
+  WorkCursor cur = work_begin(n);
   for (;;) {
-    uint32_t base = 0;
-    if (lane_id() == 0u) base = atomicAdd(&ctl->work_shadow[depth], 64u);
-    base = (uint32_t)__shfl((int)base, 0);
-    if (base >= n) break;
-    const uint32_t i = base + lane_id();
-    if (i < n) {
+    uint32_t end = 0;
+    const uint32_t first = work_next(&ctl->work_shadow, cur, n, &end);
+    if (first == kAbsent) break;
+    for (uint32_t i = first + lane_id(); i < end; i += 64u) {
       const uint32_t qi = q.shadow_list[i];
 #pragma unroll 1
       for (int k = 0; k < 2; ++k) {
@@ -135,7 +208,14 @@ __global__ void __launch_bounds__(256) k_raygen(FrameConst fc, SceneView sv, Que
     ps.albedo[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     ps.normal[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   }
-  const uint32_t qi = wave_compact(valid, &ctl->n_active[0]);
+  // unsharded frames have no invalid slots: the queue index is the slot and the queue size is known up front;
+  // sharded frames compact away padding tiles / out-of-frame pixels (one atomic per wave: the first queue only)
+  uint32_t qi = slot;
+  if (fc.world <= 1u) {
+    if (slot == 0u) ctl->n_active[0] = fc.slot_count;
+  } else {
+    qi = wave_compact(valid, &ctl->n_active[0]);
+  }
   if (valid) {
     float4* rp = reinterpret_cast<float4*>(q.rays[0] + qi);
     rp[0] = make_float4(o.x, o.y, o.z, 0.0f);
@@ -147,10 +227,18 @@ __global__ void __launch_bounds__(256) k_raygen(FrameConst fc, SceneView sv, Que
 // ---------------------------------------------------------------------------------------------------------
 // shade: closest-hit + miss + light/env NEE + BSDF sampling + Russian roulette for one bounce (RENDER_SPEC §6)
 // ---------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_shade(FrameConst fc, SceneView sv, Queues q, PathState ps, Control* __restrict__ ctl, uint32_t depth) {
+__global__ void __launch_bounds__(kShadeThreads) k_shade(FrameConst fc, SceneView sv, Queues q, PathState ps, Control* __restrict__ ctl, uint32_t depth) {
+  __shared__ BlockCompact s_compact;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t n = ctl->n_active[depth];
-  if ((i & ~63u) >= n) return;  // whole wave beyond the queue
+  // the traversal of this bounce is over and the next users (shadow pass of this bounce, closest-hit pass of the next)
+  // have not started: re-arm their work counters here
+  if (blockIdx.x == 0u && threadIdx.x < kWorkShards) {
+    ctl->work_closest.c[threadIdx.x * kWorkStride] = 0u;
+    ctl->work_shadow.c[threadIdx.x * kWorkStride] = 0u;
+    if (threadIdx.x == 0u) { ctl->work_closest.dry[0] = 0u; ctl->work_shadow.dry[0] = 0u; }
+  }
+  if (blockIdx.x * blockDim.x >= n) return;  // whole workgroup beyond the queue (uniform exit: barriers below)
   const bool active = i < n;
   const uint32_t in = depth & 1u, out = in ^ 1u;
   bool alive = false, has_shadow = false;
@@ -278,17 +366,15 @@ __global__ void __launch_bounds__(256) k_shade(FrameConst fc, SceneView sv, Queu
     ps.radiance_rng[slot] = make_float4(L.x, L.y, L.z, __uint_as_float(rng));
   }
   // ballot compaction of the surviving paths and of the paths that own shadow rays
-  const uint32_t qo = wave_compact(alive, &ctl->n_active[depth + 1u]);
+  uint32_t qo = 0, so = 0;
+  block_compact2(s_compact, alive, has_shadow, &ctl->n_active[depth + 1u], &ctl->n_shadow[depth], n_shadow_rays, &ctl->rays_shadow, &qo, &so);
   if (alive) {
     float4* rp = reinterpret_cast<float4*>(q.rays[out] + qo);
     rp[0] = make_float4(no.x, no.y, no.z, 0.0f);
     rp[1] = make_float4(nd.x, nd.y, nd.z, kTMax);
     q.slots[out][qo] = slot;
   }
-  const uint32_t so = wave_compact(has_shadow, &ctl->n_shadow[depth]);
   if (has_shadow) q.shadow_list[so] = i;
-  const uint32_t ns = wave_sum(n_shadow_rays);
-  if (lane_id() == 0u && ns) atomicAdd(&ctl->rays_shadow, (unsigned long long)ns);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -340,7 +426,7 @@ uint32_t traverse_blocks_per_cu(size_t dynamic_lds_bytes) {
 }
 
 void launch_trace_batch(const LaunchCfg& lc, const SceneView& sv, const hala_ray* rays, hala_hit* hits, const uint32_t* n_ptr,
-                        uint32_t n_imm, uint32_t* work, Control* ctl, bool any, bool count, bool account, hipStream_t s) {
+                        uint32_t n_imm, WorkCounters* work, Control* ctl, bool any, bool count, bool account, hipStream_t s) {
   const size_t smem = (size_t)sv.lds_nodes * 64 + (size_t)sv.lds_tris * 48 + (size_t)kStackLds * kTraverseThreads * 4;
   dim3 grid(lc.persistent_blocks), block(kTraverseThreads);
   const int acc = account ? 1 : 0;
@@ -365,7 +451,7 @@ void launch_raygen(const FrameConst& fc, const SceneView& sv, const Queues& q, c
   hipLaunchKernelGGL(k_raygen, dim3(blocks_for(fc.slot_count, 256)), dim3(256), 0, s, fc, sv, q, ps, ctl);
 }
 void launch_shade(const FrameConst& fc, const SceneView& sv, const Queues& q, const PathState& ps, Control* ctl, uint32_t depth, hipStream_t s) {
-  hipLaunchKernelGGL(k_shade, dim3(blocks_for(fc.slot_count, 256)), dim3(256), 0, s, fc, sv, q, ps, ctl, depth);
+  hipLaunchKernelGGL(k_shade, dim3(blocks_for(fc.slot_count, kShadeThreads)), dim3(kShadeThreads), 0, s, fc, sv, q, ps, ctl, depth);
 }
 void launch_resolve(const FrameConst& fc, const PathState& ps, float4* accum, float4* albedo, float4* normal, float4* final_img, hipStream_t s) {
   hipLaunchKernelGGL(k_resolve, dim3(blocks_for(fc.slot_count, 256)), dim3(256), 0, s, fc, ps, accum, albedo, normal, final_img);

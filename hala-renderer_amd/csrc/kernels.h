@@ -19,7 +19,7 @@ uint32_t traverse_stack_lds_levels();   // stack levels kept in LDS
 uint32_t traverse_stack_spill_levels(); // deeper levels spilled to global scratch
 uint32_t traverse_blocks_per_cu(size_t dynamic_lds_bytes);  // resident workgroups per CU (occupancy query)
 void launch_trace_batch(const LaunchCfg& lc, const SceneView& sv, const hala_ray* rays, hala_hit* hits, const uint32_t* n_ptr,
-                        uint32_t n_imm, uint32_t* work, Control* ctl, bool any, bool count, bool account, hipStream_t s);
+                        uint32_t n_imm, WorkCounters* work, Control* ctl, bool any, bool count, bool account, hipStream_t s);
 void launch_trace_shadow(const LaunchCfg& lc, const SceneView& sv, const Queues& q, const PathState& ps, Control* ctl, uint32_t depth,
                          bool count, hipStream_t s);
 void launch_raygen(const FrameConst& fc, const SceneView& sv, const Queues& q, const PathState& ps, Control* ctl, hipStream_t s);

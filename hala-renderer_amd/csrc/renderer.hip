@@ -141,7 +141,7 @@ struct hala_rt_renderer {
   DeviceArray<hala_hit> q_hits;
   DeviceArray<ShadowEntry> q_shadow;
   DeviceArray<Control> d_ctl;
-  DeviceArray<uint32_t> d_batch_work;
+  DeviceArray<WorkCounters> d_batch_work;
 
   uint64_t total_frames = 0;
   bool counting = false;
@@ -556,7 +556,7 @@ int hala_rt_update(hala_rt_renderer* r, double, uint32_t, uint32_t) {
   for (uint32_t depth = 0; depth < r->max_depth; ++depth) {
     hipEvent_t a = r->next_event(te), b = r->next_event(te);
     RT_HIP(hipEventRecord(a, s));
-    launch_trace_batch(r->lcfg, sv, q.rays[depth & 1u], q.hits, &ctl->n_active[depth], 0, &ctl->work_closest[depth], ctl, false, r->counting, true, s);
+    launch_trace_batch(r->lcfg, sv, q.rays[depth & 1u], q.hits, &ctl->n_active[depth], 0, &ctl->work_closest, ctl, false, r->counting, true, s);
     RT_HIP(hipEventRecord(b, s));
     launch_shade(fc, sv, q, ps, ctl, depth, s);
     hipEvent_t c = r->next_event(te), d = r->next_event(te);
@@ -727,7 +727,7 @@ int hala_rt_trace_rays(hala_rt_renderer* r, const hala_ray* d_rays, hala_hit* d_
   if (count == 0) return HALA_OK;
   if (!d_rays || !d_hits) RT_FAIL("The ray batch is null!");
   hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : r->stream;
-  RT_HIP(hipMemsetAsync(r->d_batch_work.ptr, 0, 4, s));
+  RT_HIP(hipMemsetAsync(r->d_batch_work.ptr, 0, sizeof(WorkCounters), s));
   // counters: the kernel accumulates into the control block's 64-bit fields; copy them out if requested
   if (d_counters) RT_HIP(hipMemsetAsync(&r->d_ctl.ptr->steps[mode][0], 0, 16, s));
   launch_trace_batch(r->lcfg, r->view(), d_rays, d_hits, nullptr, count, r->d_batch_work.ptr, r->d_ctl.ptr, mode == 1, d_counters != nullptr, false, s);

@@ -1,0 +1,122 @@
+"""N > 1 path.  CPU tier: the tile layout (docs/RENDER_SPEC.md §9) against the oracle's statement of it, and a
+world_size-2 gloo all-gather of tile-major shards + de-interleave.  GPU tier: a sharded renderer (several fake ranks
+on one GPU) must reproduce the unsharded image bit for bit, through the same all-gather buffer layout."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from hala_renderer_amd import scenes
+from hala_renderer_amd.dist import TileLayout
+
+
+@pytest.mark.parametrize("w,h,world,ts", [(1920, 1080, 8, 32), (1920, 1080, 2, 32), (100, 70, 4, 16), (64, 64, 8, 32), (3840, 2160, 8, 32)])
+def test_tile_layout_matches_oracle(oracle, w, h, world, ts):
+    L = TileLayout(w, h, world, ts)
+    owner, slot = oracle.tile_assignment(L.tiles_x, L.tiles_y, world)
+    assert np.array_equal(owner, L.owner) and np.array_equal(slot, L.slot)
+    counts = np.bincount(L.owner, minlength=world)
+    assert counts.max() - counts.min() <= 1
+
+
+def test_shard_unshard_roundtrip():
+    rng = np.random.RandomState(0)
+    for w, h, world, ts in [(100, 70, 4, 16), (64, 48, 3, 32), (33, 17, 8, 8)]:
+        L = TileLayout(w, h, world, ts)
+        img = rng.rand(h, w, 4).astype(np.float32)
+        gathered = np.concatenate([L.shard(img, r) for r in range(world)])
+        assert np.array_equal(L.unshard(gathered), img)
+        # every real pixel is owned exactly once
+        seen = np.zeros((h, w), dtype=np.int32)
+        for r in range(world):
+            m = L.rank_pixel_map(r)
+            ok = m[:, 0] >= 0
+            np.add.at(seen, (m[ok, 0], m[ok, 1]), 1)
+        assert np.all(seen == 1)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _gloo_worker(rank, world, port, w, h, ts, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        L = TileLayout(w, h, world, ts)
+        yy, xx = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+        img = np.stack([yy, xx, yy * w + xx, np.ones_like(xx)], -1).astype(np.float32)  # every pixel carries its own id
+        local = torch.from_numpy(L.shard(img, rank).reshape(-1).copy())
+        out = torch.empty(world * local.numel(), dtype=torch.float32)
+        dist.all_gather_into_tensor(out, local)  # same call and buffer layout as TileGather.gather() on RCCL
+        full = L.unshard(out.numpy())
+        q.put((rank, bool(np.array_equal(full, img))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gloo_world2_all_gather_deinterleave():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, 100, 70, 16, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(results) == [(0, True), (1, True)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 8])
+def test_sharded_render_equals_unsharded(halart, world):
+    """RNG is keyed by the global pixel id, so the union of the ranks' tiles is bit-identical to a 1-GPU render.
+    The ranks are emulated one after another on the same GPU; the gathered buffer is assembled exactly as
+    all_gather_into_tensor lays it out and de-interleaved by the library's HIP kernel."""
+    import torch
+    w, h, ts, spp = 200, 120, 32, 2
+    scene = scenes.cornell_box(aspect=w / h)
+
+    def render(rank, n):
+        r = halart.HalaRenderer("shard", w, h, 5, 3, False, False, False, 0)
+        if n > 1:
+            r.set_tile_shard(rank, n, ts)
+        r.set_scene(scene)
+        r.commit()
+        for _ in range(spp):
+            r.update()
+        r.render()
+        return r
+
+    ref = render(0, 1)
+    ref_imgs = [ref.read_image(k) for k in range(3)]
+    ref.close()
+    L = TileLayout(w, h, world, ts)
+    shards = {k: [] for k in range(3)}
+    last = None
+    for rank in range(world):
+        r = render(rank, world)
+        for k in range(3):
+            ptr, nbytes = r.tile_buffer(k)
+            assert nbytes == L.pixels_per_rank * 16
+            t = torch.as_tensor(halart.dist._DeviceView(ptr, nbytes // 4), device="cuda:0").clone()
+            shards[k].append(t)
+        if last is not None:
+            last.close()
+        last = r
+    for k in range(3):
+        gathered = torch.cat(shards[k]).contiguous()
+        # host-side statement of the layout
+        assert np.array_equal(L.unshard(gathered.cpu().numpy()), ref_imgs[k])
+        # the library's de-interleave kernel
+        last.scatter_gathered_tiles(k, gathered.data_ptr(), gathered.numel() * 4)
+        assert np.array_equal(last.read_image(k), ref_imgs[k])
+    last.close()

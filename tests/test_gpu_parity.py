@@ -1,0 +1,447 @@
+"""GPU tier (-m gpu): the HIP path of libhalart.so, called through its C ABI, against the CPU oracle on the same seeded
+inputs.  Bar: bit-exact for everything integer/index valued and for everything the rendering spec pins to single IEEE
+operations (which is all of it: docs/RENDER_SPEC.md §2); the only tolerance used is the libm tolerance of cos() in the
+light records (the reference calls f32::cos there, gpu_uploader.rs:189,206).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import hala_renderer_amd as H
+from conftest import GOLDEN
+from hala_renderer_amd import scenes
+from test_oracle_host import kat_images, light_scene
+from test_oracle_render import furnace_scene, random_rays
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+def make_renderer(halart, scene, w, h, max_depth=5, rr_depth=3, tonemap=(False, False, False), max_frames=0, env=None, env_rot=0.0):
+    r = halart.HalaRenderer("test", w, h, max_depth, rr_depth, *tonemap, max_frames)
+    if env is not None:
+        r.set_envmap(env, env_rot)
+    r.set_scene(scene)
+    r.commit()
+    return r
+
+
+def struct_bytes(s):
+    return bytes(memoryview(s))
+
+
+# ---- A1: env tables ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", list(kat_images().keys()))
+def test_envmap_tables_bit_exact_small(halart, oracle, name):
+    img = kat_images()[name]
+    h, w, _ = img.shape
+    total = C.c_float(); m = np.empty(h, f32); c = np.empty((h, w), f32)
+    halart.check(halart.load_library().hala_envmap_build_distribution(0, img.ctypes.data_as(C.POINTER(C.c_float)), w, h, C.byref(total),
+                                                                       m.ctypes.data_as(C.POINTER(C.c_float)), c.ctypes.data_as(C.POINTER(C.c_float))))
+    t0, m0, c0 = oracle.envmap_build_distribution(img)
+    assert f32(total.value).tobytes() == t0.tobytes() and m.tobytes() == m0.tobytes() and c.tobytes() == c0.tobytes()
+    g = np.load(os.path.join(GOLDEN, "envmap_kat.npz"))
+    assert c.tobytes() == g[f"{name}_conditional"].tobytes()
+
+
+@pytest.mark.parametrize("w,h", [(2048, 1024), (300, 77), (64, 1), (1, 64)])
+def test_envmap_tables_bit_exact_full_size(halart, oracle, w, h):
+    """config-3 size (2048x1024 = SURVEY §8d) and ragged shapes; sun disc 1e4x brighter exercises the table tails"""
+    img = scenes.sky_sun_envmap(w, h) if h > 1 and w > 1 else (np.random.RandomState(2).rand(h, w, 4).astype(f32) + f32(0.01))
+    total = C.c_float(); m = np.empty(h, f32); c = np.empty((h, w), f32)
+    halart.check(halart.load_library().hala_envmap_build_distribution(0, img.ctypes.data_as(C.POINTER(C.c_float)), w, h, C.byref(total),
+                                                                       m.ctypes.data_as(C.POINTER(C.c_float)), c.ctypes.data_as(C.POINTER(C.c_float))))
+    t0, m0, c0 = oracle.envmap_build_distribution(img)
+    assert f32(total.value).tobytes() == t0.tobytes()
+    assert m.tobytes() == m0.tobytes()
+    assert c.tobytes() == c0.tobytes()
+    # size-independent properties: tables are monotone and lie in [0, 1]
+    assert np.all(np.diff(c, axis=1) >= 0) and np.all(np.diff(m) >= 0) and c.min() >= 0 and c.max() <= 1
+
+
+def test_envmap_rejects_nan_and_inf(halart):
+    r = halart.HalaRenderer("env", 8, 8, 2, 1, False, False, False, 0)
+    img = np.ones((4, 8, 3), f32)
+    img[2, 3, 1] = np.nan
+    with pytest.raises(halart.HalaRendererError, match="The pixel value is NaN!"):  # src/envmap.rs:64-66
+        r.set_envmap(img)
+    img[2, 3, 1] = np.inf
+    with pytest.raises(halart.HalaRendererError, match="The pixel value is infinite!"):  # :67-69
+        r.set_envmap(img)
+    r.close()
+
+
+# ---- upload(): packed records -------------------------------------------------------------------------------------
+def test_packed_records_match_oracle(halart, oracle):
+    s = light_scene()
+    prim = scenes.cornell_box().meshes[1].primitives[0]
+    s.materials = [H.HalaMaterial(type=0, roughness=r_, anisotropic=a_) for r_ in (0.0, 0.5, 1.0) for a_ in (0.0, 0.5, 1.0)]
+    prim.material_index = 4
+    s.meshes = [H.HalaMesh([prim])]
+    s.nodes.append(H.HalaNode(name="m", parent=0, mesh_index=0))
+    r = halart.HalaRenderer("pack", 16, 16, 2, 1, False, False, False, 0)
+    r.set_scene(s)
+    cams, ocams = r.packed_cameras(), oracle.pack_cameras(s)
+    assert [struct_bytes(a) for a in cams] == [struct_bytes(b) for b in ocams]
+    (lights, boxes), (olights, oboxes) = r.packed_lights(), oracle.pack_lights(s)
+    assert len(lights) == len(olights) == 6
+    for a, b in zip(lights, olights):
+        for fld in ("intensity", "position", "u"):
+            assert list(getattr(a, fld)) == list(getattr(b, fld))
+        assert np.allclose(list(a.v), list(b.v), rtol=0, atol=1.2e-7)  # cos(): libm vs libm, <= 1 ulp
+        assert (f32(a.radius), f32(a.area), a.type) == (f32(b.radius), f32(b.area), b.type)
+    assert [struct_bytes(a) for a in boxes] == [struct_bytes(b) for b in oboxes]
+    mats = r.packed_materials()
+    assert [struct_bytes(a) for a in mats] == [struct_bytes(oracle.pack_material(m)) for m in s.materials]
+    prims, t3x4 = r.packed_primitives()
+    ot, omd = oracle.pack_instances(s)
+    assert np.array_equal(t3x4, ot)
+    for a, b in zip(prims, omd):
+        assert list(a.transform) == list(b.transform) and a.material_index == b.material_index
+        assert a.vertices != 0 and a.indices != 0 and a.vertices % 4 == 0 and a.indices % 16 == 0  # device addresses (:869-870)
+    r.close()
+
+
+def test_error_behaviour(halart):
+    r = halart.HalaRenderer("err", 16, 16, 2, 1, False, False, False, 0)
+    with pytest.raises(halart.HalaRendererError, match="The scene in GPU is none!"):  # src/rt_renderer.rs:138
+        r.commit()
+    with pytest.raises(halart.HalaRendererError):
+        r.update()
+    s = scenes.cornell_box()
+    s.nodes[3].camera_index = H._abi.INVALID_INDEX
+    with pytest.raises(halart.HalaRendererError, match="The camera node of the camera 0 is not found."):  # gpu_uploader.rs:113
+        r.set_scene(s)
+    s = scenes.cornell_box()
+    s.materials[0].type = 7
+    with pytest.raises(halart.HalaRendererError, match="Invalid material type."):
+        r.set_scene(s)
+    with pytest.raises(halart.HalaRendererError):
+        halart.HalaRenderer("zero", 0, 16, 2, 1, False, False, False, 0)
+    r.close()
+
+
+# ---- K1/K3: BVH build, validated through structure and traversal results ---------------------------------------------
+SCENES = {
+    "cornell": lambda: scenes.cornell_box(),
+    "blob_5k": lambda: scenes.bunny_class(subdivisions=4),
+    "sponza_60k": lambda: scenes.sponza_class(target_triangles=60000, disney=False),
+}
+
+
+@pytest.mark.parametrize("name", list(SCENES.keys()))
+def test_bvh_structure_and_flattening(halart, oracle, name):
+    s = SCENES[name]()
+    r = make_renderer(halart, s, 16, 16)
+    osc = oracle.OracleScene(s)
+    info = r.bvh_info()
+    assert info.triangle_count == osc.triangle_count == s.triangle_count()
+    omn, omx = osc.bounds()
+    assert list(info.scene_min) == list(omn) and list(info.scene_max) == list(omx)
+    nodes, tris = r.download_bvh()
+    rc, depth = oracle.validate_bvh(nodes, tris, osc.triangles())  # also checks v0/e1/e2 bit-exact vs RENDER_SPEC §3
+    assert rc == 0, f"validate_bvh code {rc}"
+    assert depth == info.max_depth
+    r.close()
+
+
+@pytest.mark.parametrize("name", list(SCENES.keys()))
+def test_trace_rays_closest_and_any_bit_exact(halart, oracle, name):
+    s = SCENES[name]()
+    r = make_renderer(halart, s, 16, 16)
+    osc = oracle.OracleScene(s)
+    mn, mx = osc.bounds()
+    pad = (mx - mn) * 0.25
+    rays = np.concatenate([random_rays(60000, mn - pad, mx + pad, 11), osc.camera_rays(160, 90, 0)])
+    got = r.trace_rays_host(rays, 0)
+    want = osc.trace(rays, 0)  # oracle's own BVH: results must not depend on the BVH
+    assert np.array_equal(got["prim"], want["prim"])
+    assert got["t"].tobytes() == want["t"].tobytes() and got["u"].tobytes() == want["u"].tobytes() and got["v"].tobytes() == want["v"].tobytes()
+    got_any = r.trace_rays_host(rays, 1)
+    want_any = osc.trace(rays, 1)
+    assert np.array_equal(got_any["t"], want_any["t"])
+    # brute force on a sample (BVH-free truth)
+    sub = rays[:: max(1, len(rays) // 3000)]
+    assert np.array_equal(r.trace_rays_host(sub, 0)["prim"], osc.trace(sub, 0, brute=True)["prim"])
+    r.close()
+
+
+def test_traversal_step_counts_match_oracle_on_same_bvh(halart, oracle):
+    """the inputs of roofline.achieved: nodes visited / triangles tested per ray must equal the oracle's count on the
+    SAME (GPU-built) BVH for the same rays"""
+    s = scenes.sponza_class(target_triangles=60000, disney=False)
+    r = make_renderer(halart, s, 16, 16)
+    osc = oracle.OracleScene(s)
+    rays = osc.camera_rays(320, 180, 0)
+    nodes, tris = r.download_bvh()
+    for mode in (0, 1):
+        hits, cnt = r.trace_rays_host(rays, mode, count_steps=True)
+        ohits, ocnt = oracle.trace_on_bvh(nodes, tris, rays, mode)
+        assert cnt == ocnt
+        assert np.array_equal(hits["t"], ohits["t"])
+    r.close()
+
+
+def test_empty_and_ragged_batches(halart, oracle):
+    s = scenes.cornell_box()
+    r = make_renderer(halart, s, 16, 16)
+    osc = oracle.OracleScene(s)
+    assert len(r.trace_rays_host(np.zeros(0, dtype=H._abi.RAY_DTYPE), 0)) == 0
+    mn, mx = osc.bounds()
+    for n in (1, 63, 64, 65, 1000):
+        rays = random_rays(n, mn, mx, n)
+        assert r.trace_rays_host(rays, 0).tobytes() == osc.trace(rays, 0).tobytes()
+    # degenerate rays: zero direction components, tmax = 0, rays starting on geometry
+    rays = np.zeros(4, dtype=H._abi.RAY_DTYPE)
+    rays["origin"] = [(278, 273, -800), (278, 0, 279), (100, 100, 100), (278, 273, 279)]
+    rays["direction"] = [(0, 0, 1), (0, 1, 0), (1, 0, 0), (0, -1, 0)]
+    rays["tmax"] = [3e38, 3e38, 0.0, 3e38]
+    assert r.trace_rays_host(rays, 0).tobytes() == osc.trace(rays, 0).tobytes()
+    r.close()
+
+
+def test_rtprog_trace_rays_and_indirect(halart, oracle):
+    """HalaRayTracingProgram mirror (src/raytracing_program.rs:330-340) over device buffers"""
+    import torch
+    s = scenes.cornell_box()
+    r = make_renderer(halart, s, 16, 16)
+    osc = oracle.OracleScene(s)
+    rays = osc.camera_rays(64, 32, 0)
+    d_rays = torch.from_numpy(rays.view(np.uint8).copy()).cuda()
+    d_hits = torch.zeros(len(rays) * 16, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    desc = halart.HalaRayTracingProgramDesc(raygen_shader_file_paths=["builtin"], hit_shader_file_paths=[halart.HalaRayTracingHitShaderDesc("builtin")], push_constant_size=4)
+    prog = halart.HalaRayTracingProgram(r, desc, "t")
+    prog.bind(d_rays.data_ptr(), d_hits.data_ptr())
+    prog.trace_rays(64, 32, 1)
+    r.wait_idle()
+    want = osc.trace(rays, 0)
+    assert d_hits.cpu().numpy().tobytes() == want.tobytes()
+    prog.push_constants(0, (1).to_bytes(4, "little"))  # any-hit
+    cmd = torch.tensor([64, 16, 2], dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    prog.trace_rays_indirect(cmd.data_ptr())
+    r.wait_idle()
+    got = np.frombuffer(d_hits.cpu().numpy().tobytes(), dtype=H._abi.HIT_DTYPE)
+    assert np.array_equal(got["t"], osc.trace(rays, 1)["t"])
+    r.close()
+
+
+# ---- K4: refit -------------------------------------------------------------------------------------------------------
+def test_refit_after_node_transform(halart, oracle):
+    s = scenes.cornell_box()
+    r = make_renderer(halart, s, 16, 16)
+    m = np.eye(4, dtype=f32)
+    m[:3, 3] = (60.0, 25.0, -40.0)
+    c, sn = np.cos(0.4), np.sin(0.4)
+    m[:3, :3] = np.array([[c, 0, sn], [0, 1, 0], [-sn, 0, c]], dtype=f32)
+    r.update_node_transform(2, m)  # move the tall block
+    r.refit()
+    s.nodes[2].local_transform = m
+    osc = oracle.OracleScene(s)
+    nodes, tris = r.download_bvh()
+    rc, _ = oracle.validate_bvh(nodes, tris, osc.triangles())
+    assert rc == 0
+    rays = osc.camera_rays(128, 128, 0)
+    assert r.trace_rays_host(rays, 0).tobytes() == osc.trace(rays, 0).tobytes()
+    r.update(); r.render()
+    img, _ = osc.render(16, 16, frames=1)
+    assert r.read_image(0).tobytes() == img[0].tobytes()
+    r.close()
+
+
+# ---- K5-K7: the integrator -----------------------------------------------------------------------------------------------
+def assert_images_equal(r, imgs):
+    for which, name in ((0, "accum"), (1, "albedo"), (2, "normal"), (3, "final")):
+        got = r.read_image(which)
+        want = imgs[which]
+        if got.tobytes() != want.tobytes():
+            bad = np.any(got != want, axis=-1)
+            raise AssertionError(f"{name}: {bad.sum()} of {bad.size} pixels differ, max abs diff {np.abs(got - want).max()}")
+
+
+def test_render_cornell_bit_exact_and_fixture(halart, oracle):
+    """config 1 geometry at a test size; also against the frozen oracle render"""
+    s = scenes.cornell_box()
+    r = make_renderer(halart, s, 64, 64)
+    for _ in range(2):
+        r.update(); r.render()
+    imgs, st = oracle.OracleScene(s).render(64, 64, frames=2)
+    assert_images_equal(r, imgs)
+    g = np.load(os.path.join(GOLDEN, "cornell_64x64_2spp.npz"))
+    assert r.read_image(0).tobytes() == g["accum"].tobytes()
+    stg = r.statistics()
+    assert (stg.rays_closest_total, stg.rays_shadow_total) == (st.rays_closest, st.rays_shadow)
+    u = r.global_uniform()  # src/rt_renderer.rs:408-427
+    assert (u.frame_index, u.max_depth, u.rr_depth, u.num_of_lights, u.env_type, u.camera_index) == (1, 5, 3, 1, 0, 0)
+    assert list(u.resolution) == [64.0, 64.0] and list(u.sky_color) == [f32(x) for x in (0.5, 0.7, 1.0, 1.0)] and list(u.ground_color) == [1.0] * 4
+    r.close()
+
+
+@pytest.mark.parametrize("tonemap", [(True, False, False), (True, True, False), (True, True, True)])
+def test_render_tonemap_and_setters(halart, oracle, tonemap):
+    s = scenes.cornell_box(aspect=1.5)
+    r = make_renderer(halart, s, 96, 64, max_depth=4, rr_depth=1, tonemap=tonemap)
+    r.set_exposure_value(1.7)
+    r.set_env_intensity(0.8)
+    r.set_sky_color((0.2, 0.3, 0.9, 1.0))
+    r.set_ground_color((0.4, 0.3, 0.2, 1.0))
+    for _ in range(3):
+        r.update(); r.render()
+    imgs, _ = oracle.OracleScene(s).render(96, 64, frames=3, max_depth=4, rr_depth=1, tonemap=tonemap, exposure=1.7, env_intensity=0.8,
+                                           sky=(0.2, 0.3, 0.9, 1.0), ground=(0.4, 0.3, 0.2, 1.0))
+    assert_images_equal(r, imgs)
+    r.close()
+
+
+def test_render_all_light_types_bit_exact(halart, oracle):
+    s = light_scene()
+    cb = scenes.cornell_box()
+    s.materials = cb.materials
+    s.meshes = cb.meshes
+    s.nodes += [H.HalaNode(name="room", mesh_index=0), H.HalaNode(name="b1", mesh_index=1), H.HalaNode(name="b2", mesh_index=2)]
+    s.nodes[7] = cb.nodes[3]  # the Cornell camera
+    # place the analytic lights inside the room
+    s.nodes[0].local_transform = np.eye(4, dtype=f32)
+    for idx, pos in ((1, (150, 400, 200)), (2, (0, 0, 0)), (3, (100, 50, 0)), (4, (300, 300, 150)), (5, (0, -120, 80))):
+        m = s.nodes[idx].local_transform.copy(); m[:3, 3] = pos; s.nodes[idx].local_transform = m
+    for l, k in zip(s.lights, (4e4, 1.0, 2e5, 30.0, 60.0)):
+        l.intensity = k
+    s.lights[3].params = (120.0, 90.0); s.lights[4].params = (40.0, 0.0)
+    r = make_renderer(halart, s, 80, 80, max_depth=4, rr_depth=2)
+    for _ in range(3):
+        r.update(); r.render()
+    imgs, _ = oracle.OracleScene(s).render(80, 80, frames=3, max_depth=4, rr_depth=2)
+    assert_images_equal(r, imgs)
+    assert imgs[0][..., :3].max() > 0
+    r.close()
+
+
+def test_render_envmap_importance_sampling_bit_exact(halart, oracle):
+    """config 3 at a test size: blob + ground, env map with a 1e4x sun, rotation, MIS env + BSDF"""
+    env = scenes.sky_sun_envmap(256, 128)
+    s = scenes.bunny_class(subdivisions=3, aspect=96 / 54)
+    r = make_renderer(halart, s, 96, 54, max_depth=4, rr_depth=2, env=env, env_rot=75.0)
+    r.set_env_intensity(1.25)
+    for _ in range(3):
+        r.update(); r.render()
+    imgs, st = oracle.OracleScene(s, envmap=env).render(96, 54, frames=3, max_depth=4, rr_depth=2, env_rotation=75.0, env_intensity=1.25)
+    assert_images_equal(r, imgs)
+    t, m, c = r.env_distribution(256, 128)
+    ot, om, oc = oracle.envmap_build_distribution(env)
+    assert f32(t).tobytes() == ot.tobytes() and m.tobytes() == om.tobytes() and c.tobytes() == oc.tobytes()
+    u = r.global_uniform()
+    assert (u.env_type, u.env_map_width, u.env_map_height) == (1, 256, 128) and f32(u.env_rotation) == f32(f32(75.0) / f32(360.0))
+    assert f32(u.env_total_sum) == ot
+    r.close()
+
+
+def test_render_orthographic_and_thin_lens(halart, oracle):
+    s = scenes.cornell_box()
+    s.cameras = [H.HalaOrthographicCamera(xmag=300.0, ymag=300.0)]
+    r = make_renderer(halart, s, 48, 48)
+    r.update(); r.render()
+    imgs, _ = oracle.OracleScene(s).render(48, 48, frames=1)
+    assert_images_equal(r, imgs)
+    r.close()
+    s = scenes.cornell_box()
+    s.cameras[0].aperture = 12.0; s.cameras[0].focal_distance = 1000.0
+    r = make_renderer(halart, s, 48, 48)
+    r.update(); r.render()
+    imgs, _ = oracle.OracleScene(s).render(48, 48, frames=1)
+    assert_images_equal(r, imgs)
+    r.close()
+
+
+def test_furnace_on_gpu(halart):
+    """analytic check on the GPU itself: white diffuse sphere in a uniform environment converges to the environment"""
+    r = make_renderer(halart, furnace_scene(), 32, 32, max_depth=12, rr_depth=64)
+    r.set_sky_color((0.7, 0.7, 0.7, 1)); r.set_ground_color((0.7, 0.7, 0.7, 1))
+    for _ in range(64):
+        r.update()
+    r.render()
+    assert abs(r.read_image(0)[8:24, 8:24, :3].mean() - 0.7) < 0.02
+    r.close()
+
+
+def test_max_frames_stops_accumulation(halart):
+    """update() is a no-op once total_frames > max_frames (src/rt_renderer.rs:394-396)"""
+    r = make_renderer(halart, scenes.cornell_box(), 32, 32, max_frames=2)
+    for _ in range(2):
+        r.update(); r.render()
+    a = r.read_image(0).copy()
+    for _ in range(3):
+        r.update(); r.render()
+    assert r.read_image(0).tobytes() == a.tobytes()
+    st = r.statistics()
+    assert st.total_frames == 5 and st.updates_rendered == 2
+    r.close()
+
+
+def test_save_images_pfm_trio(halart, oracle, tmp_path):
+    s = scenes.cornell_box()
+    r = make_renderer(halart, s, 40, 24, tonemap=(True, True, False))
+    r.update(); r.render()
+    r.save_images(str(tmp_path / "shot.png"))  # <stem>_color.pfm / _albedo.pfm / _normal.pfm (src/rt_renderer.rs:1235-1237)
+    imgs, _ = oracle.OracleScene(s).render(40, 24, frames=1)
+    color = oracle.tonemap_pixels(imgs[0], True, True, False)  # host tonemap of accum, no exposure (:1256-1316)
+    assert (tmp_path / "shot_color.pfm").read_bytes() == oracle.pfm_bytes(color)
+    assert (tmp_path / "shot_albedo.pfm").read_bytes() == oracle.pfm_bytes(imgs[1])
+    assert (tmp_path / "shot_normal.pfm").read_bytes() == oracle.pfm_bytes(imgs[2])
+    r.close()
+
+
+def test_envmap_file_and_dist_cache(halart, oracle, tmp_path, monkeypatch):
+    """set_envmap(path): PFM decode + ./out/<stem>.dist_cache written on first use, read on the second (src/envmap.rs:90-142)"""
+    env = scenes.sky_sun_envmap(64, 32)
+    lib = halart.load_library()
+    monkeypatch.chdir(tmp_path)
+    os.makedirs("out")
+    halart.check(lib.hala_write_pfm(b"sky.pfm", env.ctypes.data_as(C.POINTER(C.c_float)), 64, 32))
+    r = halart.HalaRenderer("envfile", 16, 16, 2, 1, False, False, False, 0)
+    r.set_envmap("sky.pfm", 10.0)
+    t, m, c = r.env_distribution(64, 32)
+    ot, om, oc = oracle.envmap_build_distribution(env)
+    assert f32(t).tobytes() == ot.tobytes() and c.tobytes() == oc.tobytes()
+    blob = np.fromfile("out/sky.dist_cache", dtype=f32)
+    assert blob.size == 1 + 32 + 64 * 32 and blob[0].tobytes() == ot.tobytes() and blob[1:33].tobytes() == om.tobytes() and blob[33:].tobytes() == oc.tobytes()
+    # a stale cache is trusted blindly, exactly like the reference (no header / version)
+    blob[0] = f32(123.0)
+    blob.tofile("out/sky.dist_cache")
+    r.set_envmap("sky.pfm", 0.0)
+    assert r.env_distribution(64, 32)[0] == 123.0
+    r.close()
+
+
+def test_full_size_render_properties(halart):
+    """BASELINE.json configs[1] at full size (1920x1080, 4 spp): size-independent properties instead of an oracle run"""
+    s = scenes.cornell_box(aspect=1920 / 1080)
+    r = make_renderer(halart, s, 1920, 1080)
+    for _ in range(4):
+        r.update()
+    r.render()
+    a = r.read_image(0)
+    st = r.statistics()
+    assert np.isfinite(a).all() and a[..., :3].min() >= 0 and a[..., 3].min() == 1.0
+    assert 0.05 < a[..., :3].mean() < 2.0
+    assert st.rays_total > 4 * 1920 * 1080 * 2  # at least primary + one more segment on average
+    # idempotence: restarting the accumulation reproduces the same frame bit for bit (counter-based RNG, no atomics on data)
+    r.reset_accumulation()
+    for _ in range(4):
+        r.update()
+    r.render()
+    assert r.read_image(0).tobytes() == a.tobytes()
+    # linearity: every source of radiance (analytic light, emissive material, sky) scaled by 2 scales the image by 2
+    # (power-of-two factor => exact in binary32; path construction does not depend on radiance)
+    s.lights[0].intensity *= 2.0
+    for m in s.materials:
+        m.emission = tuple(2.0 * e for e in m.emission)
+    r2 = make_renderer(halart, s, 1920, 1080)
+    r2.set_env_intensity(2.0)
+    for _ in range(4):
+        r2.update()
+    r2.render()
+    assert np.array_equal(r2.read_image(0)[..., :3], a[..., :3] * f32(2.0))
+    r.close(); r2.close()

@@ -1,0 +1,163 @@
+"""CPU tier: the oracle's traversal + integrator (docs/RENDER_SPEC.md).  Pixel parity with the reference is UNPINNED
+(its shaders are not in the repository); what is pinned here is internal consistency — BVH traversal vs a
+brute-force intersector, analytic renders, frozen regression fixtures — so that the oracle can act as the spec the HIP
+kernels are held to in tests/test_gpu_parity.py."""
+import os
+
+import numpy as np
+import pytest
+
+import hala_renderer_amd as H
+from conftest import GOLDEN
+from hala_renderer_amd import scenes
+
+f32 = np.float32
+
+
+def random_rays(n, lo, hi, seed):
+    rng = np.random.RandomState(seed)
+    rays = np.zeros(n, dtype=H._abi.RAY_DTYPE)
+    rays["origin"] = (lo + rng.rand(n, 3) * (hi - lo)).astype(f32)
+    d = rng.randn(n, 3)
+    rays["direction"] = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(f32)
+    rays["tmin"] = 0.0
+    rays["tmax"] = np.where(rng.rand(n) < 0.3, rng.rand(n) * np.linalg.norm(hi - lo), 3.0e38).astype(f32)
+    return rays
+
+
+@pytest.mark.parametrize("scene_name", ["cornell", "blob", "sponza_small", "single_tri"])
+def test_bvh_traversal_equals_brute_force(oracle, scene_name):
+    if scene_name == "cornell":
+        s = scenes.cornell_box()
+    elif scene_name == "blob":
+        s = scenes.bunny_class(subdivisions=2)
+    elif scene_name == "sponza_small":
+        s = scenes.sponza_class(target_triangles=3000)
+    else:
+        s = scenes.cornell_box()
+        s.meshes = [H.HalaMesh([H.HalaPrimitive(indices=np.array([0, 1, 2], np.uint32), vertices=s.meshes[0].primitives[0].vertices[:3], material_index=0)])]
+        s.nodes = [H.HalaNode(name="t", mesh_index=0), s.nodes[3]]
+    osc = oracle.OracleScene(s)
+    mn, mx = osc.bounds()
+    pad = (mx - mn) * 0.3 + 1e-3
+    rays = random_rays(4000, mn - pad, mx + pad, 5)
+    for mode in (0, 1):
+        a = osc.trace(rays, mode)
+        b = osc.trace(rays, mode, brute=True)
+        if mode == 0:
+            assert np.array_equal(a["prim"], b["prim"])
+            assert a["t"].tobytes() == b["t"].tobytes() and a["u"].tobytes() == b["u"].tobytes() and a["v"].tobytes() == b["v"].tobytes()
+        else:
+            assert np.array_equal(a["t"], b["t"])
+
+
+def test_closest_hit_tie_break_prefers_lower_id(oracle):
+    """two coincident triangles: RENDER_SPEC §4.2 says equal t -> lower global id, independent of BVH order"""
+    s = scenes.cornell_box()
+    prim = s.meshes[0].primitives[0]
+    tri = H.HalaPrimitive(indices=np.array([0, 1, 2, 0, 1, 2], np.uint32), vertices=prim.vertices[:3].copy(), material_index=0)
+    s.meshes = [H.HalaMesh([tri])]
+    s.nodes = [H.HalaNode(name="t", mesh_index=0), s.nodes[3]]
+    osc = oracle.OracleScene(s)
+    v = prim.vertices[:3]["position"]
+    c = v.mean(axis=0)
+    rays = np.zeros(1, dtype=H._abi.RAY_DTYPE)
+    rays["origin"] = c + np.array([0, 100.0, 0], dtype=f32); rays["direction"] = (0, -1, 0); rays["tmax"] = 1e30
+    h = osc.trace(rays, 0)
+    assert h["prim"][0] == 0 and h["t"][0] > 0
+
+
+def test_primary_hit_table_fixture(oracle):
+    g = np.load(os.path.join(GOLDEN, "cornell_primary_hits_16x16.npz"))
+    osc = oracle.OracleScene(scenes.cornell_box())
+    rays = osc.camera_rays(16, 16, 0)
+    assert rays.tobytes() == g["rays"].tobytes()
+    hits = osc.trace(rays, 0)
+    assert hits.tobytes() == g["hits"].tobytes()
+    assert (hits["prim"] != 0xFFFFFFFF).mean() > 0.9  # the camera looks into the box
+
+
+def test_cornell_render_fixture(oracle):
+    g = np.load(os.path.join(GOLDEN, "cornell_64x64_2spp.npz"))
+    imgs, st = oracle.OracleScene(scenes.cornell_box()).render(64, 64, frames=2, max_depth=5, rr_depth=3)
+    for k, name in enumerate(["accum", "albedo", "normal"]):
+        assert imgs[k].tobytes() == g[name].tobytes(), name
+    assert [st.rays_closest, st.rays_shadow] == list(g["rays"])
+
+
+def test_blob_env_render_fixture(oracle):
+    g = np.load(os.path.join(GOLDEN, "blob_env_64x36_2spp.npz"))
+    osc = oracle.OracleScene(scenes.bunny_class(subdivisions=2), envmap=g["env"])
+    imgs, st = osc.render(64, 36, frames=2, max_depth=4, rr_depth=2, env_rotation=30.0, env_intensity=1.5)
+    # the scene is built with numpy transcendentals (icosphere normalisation is exact, hash noise is not libm-free):
+    # compare with a tolerance so that a different numpy/libm build cannot fail the pin
+    for k, name in enumerate(["accum", "albedo", "normal"]):
+        d = np.abs(imgs[k] - g[name])
+        assert np.mean(d.max(axis=-1) > 1e-3) < 0.02, name
+
+
+def test_frame_accumulation_is_incremental(oracle):
+    """rendering frames [0,2) then [2,4) into the same images == rendering [0,4) at once (running mean, RENDER_SPEC §8)"""
+    osc = oracle.OracleScene(scenes.cornell_box())
+    a, _ = osc.render(32, 32, frames=4)
+    b, _ = osc.render(32, 32, frames=2)
+    b, _ = osc.render(32, 32, frames=2, first_frame=2, images=b)
+    assert a[0].tobytes() == b[0].tobytes() and a[1].tobytes() == b[1].tobytes()
+
+
+def test_rect_render_is_position_independent(oracle):
+    """RNG is keyed by global pixel id: a sub-rectangle renders the same pixels as the full frame (basis of tile sharding)"""
+    osc = oracle.OracleScene(scenes.cornell_box())
+    full, _ = osc.render(48, 40, frames=2)
+    part, _ = osc.render(48, 40, frames=2, rect=(16, 8, 40, 24))
+    assert full[0][8:24, 16:40].tobytes() == part[0][8:24, 16:40].tobytes()
+    assert np.all(part[0][:8] == 0)
+
+
+def furnace_scene():
+    s = H.HalaScene()
+    blob = scenes.blob_mesh(subdivisions=3, amplitude=0.0)  # a sphere
+    blob.material_index = 0
+    s.materials = [H.HalaMaterial(type=0, base_color=(1.0, 1.0, 1.0), roughness=0.0)]
+    s.meshes = [H.HalaMesh([blob])]
+    s.nodes = [H.HalaNode(name="sphere", mesh_index=0),
+               H.HalaNode(name="cam", camera_index=0, local_transform=scenes.look_at_node_transform((0, 0, 4), (0, 0, 0)))]
+    s.cameras = [H.HalaPerspectiveCamera(aspect=1.0, yfov=0.6)]
+    return s
+
+
+def test_furnace_sky(oracle):
+    """white Lambertian sphere in a uniform environment: every pixel converges to the environment radiance"""
+    osc = oracle.OracleScene(furnace_scene())
+    imgs, _ = osc.render(32, 32, frames=64, max_depth=12, rr_depth=64, ground=(0.7, 0.7, 0.7, 1), sky=(0.7, 0.7, 0.7, 1))
+    centre = imgs[0][8:24, 8:24, :3]
+    assert abs(centre.mean() - 0.7) < 0.02  # energy lost only to the max_depth cut-off ((1)^12 -> none) and noise
+
+
+def test_furnace_envmap_importance_sampling(oracle):
+    """same furnace with a constant env MAP: exercises env_map_sample/pdf + MIS; must agree with the sky result"""
+    env = np.full((16, 32, 4), 0.7, dtype=f32)
+    osc = oracle.OracleScene(furnace_scene(), envmap=env)
+    imgs, _ = osc.render(32, 32, frames=64, max_depth=12, rr_depth=64)
+    assert abs(imgs[0][8:24, 8:24, :3].mean() - 0.7) < 0.02
+
+
+def test_env_is_matches_brute_force_mean(oracle):
+    """env-map IS (with a very bright sun texel) and plain BSDF sampling must converge to the same mean"""
+    env = scenes.sky_sun_envmap(64, 32, sun_radius_deg=6.0, sun_gain=200.0)
+    s = scenes.bunny_class(subdivisions=1)
+    a = oracle.OracleScene(s, envmap=env).render(24, 16, frames=256, max_depth=2, rr_depth=8)[0][0]
+    # reference estimate: same scene, but many more samples
+    b = oracle.OracleScene(s, envmap=env).render(24, 16, frames=1024, max_depth=2, rr_depth=8)[0][0]
+    assert abs(a[..., :3].mean() - b[..., :3].mean()) / b[..., :3].mean() < 0.05
+
+
+def test_tile_assignment_is_a_balanced_partition(oracle):
+    for tx, ty, world in [(60, 34, 8), (60, 34, 2), (7, 5, 4), (120, 68, 8), (3, 1, 8)]:
+        owner, slot = oracle.tile_assignment(tx, ty, world)
+        n = tx * ty
+        counts = np.bincount(owner, minlength=world)
+        assert counts.max() - counts.min() <= 1 and counts.sum() == n
+        keys = owner.astype(np.int64) * (n + 1) + slot
+        assert len(np.unique(keys)) == n  # (owner, slot) is unique per tile
+        assert slot.max() == (n + world - 1) // world - 1
