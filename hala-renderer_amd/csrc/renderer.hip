@@ -24,7 +24,8 @@ using namespace rt;
 namespace {
 
 constexpr uint32_t kLeafMax = 4;
-constexpr size_t kLdsStageBudget = 40 * 1024;  // bytes of BVH top staged per workgroup next to the 24-KB stack
+constexpr size_t kLdsStageBudget = 40 * 1024;  // a BVH up to this size is staged whole in LDS (next to the 24-KB stack)
+constexpr size_t kLdsPartialStage = 2 * 1024;  // larger BVHs: bytes of top-of-tree nodes staged per workgroup
 constexpr int kStatRing = 16;
 
 // ---- RENDER_SPEC §2.2 on the host (for tan(yfov/2); same polynomials as rt_math.h) ---------------------------
@@ -308,8 +309,12 @@ int upload_packed(hala_rt_renderer* r) {
 
 int configure_traversal(hala_rt_renderer* r) {
   const size_t nb = (size_t)r->bvh.node_count * 64, tb = (size_t)r->bvh.tri_count * 48;
+  // Whole BVH in LDS when it fits the budget; otherwise only a small top-of-tree slice: occupancy (waves that hide
+  // the L2 / Infinity-Cache latency of the node fetches) is worth more than a larger staged slice.
+  size_t partial = kLdsPartialStage;
+  if (const char* e = getenv("HALART_LDS_STAGE_BYTES")) partial = (size_t)strtoul(e, nullptr, 10);  // tuning knob
   if (nb + tb <= kLdsStageBudget) { r->lds_nodes = r->bvh.node_count; r->lds_tris = r->bvh.tri_count; }
-  else { r->lds_nodes = (uint32_t)std::min<size_t>(r->bvh.node_count, kLdsStageBudget / 64); r->lds_tris = 0; }
+  else { r->lds_nodes = (uint32_t)std::min<size_t>(r->bvh.node_count, partial / 64); r->lds_tris = 0; }
   const size_t smem = (size_t)r->lds_nodes * 64 + (size_t)r->lds_tris * 48 + traverse_stack_bytes();
   uint32_t per_cu = traverse_blocks_per_cu(smem);
   if (per_cu == 0) RT_FAIL("The traversal kernel does not fit on a compute unit with the requested LDS staging.");
@@ -461,7 +466,6 @@ int hala_rt_set_scene(hala_rt_renderer* r, const hala_scene_desc* scene) {
   r->has_scene = false; r->committed = false;  // "Release the old scene in the GPU." (src/rt_renderer.rs:1164)
   const std::string e = r->hs.assign(scene);
   if (!e.empty()) RT_FAIL(e);
-  for (const auto& m : r->hs.materials) if (m.type == 1u) RT_FAIL("DISNEY materials (type 1) are not implemented by this integrator yet (docs/RENDER_SPEC.md §7.1).");
   if (upload_packed(r) != HALA_OK) return HALA_ERR;
   r->has_scene = true;
   return HALA_OK;

@@ -143,8 +143,98 @@ struct MatView {
   f3 base, emission;
   float ax, ay;
   uint32_t type;
+  // DISNEY (type 1) only
+  float metallic, roughness, specular_tint, sheen, sheen_tint, clearcoat, clearcoat_roughness, ior;
 };
+
+// ---- §7.1b DISNEY ----------------------------------------------------------------------------------------------
+RT_DI float schlick5(float x) {
+  float m = clampf(1.0f - x, 0.0f, 1.0f);
+  float m2 = m * m;
+  return m2 * m2 * m;
+}
+RT_DI f3 mix3(f3 a, f3 b, float t) { return a * (1.0f - t) + b * t; }
+RT_DI float mixf(float a, float b, float t) { return a * (1.0f - t) + b * t; }
+RT_DI float ggx_d(f3 h, float ax, float ay) {
+  float hx = h.x / ax, hy = h.y / ay;
+  float k = hx * hx + hy * hy + h.z * h.z;
+  return 1.0f / (kPi * ax * ay * k * k);
+}
+RT_DI float ggx_g1(f3 w, float ax, float ay) {
+  float a = ax * w.x, b = ay * w.y;
+  float l = (a * a + b * b) / (w.z * w.z);
+  return 2.0f / (1.0f + sqrtf(1.0f + l));
+}
+RT_DI f3 ggx_sample_vndf(f3 v, float ax, float ay, float r1, float r2) {
+  f3 vh = normalize3(mk3(ax * v.x, ay * v.y, v.z));
+  float lensq = vh.x * vh.x + vh.y * vh.y;
+  f3 t1 = mk3(1.0f, 0.0f, 0.0f);
+  if (lensq > 0.0f) { float il = 1.0f / sqrtf(lensq); t1 = mk3(-vh.y * il, vh.x * il, 0.0f); }
+  f3 t2 = cross3(vh, t1);
+  float r = sqrtf(r1);
+  float s, c;
+  sincos_2pi(r2, &s, &c);
+  float a = r * c, b = r * s;
+  float sn = 0.5f * (1.0f + vh.z);
+  b = (1.0f - sn) * sqrtf(maxf(0.0f, 1.0f - a * a)) + sn * b;
+  float cz = sqrtf(maxf(0.0f, 1.0f - a * a - b * b));
+  f3 nh = t1 * a + t2 * b + vh * cz;
+  return normalize3(mk3(ax * nh.x, ay * nh.y, maxf(0.0f, nh.z)));
+}
+struct DisneyLobes {
+  float pd, ps, pc;
+  f3 cspec0, csheen;
+  float cc_alpha;
+};
+RT_DI DisneyLobes disney_lobes(const MatView& m, float nv) {
+  DisneyLobes d;
+  float lb = luminance(m.base);
+  f3 tint = lb > 0.0f ? m.base * (1.0f / lb) : splat3(1.0f);
+  float f0 = (m.ior - 1.0f) / (m.ior + 1.0f);
+  f0 = f0 * f0;
+  d.cspec0 = mix3(mix3(splat3(1.0f), tint, m.specular_tint) * f0, m.base, m.metallic);
+  d.csheen = mix3(splat3(1.0f), tint, m.sheen_tint);
+  d.cc_alpha = maxf(0.001f, m.clearcoat_roughness * m.clearcoat_roughness);
+  float fv = schlick5(nv);
+  float wd = (1.0f - m.metallic) * lb;
+  float ws = luminance(mix3(d.cspec0, splat3(1.0f), fv));
+  float wc = 0.25f * m.clearcoat * mixf(0.04f, 1.0f, fv);
+  float sum = wd + ws + wc;
+  if (!(sum > 0.0f)) { d.pd = d.ps = d.pc = 0.0f; return d; }
+  float inv = 1.0f / sum;
+  d.pd = wd * inv; d.ps = ws * inv; d.pc = wc * inv;
+  return d;
+}
+RT_DI void disney_eval(const MatView& m, f3 wo, f3 wi, f3 n, f3* f, float* pdf) {
+  float nl = dot3(n, wi), nv = dot3(n, wo);
+  if (!(nl > 0.0f && nv > 0.0f)) { *f = splat3(0.0f); *pdf = 0.0f; return; }
+  f3 t, b;
+  onb(n, &t, &b);
+  f3 lo = mk3(dot3(wo, t), dot3(wo, b), nv), li = mk3(dot3(wi, t), dot3(wi, b), nl);
+  f3 h = normalize3(lo + li);
+  float ldh = dot3(li, h);
+  DisneyLobes d = disney_lobes(m, nv);
+  float fl = schlick5(nl), fv = schlick5(nv), fh = schlick5(ldh);
+  float fd90 = 0.5f + 2.0f * sqrtf(m.roughness) * ldh * ldh;
+  float fd = mixf(1.0f, fd90, fl) * mixf(1.0f, fd90, fv);
+  float dw = 1.0f - m.metallic;
+  f3 fs = mix3(d.cspec0, splat3(1.0f), fh);
+  f3 fr = m.base * (splat3(1.0f) - fs) * (kInvPi * fd * dw) + d.csheen * (m.sheen * fh * dw);
+  float ds = ggx_d(h, m.ax, m.ay);
+  float g1o = ggx_g1(lo, m.ax, m.ay), g1i = ggx_g1(li, m.ax, m.ay);
+  float denom = 4.0f * nl * nv;
+  fr = fr + fs * (ds * g1o * g1i / denom);
+  float dc = ggx_d(h, d.cc_alpha, d.cc_alpha);
+  float c1o = ggx_g1(lo, d.cc_alpha, d.cc_alpha), c1i = ggx_g1(li, d.cc_alpha, d.cc_alpha);
+  float fc = mixf(0.04f, 1.0f, fh);
+  fr = fr + splat3(0.25f * m.clearcoat * fc * dc * c1o * c1i / denom);
+  *f = fr;
+  float inv4nv = 1.0f / (4.0f * nv);
+  *pdf = d.pd * (nl * kInvPi) + d.ps * (g1o * ds * inv4nv) + d.pc * (c1o * dc * inv4nv);
+}
+
 RT_DI void bsdf_eval(const MatView& m, f3 wo, f3 wi, f3 n, f3* f, float* pdf) {
+  if (m.type == 1u) { disney_eval(m, wo, wi, n, f, pdf); return; }
   float nl = dot3(n, wi), nv = dot3(n, wo);
   if (!(nl > 0.0f && nv > 0.0f)) { *f = splat3(0.0f); *pdf = 0.0f; return; }
   float s = dot3(wi, wo) - nl * nv;
@@ -153,9 +243,27 @@ RT_DI void bsdf_eval(const MatView& m, f3 wo, f3 wi, f3 n, f3* f, float* pdf) {
   *f = m.base * k;
   *pdf = nl * kInvPi;
 }
-RT_DI bool bsdf_sample(const MatView& m, f3 wo, f3 n, float r1, float r2, float /*r3*/, f3* wi, f3* f, float* pdf) {
+RT_DI bool bsdf_sample(const MatView& m, f3 wo, f3 n, float r1, float r2, float r3, f3* wi, f3* f, float* pdf) {
   f3 t, b;
   onb(n, &t, &b);
+  if (m.type == 1u) {
+    float nv = dot3(n, wo);
+    if (!(nv > 0.0f)) { *f = splat3(0.0f); *pdf = 0.0f; return false; }
+    DisneyLobes d = disney_lobes(m, nv);
+    if (r3 < d.pd) {
+      *wi = to_world(cosine_hemisphere(r1, r2), t, b, n);
+    } else {
+      bool spec = r3 < d.pd + d.ps;
+      float ax = spec ? m.ax : d.cc_alpha, ay = spec ? m.ay : d.cc_alpha;
+      f3 lo = mk3(dot3(wo, t), dot3(wo, b), nv);
+      f3 h = ggx_sample_vndf(lo, ax, ay, r1, r2);
+      float k = 2.0f * dot3(lo, h);
+      f3 li = h * k - lo;
+      *wi = to_world(li, t, b, n);
+    }
+    disney_eval(m, wo, *wi, n, f, pdf);
+    return *pdf > 0.0f;
+  }
   f3 l = cosine_hemisphere(r1, r2);
   *wi = to_world(l, t, b, n);
   bsdf_eval(m, wo, *wi, n, f, pdf);
@@ -306,6 +414,9 @@ RT_DI Surface make_surface(const SceneView& sv, f3 o, f3 d, float t, float u, fl
   sf.mat.base = ld3(m.base_color);
   sf.mat.emission = ld3(m.emission);
   sf.mat.ax = m.ax; sf.mat.ay = m.ay; sf.mat.type = m.type;
+  sf.mat.metallic = m.metallic; sf.mat.roughness = m.roughness; sf.mat.specular_tint = m.specular_tint;
+  sf.mat.sheen = m.sheen; sf.mat.sheen_tint = m.sheen_tint; sf.mat.clearcoat = m.clearcoat;
+  sf.mat.clearcoat_roughness = m.clearcoat_roughness; sf.mat.ior = m.ior;
   return sf;
 }
 

@@ -140,7 +140,94 @@ static V3 sky_eval(const Frame& f, V3 d) {
 
 // ---- RENDER_SPEC §7.1 materials --------------------------------------------------------------------------------
 // DIFFUSE (type 0): Oren–Nayar with A = ax, B = ay as packed by src/scene/gpu/material.rs:53-60
+// DISNEY (type 1), RENDER_SPEC §7.1b: diffuse (Disney retro-reflection + sheen) + anisotropic GGX specular with the
+// alpha values packed by src/scene/gpu/material.rs:61-69 (roughness := r^2, ax, ay) + GGX clearcoat; VNDF sampling.
+static inline float schlick5(float x) {
+  float m = clampf(1.0f - x, 0.0f, 1.0f);
+  float m2 = m * m;
+  return m2 * m2 * m;
+}
+static inline V3 mix3(V3 a, V3 b, float t) { return a * (1.0f - t) + b * t; }
+static inline float mixf(float a, float b, float t) { return a * (1.0f - t) + b * t; }
+static inline float ggx_d(V3 h, float ax, float ay) {  // h in the local frame
+  float hx = h.x / ax, hy = h.y / ay;
+  float k = hx * hx + hy * hy + h.z * h.z;
+  return 1.0f / (kPi * ax * ay * k * k);
+}
+static inline float ggx_g1(V3 w, float ax, float ay) {  // Smith, w in the local frame, w.z > 0
+  float a = ax * w.x, b = ay * w.y;
+  float l = (a * a + b * b) / (w.z * w.z);
+  return 2.0f / (1.0f + sqrtf(1.0f + l));
+}
+static inline V3 ggx_sample_vndf(V3 v, float ax, float ay, float r1, float r2) {  // Heitz 2018
+  V3 vh = normalize3(v3(ax * v.x, ay * v.y, v.z));
+  float lensq = vh.x * vh.x + vh.y * vh.y;
+  V3 t1 = v3(1.0f, 0.0f, 0.0f);
+  if (lensq > 0.0f) { float il = 1.0f / sqrtf(lensq); t1 = v3(-vh.y * il, vh.x * il, 0.0f); }
+  V3 t2 = cross3(vh, t1);
+  float r = sqrtf(r1);
+  float s, c;
+  sincos_2pi(r2, &s, &c);
+  float a = r * c, b = r * s;
+  float sn = 0.5f * (1.0f + vh.z);
+  b = (1.0f - sn) * sqrtf(maxf(0.0f, 1.0f - a * a)) + sn * b;
+  float cz = sqrtf(maxf(0.0f, 1.0f - a * a - b * b));
+  V3 nh = t1 * a + t2 * b + vh * cz;
+  return normalize3(v3(ax * nh.x, ay * nh.y, maxf(0.0f, nh.z)));
+}
+struct DisneyLobes { float pd, ps, pc; V3 cspec0, csheen; float cc_alpha; };
+static inline DisneyLobes disney_lobes(const orc_gpu_material& m, V3 base, float nv) {
+  DisneyLobes d;
+  float lb = luminance(base);
+  V3 tint = lb > 0.0f ? base * (1.0f / lb) : v3s(1.0f);
+  float f0 = (m.ior - 1.0f) / (m.ior + 1.0f);
+  f0 = f0 * f0;
+  d.cspec0 = mix3(mix3(v3s(1.0f), tint, m.specular_tint) * f0, base, m.metallic);
+  d.csheen = mix3(v3s(1.0f), tint, m.sheen_tint);
+  d.cc_alpha = maxf(0.001f, m.clearcoat_roughness * m.clearcoat_roughness);
+  float fv = schlick5(nv);
+  float wd = (1.0f - m.metallic) * lb;
+  float ws = luminance(mix3(d.cspec0, v3s(1.0f), fv));
+  float wc = 0.25f * m.clearcoat * mixf(0.04f, 1.0f, fv);
+  float sum = wd + ws + wc;
+  if (!(sum > 0.0f)) { d.pd = d.ps = d.pc = 0.0f; return d; }
+  float inv = 1.0f / sum;
+  d.pd = wd * inv; d.ps = ws * inv; d.pc = wc * inv;
+  return d;
+}
+static inline void disney_eval(const orc_gpu_material& m, V3 base, V3 wo, V3 wi, V3 n, V3* f, float* pdf) {
+  float nl = dot3(n, wi), nv = dot3(n, wo);
+  if (!(nl > 0.0f && nv > 0.0f)) { *f = v3s(0.0f); *pdf = 0.0f; return; }
+  V3 t, b;
+  onb(n, &t, &b);
+  V3 lo = v3(dot3(wo, t), dot3(wo, b), nv), li = v3(dot3(wi, t), dot3(wi, b), nl);
+  V3 h = normalize3(lo + li);
+  float ldh = dot3(li, h);
+  DisneyLobes d = disney_lobes(m, base, nv);
+  float fl = schlick5(nl), fv = schlick5(nv), fh = schlick5(ldh);
+  // diffuse + sheen
+  float fd90 = 0.5f + 2.0f * sqrtf(m.roughness) * ldh * ldh;
+  float fd = mixf(1.0f, fd90, fl) * mixf(1.0f, fd90, fv);
+  float dw = 1.0f - m.metallic;
+  V3 fs = mix3(d.cspec0, v3s(1.0f), fh);  // specular Fresnel; the diffuse lobe only gets what it lets through
+  V3 fr = base * (v3s(1.0f) - fs) * (kInvPi * fd * dw) + d.csheen * (m.sheen * fh * dw);
+  // specular
+  float ds = ggx_d(h, m.ax, m.ay);
+  float g1o = ggx_g1(lo, m.ax, m.ay), g1i = ggx_g1(li, m.ax, m.ay);
+  float denom = 4.0f * nl * nv;
+  fr = fr + fs * (ds * g1o * g1i / denom);
+  // clearcoat
+  float dc = ggx_d(h, d.cc_alpha, d.cc_alpha);
+  float c1o = ggx_g1(lo, d.cc_alpha, d.cc_alpha), c1i = ggx_g1(li, d.cc_alpha, d.cc_alpha);
+  float fc = mixf(0.04f, 1.0f, fh);
+  fr = fr + v3s(0.25f * m.clearcoat * fc * dc * c1o * c1i / denom);
+  *f = fr;
+  float inv4nv = 1.0f / (4.0f * nv);
+  *pdf = d.pd * (nl * kInvPi) + d.ps * (g1o * ds * inv4nv) + d.pc * (c1o * dc * inv4nv);
+}
+
 static inline void bsdf_eval(const orc_gpu_material& m, V3 base, V3 wo, V3 wi, V3 n, V3* f, float* pdf) {
+  if (m.type == 1u) { disney_eval(m, base, wo, wi, n, f, pdf); return; }
   float nl = dot3(n, wi), nv = dot3(n, wo);
   if (!(nl > 0.0f && nv > 0.0f)) { *f = v3s(0.0f); *pdf = 0.0f; return; }
   float s = dot3(wi, wo) - nl * nv;
@@ -149,9 +236,27 @@ static inline void bsdf_eval(const orc_gpu_material& m, V3 base, V3 wo, V3 wi, V
   *f = base * k;
   *pdf = nl * kInvPi;
 }
-static inline bool bsdf_sample(const orc_gpu_material& m, V3 base, V3 wo, V3 n, float r1, float r2, float /*r3*/, V3* wi, V3* f, float* pdf) {
+static inline bool bsdf_sample(const orc_gpu_material& m, V3 base, V3 wo, V3 n, float r1, float r2, float r3, V3* wi, V3* f, float* pdf) {
   V3 t, b;
   onb(n, &t, &b);
+  if (m.type == 1u) {
+    float nv = dot3(n, wo);
+    if (!(nv > 0.0f)) { *f = v3s(0.0f); *pdf = 0.0f; return false; }
+    DisneyLobes d = disney_lobes(m, base, nv);
+    if (r3 < d.pd) {
+      *wi = to_world(cosine_hemisphere(r1, r2), t, b, n);
+    } else {
+      bool spec = r3 < d.pd + d.ps;
+      float ax = spec ? m.ax : d.cc_alpha, ay = spec ? m.ay : d.cc_alpha;
+      V3 lo = v3(dot3(wo, t), dot3(wo, b), nv);
+      V3 h = ggx_sample_vndf(lo, ax, ay, r1, r2);
+      float k = 2.0f * dot3(lo, h);
+      V3 li = h * k - lo;
+      *wi = to_world(li, t, b, n);
+    }
+    disney_eval(m, base, wo, *wi, n, f, pdf);
+    return *pdf > 0.0f;
+  }
   V3 l = cosine_hemisphere(r1, r2);
   *wi = to_world(l, t, b, n);
   bsdf_eval(m, base, wo, *wi, n, f, pdf);

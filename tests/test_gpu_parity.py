@@ -338,6 +338,32 @@ def test_render_envmap_importance_sampling_bit_exact(halart, oracle):
     r.close()
 
 
+def test_render_disney_materials_bit_exact(halart, oracle):
+    """RENDER_SPEC §7.1b: GGX/VNDF + clearcoat + sheen paths, on the blob (env map MIS) and on the atrium (24 materials,
+    quad lights, instanced meshes under a parent node)"""
+    env = scenes.sky_sun_envmap(128, 64, sun_gain=300.0)
+    s = scenes.bunny_class(subdivisions=3, aspect=80 / 48, disney=True)
+    s.materials[0].clearcoat = 1.0; s.materials[0].clearcoat_roughness = 0.15; s.materials[0].sheen = 0.5
+    s.materials[0].anisotropic = 0.6; s.materials[0].specular_tint = 0.4
+    s.materials[1] = H.HalaMaterial(type=1, base_color=(0.9, 0.85, 0.7), metallic=1.0, roughness=0.3)
+    r = make_renderer(halart, s, 80, 48, max_depth=5, rr_depth=2, env=env, env_rot=200.0)
+    for _ in range(3):
+        r.update(); r.render()
+    imgs, _ = oracle.OracleScene(s, envmap=env).render(80, 48, frames=3, max_depth=5, rr_depth=2, env_rotation=200.0)
+    assert_images_equal(r, imgs)
+    r.close()
+    s = scenes.sponza_class(target_triangles=30000, aspect=96 / 54, disney=True)
+    r = make_renderer(halart, s, 96, 54, max_depth=5, rr_depth=3)
+    for _ in range(2):
+        r.update(); r.render()
+    imgs, st = oracle.OracleScene(s).render(96, 54, frames=2, max_depth=5, rr_depth=3)
+    assert_images_equal(r, imgs)
+    assert imgs[0][..., :3].mean() > 1e-3
+    stg = r.statistics()
+    assert (stg.rays_closest_total, stg.rays_shadow_total) == (st.rays_closest, st.rays_shadow)
+    r.close()
+
+
 def test_render_orthographic_and_thin_lens(halart, oracle):
     s = scenes.cornell_box()
     s.cameras = [H.HalaOrthographicCamera(xmag=300.0, ymag=300.0)]

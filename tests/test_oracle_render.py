@@ -142,6 +142,30 @@ def test_furnace_envmap_importance_sampling(oracle):
     assert abs(imgs[0][8:24, 8:24, :3].mean() - 0.7) < 0.02
 
 
+DISNEY_VARIANTS = {
+    "plastic": dict(metallic=0.0, roughness=0.5),
+    "metal_aniso": dict(metallic=1.0, roughness=0.4, anisotropic=0.8, base_color=(0.9, 0.7, 0.4)),
+    "clearcoat_sheen": dict(metallic=0.0, roughness=0.7, clearcoat=1.0, clearcoat_roughness=0.2, sheen=0.8, sheen_tint=0.5, specular_tint=0.6),
+}
+
+
+@pytest.mark.parametrize("variant", list(DISNEY_VARIANTS.keys()))
+def test_disney_pdf_matches_sampling_and_conserves_energy(oracle, variant):
+    """constant environment seen (a) as SKY: BSDF sampling only, (b) as a constant env MAP: NEE + BSDF with MIS.
+    Both estimate the same integral; they agree only if disney_eval's pdf is the density disney_sample draws from.
+    A passive material can never return more than it receives (furnace <= environment)."""
+    s = furnace_scene()
+    kw = dict(DISNEY_VARIANTS[variant])
+    base = kw.pop("base_color", (1.0, 1.0, 1.0))
+    s.materials = [H.HalaMaterial(type=1, base_color=base, **kw)]
+    a = oracle.OracleScene(s).render(24, 24, frames=192, max_depth=6, rr_depth=64, ground=(0.7,) * 3 + (1,), sky=(0.7,) * 3 + (1,))[0][0]
+    env = np.full((8, 16, 4), 0.7, dtype=f32)
+    b = oracle.OracleScene(s, envmap=env).render(24, 24, frames=192, max_depth=6, rr_depth=64)[0][0]
+    ma, mb = a[6:18, 6:18, :3].mean(), b[6:18, 6:18, :3].mean()
+    assert abs(ma - mb) / mb < 0.03, (ma, mb)
+    assert 0.2 < mb <= 0.7 * 1.02
+
+
 def test_env_is_matches_brute_force_mean(oracle):
     """env-map IS (with a very bright sun texel) and plain BSDF sampling must converge to the same mean"""
     env = scenes.sky_sun_envmap(64, 32, sun_radius_deg=6.0, sun_gain=200.0)
