@@ -92,10 +92,10 @@ struct WorkCounters {
 };
 struct Control {
   uint32_t n_active[kMaxDepth + 1];  // ray-queue size entering bounce d
-  uint32_t n_shadow[kMaxDepth];      // shadow work items produced by bounce d
+  uint32_t n_shadow[2][kMaxDepth];   // connections produced by bounce d: [0] light, [1] environment
   uint32_t pad[3];
-  WorkCounters work_closest;  // re-zeroed by the shade kernel of every bounce (it runs between two uses)
-  WorkCounters work_shadow;
+  WorkCounters work_closest;    // re-zeroed by the shade kernel of every bounce (it runs between two uses)
+  WorkCounters work_shadow[2];
   unsigned long long rays_closest, rays_shadow;  // totals of this update
   // only filled by counting launches: steps[kind] = {nodes visited, triangles tested}; kind 0 closest-hit
   // kernel, kind 1 shadow / any-hit kernel
@@ -110,19 +110,20 @@ struct PathState {
   float4* normal;
 };
 
-struct ShadowEntry {  // 64 B: one NEE connection
+struct ShadowEntry {  // 48 B: one NEE connection = shadow ray + the contribution it carries if unoccluded
   hala_ray ray;
-  float contrib[3];
-  uint32_t slot;
-  uint32_t pad[4];
+  float contrib[3];  // throughput * f * Le * cos * weight / pdf, already multiplied out (RENDER_SPEC §6.5-6.6)
+  uint32_t slot;     // pixel slot whose radiance receives it
 };
+static_assert(sizeof(ShadowEntry) == 48, "shadow entry is 48 B");
 
 struct Queues {
   hala_ray* rays[2];
   uint32_t* slots[2];
   hala_hit* hits;
-  ShadowEntry* shadow;  // 2 per path slot: [2*q] light, [2*q+1] environment (ray.tmax < 0: unused)
-  uint32_t* shadow_list;  // compact list of path-queue indices q that own >= 1 shadow ray
+  // compact connection queues of the current bounce: [0] light NEE, [1] environment NEE.  A path owns at most one entry
+  // per queue, the two queues are traced by consecutive launches, so contributions land in spec order without atomics.
+  ShadowEntry* shadow[2];
 };
 
 }  // namespace rt

@@ -38,33 +38,39 @@ RT_DI uint32_t wave_sum(uint32_t v) {
 // All threads of the block must call it.  Returns this lane's output index for each predicate.
 constexpr int kShadeThreads = 512;
 struct BlockCompact {
-  uint32_t cnt[2][kShadeThreads / 64];
-  uint32_t base[2];
-  uint32_t extra[kShadeThreads / 64];
+  uint32_t cnt[3][kShadeThreads / 64];
+  uint32_t base[3];
 };
-RT_DI void block_compact2(BlockCompact& sm, bool keep0, bool keep1, uint32_t* counter0, uint32_t* counter1, uint32_t extra,
-                          unsigned long long* extra_counter, uint32_t* out0, uint32_t* out1) {
-  const unsigned long long m0 = __ballot(keep0), m1 = __ballot(keep1);
+// Three predicates at once (surviving path, light connection, environment connection); counters[k] receives the
+// block total of predicate k; shadow_total (64-bit) receives the number of connections (predicates 1 + 2).
+RT_DI void block_compact3(BlockCompact& sm, const bool keep[3], uint32_t* const counters[3], unsigned long long* shadow_total,
+                          uint32_t out[3]) {
+  unsigned long long m[3];
   const uint32_t w = threadIdx.x >> 6, l = lane_id();
-  const uint32_t ex = wave_sum(extra);
-  if (l == 0u) { sm.cnt[0][w] = (uint32_t)__popcll(m0); sm.cnt[1][w] = (uint32_t)__popcll(m1); sm.extra[w] = ex; }
-  __syncthreads();
-  const uint32_t nw = blockDim.x >> 6;
-  if (threadIdx.x < 2u) {
-    uint32_t total = 0;
-    for (uint32_t k = 0; k < nw; ++k) total += sm.cnt[threadIdx.x][k];
-    sm.base[threadIdx.x] = total ? atomicAdd(threadIdx.x == 0u ? counter0 : counter1, total) : 0u;
-  } else if (threadIdx.x == 64u && extra_counter) {
-    uint32_t total = 0;
-    for (uint32_t k = 0; k < nw; ++k) total += sm.extra[k];
-    if (total) atomicAdd(extra_counter, (unsigned long long)total);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    m[k] = __ballot(keep[k]);
+    if (l == 0u) sm.cnt[k][w] = (uint32_t)__popcll(m[k]);
   }
   __syncthreads();
-  uint32_t p0 = sm.base[0], p1 = sm.base[1];
-  for (uint32_t k = 0; k < w; ++k) { p0 += sm.cnt[0][k]; p1 += sm.cnt[1][k]; }
+  const uint32_t nw = blockDim.x >> 6;
+  if (threadIdx.x < 3u) {
+    uint32_t total = 0;
+    for (uint32_t j = 0; j < nw; ++j) total += sm.cnt[threadIdx.x][j];
+    sm.base[threadIdx.x] = total ? atomicAdd(counters[threadIdx.x], total) : 0u;
+  } else if (threadIdx.x == 64u) {
+    uint32_t total = 0;
+    for (uint32_t j = 0; j < nw; ++j) total += sm.cnt[1][j] + sm.cnt[2][j];
+    if (total) atomicAdd(shadow_total, (unsigned long long)total);
+  }
+  __syncthreads();
   const unsigned long long below = (1ull << l) - 1ull;
-  *out0 = p0 + (uint32_t)__popcll(m0 & below);
-  *out1 = p1 + (uint32_t)__popcll(m1 & below);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    uint32_t p = sm.base[k];
+    for (uint32_t j = 0; j < w; ++j) p += sm.cnt[k][j];
+    out[k] = p + (uint32_t)__popcll(m[k] & below);
+  }
 }
 
 // Sharded dequeue of ray batches for the persistent kernels (see WorkCounters).  Returns the first ray of a batch of
@@ -108,6 +114,114 @@ RT_DI uint32_t work_next(WorkCounters* wc, WorkCursor& c, uint32_t n, uint32_t* 
   }
 }
 
+// Variable-size dequeue for the refill loop: asks for `want` rays, is granted 1..want of them from one shard.
+RT_DI uint32_t work_take(WorkCounters* wc, WorkCursor& c, uint32_t n, uint32_t want, uint32_t* got) {
+  constexpr uint32_t kAll = (1u << kWorkShards) - 1u;
+  for (;;) {
+    uint32_t v = 0;
+    if (lane_id() == 0u) v = atomicAdd(&wc->c[c.shard * kWorkStride], want);
+    v = (uint32_t)__shfl((int)v, 0);
+    const unsigned long long lo = (unsigned long long)c.shard * c.per + v;
+    const unsigned long long hi = min((unsigned long long)(c.shard + 1u) * c.per, (unsigned long long)n);
+    if (v < c.per && lo < hi) {
+      *got = (uint32_t)min((unsigned long long)want, hi - lo);
+      return (uint32_t)lo;
+    }
+    uint32_t m = 0;
+    if (lane_id() == 0u) {
+      m = __hip_atomic_load(&wc->dry[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!(m & (1u << c.shard))) { atomicOr(&wc->dry[0], 1u << c.shard); m |= 1u << c.shard; }
+    }
+    m = (uint32_t)__shfl((int)m, 0);
+    if ((m & kAll) == kAll) { *got = 0; return kAbsent; }
+    const uint32_t avail = ~m & kAll;
+    const uint32_t rot = (c.shard + 1u) & (kWorkShards - 1u);
+    const uint32_t r = ((avail >> rot) | (avail << (kWorkShards - rot))) & kAll;
+    c.shard = (rot + (uint32_t)__ffs((int)r) - 1u) & (kWorkShards - 1u);
+  }
+}
+
+// The persistent wavefront loop: every lane owns at most one ray in flight; whenever `refill` or more lanes are idle
+// (and the queue is not dry) the wave dequeues exactly that many rays and hands them to its idle lanes by ballot rank
+// — consecutive queue entries go to consecutive idle lanes, so refill loads stay as coalesced as the holes allow.
+// Source: load(i, &o, &d, &tmin, &tmax) fetches queue entry i; done(i, trav, found) consumes the result.
+template <bool ANY, bool COUNT, class Source>
+RT_DI void persistent_trace(const SceneView& sv, const TraverseLds& lds, uint32_t* spill, WorkCounters* work, uint32_t n, uint32_t refill,
+                            Source& src, uint32_t& cn, uint32_t& ct) {
+  WorkCursor cur = work_begin(n);
+  bool more = n > 0u;  // wave-uniform: some shard may still hold rays
+  bool has = false;
+  uint32_t idx = 0;
+  Trav t;
+  typename Source::Payload pay;
+  for (;;) {
+    const unsigned long long idle = __ballot(!has);
+    if (more && idle) {
+      uint32_t got = 0;
+      const uint32_t base = work_take(work, cur, n, (uint32_t)__popcll(idle), &got);
+      if (base == kAbsent) more = false;
+      else if (!has) {
+        const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane_id()) - 1ull));
+        if (rank < got) {
+          idx = base + rank;
+          f3 o, d; float tmin, tmax;
+          src.load(idx, &o, &d, &tmin, &tmax, &pay);
+          trav_begin(t, make_ray(o, d, tmin), tmax);
+          has = true;
+        }
+      }
+    }
+    if (__ballot(has) == 0ull) { if (!more) break; continue; }
+    for (;;) {
+      if (has) {
+        if (trav_step<ANY, COUNT>(sv, lds, spill, t, cn, ct)) { src.done(idx, t, pay); has = false; }
+      }
+      const uint32_t nidle = (uint32_t)__popcll(__ballot(!has));
+      if (nidle == 64u || (more && nidle >= refill)) break;
+    }
+  }
+}
+
+struct BatchSource {
+  struct Payload {};
+  const hala_ray* rays;
+  hala_hit* hits;
+  bool any;
+  RT_DI void load(uint32_t i, f3* o, f3* d, float* tmin, float* tmax, Payload*) const {
+    const float4* rp = reinterpret_cast<const float4*>(rays + i);
+    const float4 ro = rp[0], rd = rp[1];
+    *o = mk3(ro.x, ro.y, ro.z); *d = mk3(rd.x, rd.y, rd.z); *tmin = ro.w; *tmax = rd.w;
+  }
+  RT_DI void done(uint32_t i, const Trav& t, const Payload&) const {
+    const bool found = t.best.prim != kAbsent;
+    float4 out;
+    if (any) out = make_float4(found ? 1.0f : -1.0f, 0.0f, 0.0f, __uint_as_float(kAbsent));
+    else out = found ? make_float4(t.best.t, t.best.u, t.best.v, __uint_as_float(t.best.prim)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(kAbsent));
+    reinterpret_cast<float4*>(hits)[i] = out;
+  }
+};
+struct ShadowSource {
+  struct Payload { float4 cs; };  // contribution.xyz | pixel slot, fetched with the ray (one coalesced 48-B record)
+  const ShadowEntry* entries;
+  float4* radiance_rng;
+  RT_DI void load(uint32_t i, f3* o, f3* d, float* tmin, float* tmax, Payload* p) const {
+    const float4* e = reinterpret_cast<const float4*>(entries + i);
+    const float4 ro = e[0], rd = e[1];
+    p->cs = e[2];
+    *o = mk3(ro.x, ro.y, ro.z); *d = mk3(rd.x, rd.y, rd.z); *tmin = ro.w; *tmax = rd.w;
+  }
+  // A path owns at most one connection per queue and the two queues are traced by separate launches, so each radiance
+  // word receives at most ONE add per launch: a fire-and-forget float atomic is then exactly `L = L + c` (one IEEE add,
+  // no ordering freedom) and the lane does not stall on a read-modify-write round trip.
+  RT_DI void done(uint32_t, const Trav& t, const Payload& p) const {
+    if (t.best.prim != kAbsent) return;  // occluded
+    float* l = reinterpret_cast<float*>(radiance_rng + __float_as_uint(p.cs.w));
+    atomicAdd(l + 0, p.cs.x);
+    atomicAdd(l + 1, p.cs.y);
+    atomicAdd(l + 2, p.cs.z);
+  }
+};
+
 extern __shared__ __attribute__((aligned(16))) unsigned char g_smem[];
 
 // ---------------------------------------------------------------------------------------------------------
@@ -116,7 +230,8 @@ extern __shared__ __attribute__((aligned(16))) unsigned char g_smem[];
 template <bool ANY, bool COUNT>
 __global__ void __launch_bounds__(kTraverseThreads)
 k_trace_batch(SceneView sv, const hala_ray* __restrict__ rays, hala_hit* __restrict__ hits, const uint32_t* __restrict__ n_ptr,
-              uint32_t n_imm, WorkCounters* __restrict__ work, uint32_t* __restrict__ spill_base, Control* __restrict__ ctl, int account) {
+              uint32_t n_imm, WorkCounters* __restrict__ work, uint32_t* __restrict__ spill_base, Control* __restrict__ ctl, int account,
+              uint32_t refill) {
   const TraverseLds lds = stage_bvh(sv, g_smem);
   const uint32_t n = n_ptr ? *n_ptr : n_imm;
   uint32_t* spill = spill_base ? spill_base + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * kStackSpill : nullptr;
@@ -124,23 +239,8 @@ k_trace_batch(SceneView sv, const hala_ray* __restrict__ rays, hala_hit* __restr
   if (account && blockIdx.x == 0 && threadIdx.x == 0) {
     if (ANY) ctl->rays_shadow += n; else ctl->rays_closest += n;
   }
-  WorkCursor cur = work_begin(n);
-  for (;;) {
-    uint32_t end = 0;
-    const uint32_t first = work_next(work, cur, n, &end);
-    if (first == kAbsent) break;
-    for (uint32_t i = first + lane_id(); i < end; i += 64u) {
-      const float4* rp = reinterpret_cast<const float4*>(rays + i);
-      const float4 ro = rp[0], rd = rp[1];
-      const RayPre r = make_ray(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w);
-      HitRec h;
-      const bool found = traverse<ANY, COUNT>(sv, lds, spill, r, rd.w, h, cn, ct);
-      float4 out;
-      if (ANY) out = make_float4(found ? 1.0f : -1.0f, 0.0f, 0.0f, __uint_as_float(kAbsent));
-      else out = found ? make_float4(h.t, h.u, h.v, __uint_as_float(h.prim)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(kAbsent));
-      reinterpret_cast<float4*>(hits)[i] = out;
-    }
-  }
+  BatchSource src{rays, hits, ANY};
+  persistent_trace<ANY, COUNT>(sv, lds, spill, work, n, refill, src, cn, ct);
   if (COUNT) {
     cn = wave_sum(cn); ct = wave_sum(ct);
     if (lane_id() == 0u) { atomicAdd(&ctl->steps[ANY ? 1 : 0][0], (unsigned long long)cn); atomicAdd(&ctl->steps[ANY ? 1 : 0][1], (unsigned long long)ct); }
@@ -153,36 +253,14 @@ k_trace_batch(SceneView sv, const hala_ray* __restrict__ rays, hala_hit* __restr
 // ---------------------------------------------------------------------------------------------------------
 template <bool COUNT>
 __global__ void __launch_bounds__(kTraverseThreads)
-k_trace_shadow(SceneView sv, Queues q, PathState ps, Control* __restrict__ ctl, uint32_t depth, uint32_t* __restrict__ spill_base) {
+k_trace_shadow(SceneView sv, Queues q, PathState ps, Control* __restrict__ ctl, uint32_t depth, uint32_t kind, uint32_t* __restrict__ spill_base,
+               uint32_t refill) {
   const TraverseLds lds = stage_bvh(sv, g_smem);
-  const uint32_t n = ctl->n_shadow[depth];
+  const uint32_t n = ctl->n_shadow[kind][depth];
   uint32_t* spill = spill_base ? spill_base + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * kStackSpill : nullptr;
   uint32_t cn = 0, ct = 0;
-  WorkCursor cur = work_begin(n);
-  for (;;) {
-    uint32_t end = 0;
-    const uint32_t first = work_next(&ctl->work_shadow, cur, n, &end);
-    if (first == kAbsent) break;
-    for (uint32_t i = first + lane_id(); i < end; i += 64u) {
-      const uint32_t qi = q.shadow_list[i];
-#pragma unroll 1
-      for (int k = 0; k < 2; ++k) {
-        const float4* e = reinterpret_cast<const float4*>(q.shadow + 2 * (size_t)qi + k);
-        const float4 ro = e[0], rd = e[1];
-        if (!(rd.w >= 0.0f)) continue;  // unused connection
-        const float4 cs = e[2];
-        const RayPre r = make_ray(mk3(ro.x, ro.y, ro.z), mk3(rd.x, rd.y, rd.z), ro.w);
-        HitRec h;
-        const bool occluded = traverse<true, COUNT>(sv, lds, spill, r, rd.w, h, cn, ct);
-        if (!occluded) {
-          const uint32_t slot = __float_as_uint(cs.w);
-          float4 lr = ps.radiance_rng[slot];
-          lr.x = lr.x + cs.x; lr.y = lr.y + cs.y; lr.z = lr.z + cs.z;
-          ps.radiance_rng[slot] = lr;
-        }
-      }
-    }
-  }
+  ShadowSource src{q.shadow[kind], ps.radiance_rng};
+  persistent_trace<true, COUNT>(sv, lds, spill, &ctl->work_shadow[kind], n, refill, src, cn, ct);
   if (COUNT) {
     cn = wave_sum(cn); ct = wave_sum(ct);
     if (lane_id() == 0u) { atomicAdd(&ctl->steps[1][0], (unsigned long long)cn); atomicAdd(&ctl->steps[1][1], (unsigned long long)ct); }
@@ -235,15 +313,16 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(FrameConst fc, SceneVie
   // have not started: re-arm their work counters here
   if (blockIdx.x == 0u && threadIdx.x < kWorkShards) {
     ctl->work_closest.c[threadIdx.x * kWorkStride] = 0u;
-    ctl->work_shadow.c[threadIdx.x * kWorkStride] = 0u;
-    if (threadIdx.x == 0u) { ctl->work_closest.dry[0] = 0u; ctl->work_shadow.dry[0] = 0u; }
+    ctl->work_shadow[0].c[threadIdx.x * kWorkStride] = 0u;
+    ctl->work_shadow[1].c[threadIdx.x * kWorkStride] = 0u;
+    if (threadIdx.x == 0u) { ctl->work_closest.dry[0] = 0u; ctl->work_shadow[0].dry[0] = 0u; ctl->work_shadow[1].dry[0] = 0u; }
   }
   if (blockIdx.x * blockDim.x >= n) return;  // whole workgroup beyond the queue (uniform exit: barriers below)
   const bool active = i < n;
   const uint32_t in = depth & 1u, out = in ^ 1u;
-  bool alive = false, has_shadow = false;
-  uint32_t n_shadow_rays = 0;
+  bool keep[3] = {false, false, false};  // path survives, light connection, environment connection
   f3 no = splat3(0.0f), nd = splat3(0.0f);
+  float4 conn[2][3];  // the two NEE connections of this path, written to the compact queues after the block scan
   uint32_t slot = 0;
   if (active) {
     slot = q.slots[in][i];
@@ -259,10 +338,6 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(FrameConst fc, SceneVie
     const uint32_t hit_prim = __float_as_uint(hv.w);
     const uint32_t nl = fc.u.num_of_lights;
     const float t_surf = hit_prim != kAbsent ? hv.x : kTMax;
-    // unused connections by default
-    float4* se = reinterpret_cast<float4*>(q.shadow + 2 * (size_t)i);
-    se[1].w = -1.0f;
-    se[4 + 1].w = -1.0f;
 
     int hit_light = -1;
     float t_light = t_surf, light_pdf = 0.0f;
@@ -315,10 +390,10 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(FrameConst fc, SceneVie
               contrib = fb * ls.le * (cosl * w / pl);
             }
             const f3 tc = T * contrib;
-            se[0] = make_float4(so.x, so.y, so.z, 0.0f);
-            se[1] = make_float4(ls.wi.x, ls.wi.y, ls.wi.z, tmax);
-            se[2] = make_float4(tc.x, tc.y, tc.z, __uint_as_float(slot));
-            has_shadow = true; n_shadow_rays++;
+            conn[0][0] = make_float4(so.x, so.y, so.z, 0.0f);
+            conn[0][1] = make_float4(ls.wi.x, ls.wi.y, ls.wi.z, tmax);
+            conn[0][2] = make_float4(tc.x, tc.y, tc.z, __uint_as_float(slot));
+            keep[1] = true;
           }
         }
       }
@@ -335,10 +410,10 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(FrameConst fc, SceneVie
             const float w = power_heuristic(pdf_e, pdf_b);
             const f3 col = env_map_eval(fc, sv, wi);
             const f3 tc = T * (fb * col * (cosl * w / pdf_e));
-            se[4 + 0] = make_float4(so.x, so.y, so.z, 0.0f);
-            se[4 + 1] = make_float4(wi.x, wi.y, wi.z, kTMax);
-            se[4 + 2] = make_float4(tc.x, tc.y, tc.z, __uint_as_float(slot));
-            has_shadow = true; n_shadow_rays++;
+            conn[1][0] = make_float4(so.x, so.y, so.z, 0.0f);
+            conn[1][1] = make_float4(wi.x, wi.y, wi.z, kTMax);
+            conn[1][2] = make_float4(tc.x, tc.y, tc.z, __uint_as_float(slot));
+            keep[2] = true;
           }
         }
       }
@@ -348,13 +423,14 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(FrameConst fc, SceneVie
       if (bsdf_sample(sf.mat, wo, sf.ns, r1, r2, r3, &wi, &fb, &pdf_b)) {
         T = T * fb * (fabsf(dot3(sf.ns, wi)) / pdf_b);
         prev_pdf = pdf_b;
-        alive = true;
+        bool alive = true;
         if (depth >= fc.u.rr_depth) {
           const float qq = minf(max3f(T), 0.95f);
           const float rr = rng_next(rng);
           if (!(rr < qq)) alive = false; else T = T * (1.0f / qq);
         }
         if (depth + 1u >= fc.u.max_depth) alive = false;
+        keep[0] = alive;
         if (alive) {
           const float side = dot3(wi, sf.ng) >= 0.0f ? sv.ray_eps : -sv.ray_eps;
           no = madd3(sf.ng, side, sf.P);
@@ -365,16 +441,23 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(FrameConst fc, SceneVie
     }
     ps.radiance_rng[slot] = make_float4(L.x, L.y, L.z, __uint_as_float(rng));
   }
-  // ballot compaction of the surviving paths and of the paths that own shadow rays
-  uint32_t qo = 0, so = 0;
-  block_compact2(s_compact, alive, has_shadow, &ctl->n_active[depth + 1u], &ctl->n_shadow[depth], n_shadow_rays, &ctl->rays_shadow, &qo, &so);
-  if (alive) {
-    float4* rp = reinterpret_cast<float4*>(q.rays[out] + qo);
+  // ballot compaction (block level) of the surviving paths and of the two kinds of NEE connections
+  uint32_t pos[3];
+  uint32_t* const counters[3] = {&ctl->n_active[depth + 1u], &ctl->n_shadow[0][depth], &ctl->n_shadow[1][depth]};
+  block_compact3(s_compact, keep, counters, &ctl->rays_shadow, pos);
+  if (keep[0]) {
+    float4* rp = reinterpret_cast<float4*>(q.rays[out] + pos[0]);
     rp[0] = make_float4(no.x, no.y, no.z, 0.0f);
     rp[1] = make_float4(nd.x, nd.y, nd.z, kTMax);
-    q.slots[out][qo] = slot;
+    q.slots[out][pos[0]] = slot;
   }
-  if (has_shadow) q.shadow_list[so] = i;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    if (keep[1 + k]) {
+      float4* e = reinterpret_cast<float4*>(q.shadow[k] + pos[1 + k]);
+      e[0] = conn[k][0]; e[1] = conn[k][1]; e[2] = conn[k][2];
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -431,20 +514,20 @@ void launch_trace_batch(const LaunchCfg& lc, const SceneView& sv, const hala_ray
   dim3 grid(lc.persistent_blocks), block(kTraverseThreads);
   const int acc = account ? 1 : 0;
   if (any) {
-    if (count) hipLaunchKernelGGL((k_trace_batch<true, true>), grid, block, smem, s, sv, rays, hits, n_ptr, n_imm, work, lc.spill, ctl, acc);
-    else hipLaunchKernelGGL((k_trace_batch<true, false>), grid, block, smem, s, sv, rays, hits, n_ptr, n_imm, work, lc.spill, ctl, acc);
+    if (count) hipLaunchKernelGGL((k_trace_batch<true, true>), grid, block, smem, s, sv, rays, hits, n_ptr, n_imm, work, lc.spill, ctl, acc, lc.refill);
+    else hipLaunchKernelGGL((k_trace_batch<true, false>), grid, block, smem, s, sv, rays, hits, n_ptr, n_imm, work, lc.spill, ctl, acc, lc.refill);
   } else {
-    if (count) hipLaunchKernelGGL((k_trace_batch<false, true>), grid, block, smem, s, sv, rays, hits, n_ptr, n_imm, work, lc.spill, ctl, acc);
-    else hipLaunchKernelGGL((k_trace_batch<false, false>), grid, block, smem, s, sv, rays, hits, n_ptr, n_imm, work, lc.spill, ctl, acc);
+    if (count) hipLaunchKernelGGL((k_trace_batch<false, true>), grid, block, smem, s, sv, rays, hits, n_ptr, n_imm, work, lc.spill, ctl, acc, lc.refill);
+    else hipLaunchKernelGGL((k_trace_batch<false, false>), grid, block, smem, s, sv, rays, hits, n_ptr, n_imm, work, lc.spill, ctl, acc, lc.refill);
   }
 }
 
 void launch_trace_shadow(const LaunchCfg& lc, const SceneView& sv, const Queues& q, const PathState& ps, Control* ctl, uint32_t depth,
-                         bool count, hipStream_t s) {
+                         uint32_t kind, bool count, hipStream_t s) {
   const size_t smem = (size_t)sv.lds_nodes * 64 + (size_t)sv.lds_tris * 48 + (size_t)kStackLds * kTraverseThreads * 4;
   dim3 grid(lc.persistent_blocks), block(kTraverseThreads);
-  if (count) hipLaunchKernelGGL((k_trace_shadow<true>), grid, block, smem, s, sv, q, ps, ctl, depth, lc.spill);
-  else hipLaunchKernelGGL((k_trace_shadow<false>), grid, block, smem, s, sv, q, ps, ctl, depth, lc.spill);
+  if (count) hipLaunchKernelGGL((k_trace_shadow<true>), grid, block, smem, s, sv, q, ps, ctl, depth, kind, lc.spill, lc.refill);
+  else hipLaunchKernelGGL((k_trace_shadow<false>), grid, block, smem, s, sv, q, ps, ctl, depth, kind, lc.spill, lc.refill);
 }
 
 void launch_raygen(const FrameConst& fc, const SceneView& sv, const Queues& q, const PathState& ps, Control* ctl, hipStream_t s) {

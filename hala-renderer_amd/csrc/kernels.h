@@ -11,6 +11,7 @@ namespace rt {
 struct LaunchCfg {
   uint32_t persistent_blocks;  // grid of the persistent traversal kernels
   uint32_t* spill;             // global stack spill area or nullptr (tree depth <= kStackLds)
+  uint32_t refill;             // a wave refills its idle lanes once this many are idle (64 = whole-wave batches)
 };
 
 // integrator.hip
@@ -21,7 +22,7 @@ uint32_t traverse_blocks_per_cu(size_t dynamic_lds_bytes);  // resident workgrou
 void launch_trace_batch(const LaunchCfg& lc, const SceneView& sv, const hala_ray* rays, hala_hit* hits, const uint32_t* n_ptr,
                         uint32_t n_imm, WorkCounters* work, Control* ctl, bool any, bool count, bool account, hipStream_t s);
 void launch_trace_shadow(const LaunchCfg& lc, const SceneView& sv, const Queues& q, const PathState& ps, Control* ctl, uint32_t depth,
-                         bool count, hipStream_t s);
+                         uint32_t kind /* 0 light, 1 environment */, bool count, hipStream_t s);
 void launch_raygen(const FrameConst& fc, const SceneView& sv, const Queues& q, const PathState& ps, Control* ctl, hipStream_t s);
 void launch_shade(const FrameConst& fc, const SceneView& sv, const Queues& q, const PathState& ps, Control* ctl, uint32_t depth, hipStream_t s);
 void launch_resolve(const FrameConst& fc, const PathState& ps, float4* accum, float4* albedo, float4* normal, float4* final_img, hipStream_t s);

@@ -26,6 +26,7 @@ namespace {
 constexpr uint32_t kLeafMax = 4;
 constexpr size_t kLdsStageBudget = 40 * 1024;  // a BVH up to this size is staged whole in LDS (next to the 24-KB stack)
 constexpr size_t kLdsPartialStage = 2 * 1024;  // larger BVHs: bytes of top-of-tree nodes staged per workgroup
+constexpr uint32_t kRefillThreshold = 32;      // idle lanes that trigger a refill of the wave (persistent_trace)
 constexpr int kStatRing = 16;
 
 // ---- RENDER_SPEC §2.2 on the host (for tan(yfov/2); same polynomials as rt_math.h) ---------------------------
@@ -138,9 +139,9 @@ struct hala_rt_renderer {
   bool full_valid[4] = {false, false, false, false};
   DeviceArray<float4> ps_tp, ps_lr, ps_alb, ps_nrm;
   DeviceArray<hala_ray> q_rays[2];
-  DeviceArray<uint32_t> q_slots[2], q_shadow_list;
+  DeviceArray<uint32_t> q_slots[2];
   DeviceArray<hala_hit> q_hits;
-  DeviceArray<ShadowEntry> q_shadow;
+  DeviceArray<ShadowEntry> q_shadow[2];
   DeviceArray<Control> d_ctl;
   DeviceArray<WorkCounters> d_batch_work;
 
@@ -180,7 +181,7 @@ struct hala_rt_renderer {
   Queues queues() const {
     Queues q{};
     q.rays[0] = q_rays[0].ptr; q.rays[1] = q_rays[1].ptr; q.slots[0] = q_slots[0].ptr; q.slots[1] = q_slots[1].ptr;
-    q.hits = q_hits.ptr; q.shadow = q_shadow.ptr; q.shadow_list = q_shadow_list.ptr;
+    q.hits = q_hits.ptr; q.shadow[0] = q_shadow[0].ptr; q.shadow[1] = q_shadow[1].ptr;
     return q;
   }
   PathState path_state() const { return PathState{ps_tp.ptr, ps_lr.ptr, ps_alb.ptr, ps_nrm.ptr}; }
@@ -269,7 +270,7 @@ int alloc_frame_buffers(hala_rt_renderer* r) {
   for (auto& i : r->img_local) { RT_HIP(i.resize(n)); RT_HIP(hipMemsetAsync(i.ptr, 0, n * sizeof(float4), r->stream)); }
   RT_HIP(r->ps_tp.resize(n)); RT_HIP(r->ps_lr.resize(n)); RT_HIP(r->ps_alb.resize(n)); RT_HIP(r->ps_nrm.resize(n));
   RT_HIP(r->q_rays[0].resize(n)); RT_HIP(r->q_rays[1].resize(n)); RT_HIP(r->q_slots[0].resize(n)); RT_HIP(r->q_slots[1].resize(n));
-  RT_HIP(r->q_hits.resize(n)); RT_HIP(r->q_shadow.resize(2 * n)); RT_HIP(r->q_shadow_list.resize(n));
+  RT_HIP(r->q_hits.resize(n)); RT_HIP(r->q_shadow[0].resize(n)); RT_HIP(r->q_shadow[1].resize(n));
   RT_HIP(r->d_ctl.resize(1));
   RT_HIP(hipMemsetAsync(r->d_ctl.ptr, 0, sizeof(Control), r->stream));
   RT_HIP(r->d_batch_work.resize(1));
@@ -321,6 +322,10 @@ int configure_traversal(hala_rt_renderer* r) {
   per_cu = std::min(per_cu, 8u);
   r->lcfg.persistent_blocks = r->cu_count * per_cu;
   r->lcfg.spill = nullptr;
+  // measured (profiles/r01_c_refill_sweep.txt): whole-wave refills are best when the BVH lives in LDS (uniform, cheap rays);
+  // refilling once half the wave is idle is best when node fetches go to L2 / Infinity Cache
+  r->lcfg.refill = (r->lds_nodes == r->bvh.node_count) ? 64u : kRefillThreshold;
+  if (const char* e = getenv("HALART_REFILL")) r->lcfg.refill = std::min(64u, std::max(1u, (uint32_t)strtoul(e, nullptr, 10)));  // tuning knob
   if (r->bvh.max_depth > traverse_stack_lds_levels()) {
     if (r->bvh.max_depth > traverse_stack_lds_levels() + traverse_stack_spill_levels())
       RT_FAIL("The BVH is deeper than the traversal stack supports (" + std::to_string(r->bvh.max_depth) + " levels).");
@@ -565,7 +570,9 @@ int hala_rt_update(hala_rt_renderer* r, double, uint32_t, uint32_t) {
     launch_shade(fc, sv, q, ps, ctl, depth, s);
     hipEvent_t c = r->next_event(te), d = r->next_event(te);
     RT_HIP(hipEventRecord(c, s));
-    launch_trace_shadow(r->lcfg, sv, q, ps, ctl, depth, r->counting, s);
+    // light connections first, environment connections second: contributions land in spec order (RENDER_SPEC §6)
+    if (u.num_of_lights > 0) launch_trace_shadow(r->lcfg, sv, q, ps, ctl, depth, 0, r->counting, s);
+    if (u.env_type == 1u) launch_trace_shadow(r->lcfg, sv, q, ps, ctl, depth, 1, r->counting, s);
     RT_HIP(hipEventRecord(d, s));
   }
   launch_resolve(fc, ps, r->img_local[0].ptr, r->img_local[1].ptr, r->img_local[2].ptr, r->img_local[3].ptr, s);

@@ -80,17 +80,33 @@ struct HitRec {
   uint32_t prim;
 };
 
-// §4.4 traversal.  Returns true if something was hit (ANY: first hit inside (tmin,tmax) ends the walk).
+// §4.4 traversal as a re-entrant state machine: one lane = one ray in flight; trav_step performs ONE node visit
+// (both child box tests, leaf triangles, push/pop).  The persistent kernels interleave steps of all lanes and refill
+// finished lanes with new rays, so a wave is not held hostage by its longest ray (wave64 divergence).
+struct Trav {
+  RayPre r;
+  float tmax;
+  HitRec best;
+  uint32_t cur;
+  int sp;
+};
+RT_DI void trav_begin(Trav& t, const RayPre& r, float tmax) {
+  t.r = r; t.tmax = tmax;
+  t.best.t = tmax; t.best.u = 0.0f; t.best.v = 0.0f; t.best.prim = kAbsent;
+  t.cur = 0; t.sp = 0;
+}
+// returns true when the ray is finished (ANY: also on the first hit inside (tmin, tmax))
 template <bool ANY, bool COUNT>
-RT_DI bool traverse(const SceneView& sv, const TraverseLds& lds, uint32_t* spill, const RayPre& r, float tmax, HitRec& best,
-                    uint32_t& n_nodes, uint32_t& n_tris) {
-  best.t = tmax; best.u = 0.0f; best.v = 0.0f; best.prim = kAbsent;
+RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint32_t* spill, Trav& t, uint32_t& n_nodes, uint32_t& n_tris) {
   const float4* gnodes = reinterpret_cast<const float4*>(sv.nodes);
   const float4* gtris = reinterpret_cast<const float4*>(sv.tris);
   uint32_t* stack = lds.stack + threadIdx.x;
-  int sp = 0;
-  uint32_t cur = 0;
-  for (;;) {
+  const RayPre& r = t.r;
+  HitRec& best = t.best;
+  const float tmax = t.tmax;
+  const uint32_t cur = t.cur;
+  int sp = t.sp;
+  {
     float4 q0, q1, q2, q3;
     if (cur < sv.lds_nodes) {
       const float4* p = lds.nodes + (size_t)cur * 4;
@@ -140,12 +156,24 @@ RT_DI bool traverse(const SceneView& sv, const TraverseLds& lds, uint32_t* spill
       }
     }
     if (next == kAbsent) {
-      if (sp == 0) break;
+      if (sp == 0) return true;
       --sp;
       next = sp < kStackLds ? stack[sp * kTraverseThreads] : spill[sp - kStackLds];
     }
-    cur = next;
+    t.cur = next;
+    t.sp = sp;
   }
+  return false;
+}
+
+// whole-ray form (one lane runs its ray to completion)
+template <bool ANY, bool COUNT>
+RT_DI bool traverse(const SceneView& sv, const TraverseLds& lds, uint32_t* spill, const RayPre& r, float tmax, HitRec& best,
+                    uint32_t& n_nodes, uint32_t& n_tris) {
+  Trav t;
+  trav_begin(t, r, tmax);
+  while (!trav_step<ANY, COUNT>(sv, lds, spill, t, n_nodes, n_tris)) {}
+  best = t.best;
   return best.prim != kAbsent;
 }
 
