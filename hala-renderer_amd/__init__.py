@@ -13,7 +13,7 @@ from .scene import (HalaScene, HalaNode, HalaMesh, HalaPrimitive, HalaMaterial, 
                     HalaMaterialType, HalaMediumType)
 
 _PKG_DIR = _os.path.dirname(_os.path.abspath(__file__))
-LIB_PATH = _os.path.join(_PKG_DIR, "lib", "libhalart.so")
+LIB_PATH = _os.environ.get("HALART_LIB") or _os.path.join(_PKG_DIR, "lib", "libhalart.so")  # HALART_LIB: tuning builds
 _lib = None
 
 

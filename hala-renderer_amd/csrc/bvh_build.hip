@@ -97,11 +97,12 @@ RT_DI unsigned long long spread21(uint32_t v) {  // 21 bits -> every third bit
   return x;
 }
 __global__ void __launch_bounds__(256) k_morton(const Box6* __restrict__ tri_box, uint32_t n, const uint32_t* __restrict__ scene_ord,
-                                                 unsigned long long* __restrict__ keys, uint32_t* __restrict__ ids) {
+                                                 unsigned long long* __restrict__ keys, uint32_t* __restrict__ ids, uint32_t size_classes) {
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n) return;
   const Box6 b = tri_box[g];
   uint32_t q[3];
+  float scene_d2 = 0.0f, tri_d2 = 0.0f;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     const float lo = ord2f(scene_ord[k]), hi = ord2f(scene_ord[3 + k]);
@@ -109,9 +110,18 @@ __global__ void __launch_bounds__(256) k_morton(const Box6* __restrict__ tri_box
     const float ext = hi - lo;
     float t = ext > 0.0f ? (c - lo) / ext : 0.0f;
     t = fminf(fmaxf(t, 0.0f), 1.0f);
-    q[k] = min((uint32_t)(t * 2097152.0f), 2097151u);
+    q[k] = min((uint32_t)(t * 1048576.0f), 1048575u);  // 20 bits per axis
+    scene_d2 += ext * ext;
+    tri_d2 += (b.mx[k] - b.mn[k]) * (b.mx[k] - b.mn[k]);
   }
-  keys[g] = (spread21(q[0]) << 2) | (spread21(q[1]) << 1) | spread21(q[2]);
+  // Size class in the two top key bits: LBVH sorts by centroid only, so one huge triangle (a ground quad, a wall) would
+  // inflate the boxes of every ancestor it shares with small neighbours.  With the class on top of the key the Karras
+  // hierarchy splits by class first: big triangles form their own shallow subtrees next to the well-formed rest.
+  // class 0: box diagonal > 1/8 of the scene's, 1: > 1/32, 2: > 1/128, 3: the rest.
+  const float ratio2 = scene_d2 > 0.0f ? tri_d2 / scene_d2 : 0.0f;
+  uint32_t cls = ratio2 > (1.0f / 64.0f) ? 0u : (ratio2 > (1.0f / 1024.0f) ? 1u : (ratio2 > (1.0f / 16384.0f) ? 2u : 3u));
+  if (!size_classes) cls = 0u;
+  keys[g] = ((unsigned long long)cls << 60) | (spread21(q[0]) << 2) | (spread21(q[1]) << 1) | spread21(q[2]);
   ids[g] = g;
 }
 
@@ -336,8 +346,10 @@ std::string bvh_build(BvhBuffers& b, uint32_t leaf_max, hipStream_t s) {
     if (!(e = keys_in.alloc((size_t)n * 8)).empty()) return e;
     if (!(e = keys_out.alloc((size_t)n * 8)).empty()) return e;
     if (!(e = ids_in.alloc((size_t)n * 4)).empty()) return e;
+    uint32_t size_classes = 1;
+    if (const char* ev = getenv("HALART_SIZE_CLASSES")) size_classes = (uint32_t)atoi(ev);  // tuning knob
     hipLaunchKernelGGL(k_morton, dim3(nblk(n)), dim3(256), 0, s, t.tri_box.as<Box6>(), n, t.scene_ord.as<uint32_t>(),
-                       keys_in.as<unsigned long long>(), ids_in.as<uint32_t>());
+                       keys_in.as<unsigned long long>(), ids_in.as<uint32_t>(), size_classes);
     size_t tmp_bytes = 0;
     HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in.as<unsigned long long>(), keys_out.as<unsigned long long>(),
                                       ids_in.as<uint32_t>(), t.sorted_ids.as<uint32_t>(), n, 0, 64, s));

@@ -228,7 +228,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char g_smem[];
 // K5a: persistent closest-hit traversal over a compact ray queue (coalesced 32-B ray reads, 16-B hit writes)
 // ---------------------------------------------------------------------------------------------------------
 template <bool ANY, bool COUNT>
-__global__ void __launch_bounds__(kTraverseThreads)
+__global__ void __launch_bounds__(kTraverseThreads, kTraverseWavesPerSimd)
 k_trace_batch(SceneView sv, const hala_ray* __restrict__ rays, hala_hit* __restrict__ hits, const uint32_t* __restrict__ n_ptr,
               uint32_t n_imm, WorkCounters* __restrict__ work, uint32_t* __restrict__ spill_base, Control* __restrict__ ctl, int account,
               uint32_t refill) {
@@ -252,7 +252,7 @@ k_trace_batch(SceneView sv, const hala_ray* __restrict__ rays, hala_hit* __restr
 // path's radiance in the fixed order light, environment (RENDER_SPEC §6)
 // ---------------------------------------------------------------------------------------------------------
 template <bool COUNT>
-__global__ void __launch_bounds__(kTraverseThreads)
+__global__ void __launch_bounds__(kTraverseThreads, kTraverseWavesPerSimd)
 k_trace_shadow(SceneView sv, Queues q, PathState ps, Control* __restrict__ ctl, uint32_t depth, uint32_t kind, uint32_t* __restrict__ spill_base,
                uint32_t refill) {
   const TraverseLds lds = stage_bvh(sv, g_smem);

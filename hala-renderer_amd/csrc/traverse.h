@@ -15,8 +15,17 @@
 namespace rt {
 
 constexpr int kTraverseThreads = 256;
-constexpr int kStackLds = 24;     // stack levels kept in LDS per lane
-constexpr int kStackSpill = 104;  // deeper levels, global scratch (max supported tree depth = 128)
+// The traversal kernels are latency-bound (72 % of wave cycles wait on memory, profiles/r01_d_pmc_config4.txt); the
+// second launch-bound argument is waves per SIMD and caps the register allocation accordingly.
+#ifndef RT_WAVES_PER_SIMD
+#define RT_WAVES_PER_SIMD 6  // measured best (profiles/r01_e_variant_sweep.txt): 7-8 waves/SIMD force spills that cost more
+#endif
+#ifndef RT_TRI_PAIR
+#define RT_TRI_PAIR 1
+#endif
+constexpr int kTraverseWavesPerSimd = RT_WAVES_PER_SIMD;
+constexpr int kStackLds = 16;     // stack levels kept in LDS per lane (16 KB per workgroup -> 8 workgroups / CU)
+constexpr int kStackSpill = 112;  // deeper levels, global scratch (max supported tree depth = 128)
 
 struct TraverseLds {
   const float4* nodes;  // lds_nodes * 4
@@ -134,18 +143,33 @@ RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint32_t* spil
       if (count > 0u) {
         if (!(tn <= best.t)) continue;
         if (COUNT) n_tris += count;
-        for (uint32_t i = 0; i < count; ++i) {
+        // triangles are tested in storage order (spec), but fetched two at a time so that a leaf costs
+        // ceil(count/2) memory round trips instead of count (the kernel is latency-bound: profiles/r01_d_pmc)
+        for (uint32_t i = 0; i < count; i += (RT_TRI_PAIR ? 2u : 1u)) {
           const uint32_t ti = child + i;
-          float4 a, b, c;
-          if (ti < sv.lds_tris) { const float4* p = lds.tris + (size_t)ti * 3; a = p[0]; b = p[1]; c = p[2]; }
-          else { const float4* p = gtris + (size_t)ti * 3; a = p[0]; b = p[1]; c = p[2]; }
-          float t, u, v;
-          if (!tri_test(r, a, b, c, &t, &u, &v)) continue;
-          const uint32_t id = __float_as_uint(a.w);
-          if (ANY) {
-            if (t > r.tmin && t < tmax) { best.t = t; best.u = u; best.v = v; best.prim = id; return true; }
-          } else if (t > r.tmin && (t < best.t || (t == best.t && id < best.prim))) {
-            best.t = t; best.u = u; best.v = v; best.prim = id;
+          const bool two = RT_TRI_PAIR && (i + 1u < count);
+          float4 a0, b0, c0, a1, b1, c1;
+          if (ti < sv.lds_tris) {
+            const float4* p = lds.tris + (size_t)ti * 3;
+            a0 = p[0]; b0 = p[1]; c0 = p[2];
+            if (two) { a1 = p[3]; b1 = p[4]; c1 = p[5]; }
+          } else {
+            const float4* p = gtris + (size_t)ti * 3;
+            a0 = p[0]; b0 = p[1]; c0 = p[2];
+            if (two) { a1 = p[3]; b1 = p[4]; c1 = p[5]; }
+          }
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            if (j == 1 && !two) break;
+            const float4 a = j ? a1 : a0, b = j ? b1 : b0, c = j ? c1 : c0;
+            float t, u, v;
+            if (!tri_test(r, a, b, c, &t, &u, &v)) continue;
+            const uint32_t id = __float_as_uint(a.w);
+            if (ANY) {
+              if (t > r.tmin && t < tmax) { best.t = t; best.u = u; best.v = v; best.prim = id; return true; }
+            } else if (t > r.tmin && (t < best.t || (t == best.t && id < best.prim))) {
+              best.t = t; best.u = u; best.v = v; best.prim = id;
+            }
           }
         }
       } else if (next == kAbsent) {
