@@ -107,8 +107,7 @@ def main():
     def step():
         # a frame restarts the accumulation: frame_index 0..SPP-1 (same work every step)
         r.reset_accumulation()
-        for _ in range(SPP):
-            r.update(0.0, W, Hh)
+        r.update_batch(SPP)  # == SPP x update(): the SPP samples travel through the wavefront kernels together
         if gather is not None:
             gather.gather()  # one RCCL all-gather per AOV + de-interleave kernel
         r.render()

@@ -73,7 +73,12 @@ struct FrameConst {
   uint32_t width, height;
   // pixel-tile sharding (RENDER_SPEC §9)
   uint32_t tile_size, tiles_x, tiles_y, world, rank, tiles_per_rank, perm_a, perm_b;
-  uint32_t slot_count;  // number of pixel slots this rank renders
+  uint32_t pixel_slots;  // number of pixel slots this rank renders
+  // sample batching: `samples` consecutive frames (frame_index .. frame_index+samples-1) travel through the wavefront
+  // together; path slot = sample * pixel_slots + pixel slot.  The resolve kernel folds them in frame order, so the
+  // result is bit-identical to `samples` single-sample updates.
+  uint32_t samples;
+  uint32_t slot_count;  // pixel_slots * samples
 };
 
 // device control block: queue sizes and work counters of the wavefront loop.  One slot per bounce, so a single

@@ -272,12 +272,13 @@ k_trace_shadow(SceneView sv, Queues q, PathState ps, Control* __restrict__ ctl, 
 // ---------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_raygen(FrameConst fc, SceneView sv, Queues q, PathState ps, Control* __restrict__ ctl) {
   const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t sample = slot / fc.pixel_slots, pslot = slot - sample * fc.pixel_slots;
   uint32_t px = 0, py = 0;
-  const bool valid = slot < fc.slot_count && slot_to_pixel(fc, slot, &px, &py);
+  const bool valid = slot < fc.slot_count && slot_to_pixel(fc, pslot, &px, &py);
   f3 o = splat3(0.0f), d = mk3(0.0f, 0.0f, 1.0f);
   uint32_t rng = 0;
   if (valid) {
-    rng = rng_init(py * fc.width + px, fc.u.frame_index);
+    rng = rng_init(py * fc.width + px, fc.u.frame_index + sample);
     camera_ray(fc, sv.cameras[fc.u.camera_index], px, py, rng, &o, &d);
   }
   if (slot < fc.slot_count) {
@@ -465,20 +466,23 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(FrameConst fc, SceneVie
 // ---------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_resolve(FrameConst fc, PathState ps, float4* __restrict__ accum, float4* __restrict__ albedo,
                                                   float4* __restrict__ normal, float4* __restrict__ final_img) {
-  const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-  if (slot >= fc.slot_count) return;
-  const float4 lr = ps.radiance_rng[slot];
-  f3 L = mk3(lr.x, lr.y, lr.z);
-  if (!(isfinite(L.x) && isfinite(L.y) && isfinite(L.z))) L = splat3(0.0f);
-  const uint32_t fi = fc.u.frame_index;
-  const float4 a0 = accum[slot], b0 = albedo[slot], n0 = normal[slot];
-  const float4 sa = ps.albedo[slot], sn = ps.normal[slot];
-  const float4 a1 = make_float4(fold_mean(a0.x, L.x, fi), fold_mean(a0.y, L.y, fi), fold_mean(a0.z, L.z, fi), 1.0f);
-  accum[slot] = a1;
-  albedo[slot] = make_float4(fold_mean(b0.x, sa.x, fi), fold_mean(b0.y, sa.y, fi), fold_mean(b0.z, sa.z, fi), 1.0f);
-  normal[slot] = make_float4(fold_mean(n0.x, sn.x, fi), fold_mean(n0.y, sn.y, fi), fold_mean(n0.z, sn.z, fi), 1.0f);
-  const f3 c = tonemap_select(mk3(a1.x, a1.y, a1.z) * fc.u.exposure_value, fc.u.enable_tonemap, fc.u.enable_aces, fc.u.use_simple_aces);
-  final_img[slot] = make_float4(c.x, c.y, c.z, 1.0f);
+  const uint32_t pslot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pslot >= fc.pixel_slots) return;
+  float4 a = accum[pslot], b = albedo[pslot], n = normal[pslot];
+  for (uint32_t k = 0; k < fc.samples; ++k) {  // the batch's samples, folded in frame order
+    const uint32_t slot = k * fc.pixel_slots + pslot;
+    const float4 lr = ps.radiance_rng[slot];
+    f3 L = mk3(lr.x, lr.y, lr.z);
+    if (!(isfinite(L.x) && isfinite(L.y) && isfinite(L.z))) L = splat3(0.0f);
+    const uint32_t fi = fc.u.frame_index + k;
+    const float4 sa = ps.albedo[slot], sn = ps.normal[slot];
+    a = make_float4(fold_mean(a.x, L.x, fi), fold_mean(a.y, L.y, fi), fold_mean(a.z, L.z, fi), 1.0f);
+    b = make_float4(fold_mean(b.x, sa.x, fi), fold_mean(b.y, sa.y, fi), fold_mean(b.z, sa.z, fi), 1.0f);
+    n = make_float4(fold_mean(n.x, sn.x, fi), fold_mean(n.y, sn.y, fi), fold_mean(n.z, sn.z, fi), 1.0f);
+  }
+  accum[pslot] = a; albedo[pslot] = b; normal[pslot] = n;
+  const f3 c = tonemap_select(mk3(a.x, a.y, a.z) * fc.u.exposure_value, fc.u.enable_tonemap, fc.u.enable_aces, fc.u.use_simple_aces);
+  final_img[pslot] = make_float4(c.x, c.y, c.z, 1.0f);
 }
 
 // tile-major gathered buffer [world][tiles_per_rank][ts][ts] -> row-major full image (RENDER_SPEC §9)
@@ -537,7 +541,7 @@ void launch_shade(const FrameConst& fc, const SceneView& sv, const Queues& q, co
   hipLaunchKernelGGL(k_shade, dim3(blocks_for(fc.slot_count, kShadeThreads)), dim3(kShadeThreads), 0, s, fc, sv, q, ps, ctl, depth);
 }
 void launch_resolve(const FrameConst& fc, const PathState& ps, float4* accum, float4* albedo, float4* normal, float4* final_img, hipStream_t s) {
-  hipLaunchKernelGGL(k_resolve, dim3(blocks_for(fc.slot_count, 256)), dim3(256), 0, s, fc, ps, accum, albedo, normal, final_img);
+  hipLaunchKernelGGL(k_resolve, dim3(blocks_for(fc.pixel_slots, 256)), dim3(256), 0, s, fc, ps, accum, albedo, normal, final_img);
 }
 void launch_scatter_tiles(const FrameConst& fc, const float4* gathered, float4* full, hipStream_t s) {
   const uint32_t n = fc.tiles_per_rank * fc.tile_size * fc.tile_size * fc.world;

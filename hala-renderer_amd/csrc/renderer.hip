@@ -28,6 +28,7 @@ constexpr size_t kLdsStageBudget = 40 * 1024;  // a BVH up to this size is stage
 constexpr size_t kLdsPartialStage = 2 * 1024;  // larger BVHs: bytes of top-of-tree nodes staged per workgroup
 constexpr uint32_t kRefillThreshold = 32;      // idle lanes that trigger a refill of the wave (persistent_trace)
 constexpr int kStatRing = 16;
+constexpr uint32_t kMaxSampleBatch = 16;  // frames per wavefront pass in hala_rt_update_batch (~250 B of state per path)
 
 // ---- RENDER_SPEC §2.2 on the host (for tan(yfov/2); same polynomials as rt_math.h) ---------------------------
 float h_sin_poly(float a) {
@@ -81,6 +82,7 @@ struct TraceEvents {
   size_t used = 0;
   hipEvent_t frame_begin = nullptr, frame_end = nullptr;
   bool pending = false, counted = false;
+  uint32_t samples = 1;  // frames rendered by this wavefront pass
   unsigned long long* host_counts = nullptr;  // pinned: rays_closest, rays_shadow, steps[2][2]
 };
 
@@ -132,7 +134,8 @@ struct hala_rt_renderer {
 
   // tile shard (RENDER_SPEC §9)
   uint32_t rank = 0, world = 1, tile_size = 32, tiles_x = 0, tiles_y = 0, tiles_per_rank = 0, perm_a_inv = 0, perm_b = 7;
-  uint32_t slot_count = 0;
+  uint32_t slot_count = 0;      // pixel slots of this rank
+  uint32_t batch_capacity = 1;  // samples the wavefront buffers can hold in flight (hala_rt_update_batch)
 
   DeviceArray<float4> img_local[4];  // accum, albedo, normal, final (slot order)
   DeviceArray<float4> img_full[4];   // row-major, only after scatter_gathered_tiles (world > 1)
@@ -186,7 +189,7 @@ struct hala_rt_renderer {
   }
   PathState path_state() const { return PathState{ps_tp.ptr, ps_lr.ptr, ps_alb.ptr, ps_nrm.ptr}; }
 
-  FrameConst frame_const(const hala_global_uniform& u) const {
+  FrameConst frame_const(const hala_global_uniform& u, uint32_t samples = 1) const {
     FrameConst fc{};
     fc.u = u;
     fc.aspect = u.resolution[0] / u.resolution[1];
@@ -195,7 +198,8 @@ struct hala_rt_renderer {
     fc.tan_half = sn / cs;
     fc.width = width; fc.height = height;
     fc.tile_size = tile_size; fc.tiles_x = tiles_x; fc.tiles_y = tiles_y; fc.world = world; fc.rank = rank;
-    fc.tiles_per_rank = tiles_per_rank; fc.perm_a = perm_a_inv; fc.perm_b = perm_b; fc.slot_count = slot_count;
+    fc.tiles_per_rank = tiles_per_rank; fc.perm_a = perm_a_inv; fc.perm_b = perm_b;
+    fc.pixel_slots = slot_count; fc.samples = samples; fc.slot_count = slot_count * samples;
     return fc;
   }
 
@@ -220,7 +224,7 @@ struct hala_rt_renderer {
     stats.traverse_shadow_ms_total += tr[1];
     stats.traverse_closest_launches += t.used / 4;
     stats.traverse_shadow_launches += t.used / 4;
-    stats.updates_rendered += 1;
+    stats.updates_rendered += t.samples;
     const unsigned long long rc = t.host_counts[0], rs = t.host_counts[1];
     stats.rays_last_update = rc + rs;
     stats.rays_total += rc + rs;
@@ -265,12 +269,21 @@ void compute_tiling(hala_rt_renderer* r) {
   r->slot_count = r->tiles_per_rank * r->tile_size * r->tile_size;
 }
 
-int alloc_frame_buffers(hala_rt_renderer* r) {
-  const size_t n = r->slot_count;
-  for (auto& i : r->img_local) { RT_HIP(i.resize(n)); RT_HIP(hipMemsetAsync(i.ptr, 0, n * sizeof(float4), r->stream)); }
+// wavefront state for `samples` frames in flight (hala_rt_update_batch): everything indexed by path slot
+int alloc_wavefront(hala_rt_renderer* r, uint32_t samples) {
+  const size_t n = (size_t)r->slot_count * samples;
+  if (n > 0xfffffff0ull) RT_FAIL("The sample batch is too large for 32-bit path slots.");
   RT_HIP(r->ps_tp.resize(n)); RT_HIP(r->ps_lr.resize(n)); RT_HIP(r->ps_alb.resize(n)); RT_HIP(r->ps_nrm.resize(n));
   RT_HIP(r->q_rays[0].resize(n)); RT_HIP(r->q_rays[1].resize(n)); RT_HIP(r->q_slots[0].resize(n)); RT_HIP(r->q_slots[1].resize(n));
   RT_HIP(r->q_hits.resize(n)); RT_HIP(r->q_shadow[0].resize(n)); RT_HIP(r->q_shadow[1].resize(n));
+  r->batch_capacity = samples;
+  return HALA_OK;
+}
+
+int alloc_frame_buffers(hala_rt_renderer* r) {
+  const size_t n = r->slot_count;
+  for (auto& i : r->img_local) { RT_HIP(i.resize(n)); RT_HIP(hipMemsetAsync(i.ptr, 0, n * sizeof(float4), r->stream)); }
+  if (alloc_wavefront(r, 1) != HALA_OK) return HALA_ERR;
   RT_HIP(r->d_ctl.resize(1));
   RT_HIP(hipMemsetAsync(r->d_ctl.ptr, 0, sizeof(Control), r->stream));
   RT_HIP(r->d_batch_work.resize(1));
@@ -527,16 +540,25 @@ int hala_rt_commit(hala_rt_renderer* r) {
   return HALA_OK;
 }
 
-int hala_rt_update(hala_rt_renderer* r, double, uint32_t, uint32_t) {
+// `frames` consecutive update()s in one wavefront pass.  Bookkeeping per frame as in the reference: total_frames is
+// incremented first (pre_update, src/renderer.rs:278) and a frame whose number exceeds max_frames is skipped
+// (src/rt_renderer.rs:394-396); the frames that do render share one kernel sequence with `samples` paths per pixel.
+static int update_impl(hala_rt_renderer* r, uint32_t frames) {
   if (ensure_device(r) != HALA_OK) return HALA_ERR;
   if (!r->committed) RT_FAIL("The pipeline is none!");  // src/rt_renderer.rs:443
-  r->total_frames += 1;                                    // pre_update -> inc_total_frames (src/renderer.rs:278)
-  if (r->total_frames > r->max_frames) return HALA_OK;     // :394-396
+  const uint64_t first = r->total_frames;  // frame_index of the first frame of this batch = total_frames - 1 after its increment
+  r->total_frames += frames;
+  if (first >= r->max_frames) return HALA_OK;
+  const uint32_t samples = (uint32_t)std::min<uint64_t>(frames, r->max_frames - first);
+  if (samples > r->batch_capacity) {
+    RT_HIP(hipStreamSynchronize(r->stream));
+    if (alloc_wavefront(r, samples) != HALA_OK) return HALA_ERR;
+  }
   hala_global_uniform u{};                                 // :408-427
   memcpy(u.ground_color, r->ground, 16); memcpy(u.sky_color, r->sky, 16);
   u.resolution[0] = (float)r->width; u.resolution[1] = (float)r->height;
   u.max_depth = r->max_depth; u.rr_depth = r->rr_depth;
-  u.frame_index = (uint32_t)(r->total_frames - 1);
+  u.frame_index = (uint32_t)first;  // == total_frames - 1 for a single-frame update (:414)
   u.camera_index = 0;
   u.env_type = r->has_env ? 1u : 0u;
   u.env_map_width = r->has_env ? r->env_w : 0; u.env_map_height = r->has_env ? r->env_h : 0;
@@ -546,6 +568,7 @@ int hala_rt_update(hala_rt_renderer* r, double, uint32_t, uint32_t) {
   u.enable_tonemap = r->enable_tonemap; u.enable_aces = r->enable_aces; u.use_simple_aces = r->use_simple_aces;
   u.num_of_lights = (uint32_t)r->hs.lights.size();
   r->last_uniform = u;
+  r->last_uniform.frame_index = (uint32_t)(first + samples - 1);  // what the last frame of the batch would have uploaded
 
   TraceEvents& te = r->ring[r->ring_pos];
   r->ring_pos = (r->ring_pos + 1) % kStatRing;
@@ -553,7 +576,8 @@ int hala_rt_update(hala_rt_renderer* r, double, uint32_t, uint32_t) {
   if (!te.frame_begin) { RT_HIP(hipEventCreate(&te.frame_begin)); RT_HIP(hipEventCreate(&te.frame_end)); RT_HIP(hipHostMalloc(reinterpret_cast<void**>(&te.host_counts), 6 * sizeof(unsigned long long), hipHostMallocDefault)); }
   te.used = 0; te.counted = r->counting;
 
-  const FrameConst fc = r->frame_const(u);
+  te.samples = samples;
+  const FrameConst fc = r->frame_const(u, samples);
   const SceneView sv = r->view();
   const Queues q = r->queues();
   const PathState ps = r->path_state();
@@ -581,6 +605,18 @@ int hala_rt_update(hala_rt_renderer* r, double, uint32_t, uint32_t) {
   RT_HIP(hipGetLastError());
   te.pending = true;
   for (bool& v : r->full_valid) v = false;
+  return HALA_OK;
+}
+
+int hala_rt_update(hala_rt_renderer* r, double, uint32_t, uint32_t) { return update_impl(r, 1); }
+
+int hala_rt_update_batch(hala_rt_renderer* r, uint32_t frames) {
+  if (!r) RT_FAIL("The renderer handle is null!");
+  while (frames > 0) {
+    const uint32_t chunk = std::min(frames, kMaxSampleBatch);
+    if (update_impl(r, chunk) != HALA_OK) return HALA_ERR;
+    frames -= chunk;
+  }
   return HALA_OK;
 }
 

@@ -115,6 +115,10 @@ class HalaRenderer:
         """src/rt_renderer.rs:387-471 — one sample per pixel; `ui_fn` is dropped."""
         self._check(self._lib.hala_rt_update(self._h, C.c_double(delta_time), C.c_uint32(width or self.width), C.c_uint32(height or self.height)))
 
+    def update_batch(self, frames: int):
+        """`frames` update()s as one wavefront pass (bit-identical result; fewer, larger launches)"""
+        self._check(self._lib.hala_rt_update_batch(self._h, C.c_uint32(frames)))
+
     def render(self):
         """src/rt_renderer.rs:475-502"""
         self._check(self._lib.hala_rt_render(self._h))

@@ -318,6 +318,11 @@ int hala_rt_commit(hala_rt_renderer* r);
  * `total_frames > max_frames` early-out (:394-396), the HalaGlobalUniform fill (:408-427) and one
  * trace_rays(width, height, 1) (:458-464) == one sample per pixel.  ui_fn is dropped. */
 int hala_rt_update(hala_rt_renderer* r, double delta_time, uint32_t width, uint32_t height);
+/* `frames` consecutive update() calls executed as ONE wavefront pass with `frames` paths per pixel in flight (in
+ * chunks of at most 16).  Result, frame bookkeeping and max_frames behaviour are bit-identical to calling
+ * hala_rt_update `frames` times; what changes is the launch count and the size of each launch (288 GB of HBM hold
+ * the extra path state; the per-launch tail of the longest ray is amortised over `frames` times more rays). */
+int hala_rt_update_batch(hala_rt_renderer* r, uint32_t frames);
 /* render (src/rt_renderer.rs:475-502): no swapchain to present to; flushes the stream. */
 int hala_rt_render(hala_rt_renderer* r);
 /* wait_idle (src/renderer.rs:251-256) */

@@ -33,8 +33,11 @@ def run(name, scene, w, h, spp, env=None, max_depth=5, rr_depth=3, steps=3):
     t3 = time.perf_counter()
     for _ in range(steps):
         r.reset_accumulation()
-        for _ in range(spp):
-            r.update()
+        if os.environ.get("HALART_NO_BATCH"):
+            for _ in range(spp):
+                r.update()
+        else:
+            r.update_batch(spp)
     r.wait_idle()
     dt = time.perf_counter() - t3
     s1 = r.statistics()

@@ -22,8 +22,10 @@ if env is not None:
     r.set_envmap(env, 0.0)
 r.set_scene(s)
 r.commit()
-for _ in range(frames):
-    r.update()
+spp = 16 if cfg == "3" else 4
+for _ in range(frames):  # same launch shape as bench.py: one wavefront pass per frame
+    r.reset_accumulation()
+    r.update_batch(spp)
 r.wait_idle()
 print("rays", r.statistics().rays_total)
 r.close()

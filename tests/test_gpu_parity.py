@@ -406,6 +406,31 @@ def test_max_frames_stops_accumulation(halart):
     r.close()
 
 
+def test_update_batch_equals_single_updates(halart, oracle):
+    """hala_rt_update_batch(n) == n x update(): same images bit for bit, same ray counts, same frame bookkeeping,
+    including a batch that straddles max_frames and a batch larger than one chunk (16)"""
+    env = scenes.sky_sun_envmap(64, 32)
+    s = scenes.bunny_class(subdivisions=2, aspect=72 / 40, disney=True)
+    a = make_renderer(halart, s, 72, 40, max_depth=4, rr_depth=2, env=env, max_frames=21)
+    b = make_renderer(halart, s, 72, 40, max_depth=4, rr_depth=2, env=env, max_frames=21)
+    for _ in range(25):
+        a.update()
+    a.render()
+    b.update_batch(3)
+    b.update_batch(18)  # 16 + 2, reaches max_frames exactly at the end
+    b.update_batch(4)   # entirely beyond max_frames: no-op, but total_frames still advances
+    b.render()
+    for which in range(4):
+        assert a.read_image(which).tobytes() == b.read_image(which).tobytes()
+    sa, sb = a.statistics(), b.statistics()
+    assert (sa.total_frames, sa.updates_rendered, sa.rays_closest_total, sa.rays_shadow_total) == \
+           (sb.total_frames, sb.updates_rendered, sb.rays_closest_total, sb.rays_shadow_total)
+    assert sa.total_frames == 25 and sa.updates_rendered == 21
+    imgs, _ = oracle.OracleScene(s, envmap=env).render(72, 40, frames=21, max_depth=4, rr_depth=2)
+    assert_images_equal(b, imgs)
+    a.close(); b.close()
+
+
 def test_save_images_pfm_trio(halart, oracle, tmp_path):
     s = scenes.cornell_box()
     r = make_renderer(halart, s, 40, 24, tonemap=(True, True, False))
