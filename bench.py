@@ -188,6 +188,11 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "rt::k_trace_batch<false,false> (closest-hit traversal)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_GBps": (round(traffic / (avg_launch_ms * 1e-3) / 1e9, 1) if traffic and avg_launch_ms > 0 else None),
+                         "note": "achieved = ALGORITHMIC bytes (SURVEY §8d formula) / launch time. For this 32-triangle scene the whole BVH "
+                                 "(12 nodes + 32 triangles = 2.3 KB) is staged in LDS, so node/triangle bytes never reach HBM: `traffic` (PMC "
+                                 "FETCH_SIZE*2 + WRITE_SIZE per launch, profiles/traffic_closest.json) is just the ray-queue read + hit write, "
+                                 "and frac can exceed 1. scripts/bench_scenes.py reports the same figure for the 82 k and 1 M triangle scenes.",
                          "bytes_per_ray": round(bytes_per_ray, 1), "nodes_per_ray": round(nodes_per_ray, 3),
                          "tris_per_ray": round(tris_per_ray, 3), "avg_launch_ms": round(avg_launch_ms, 5),
                          "launches": int(closest_launches), "rays_per_launch": round(rays_per_launch, 1),
