@@ -180,7 +180,8 @@ EXPORTS = [
     "hala_rt_render", "hala_rt_wait_idle", "hala_rt_save_images", "hala_rt_read_image",
     "hala_rt_get_info", "hala_rt_get_statistics", "hala_rt_set_counting", "hala_rt_reset_accumulation", "hala_rt_get_global_uniform",
     "hala_rt_get_packed_cameras", "hala_rt_get_packed_lights", "hala_rt_get_packed_materials",
-    "hala_rt_get_packed_primitives", "hala_rt_get_env_distribution", "hala_rt_set_tile_shard",
+    "hala_rt_get_packed_primitives", "hala_rt_get_env_distribution", "hala_rt_get_texture_info",
+    "hala_rt_read_texture_level", "hala_rt_sample_texture_host", "hala_rt_set_tile_shard",
     "hala_rt_tile_buffer", "hala_rt_scatter_gathered_tiles", "hala_rt_trace_rays",
     "hala_rt_trace_rays_host", "hala_rt_trace_rays_indirect", "hala_rt_get_bvh_info", "hala_rt_download_bvh",
     "hala_rt_update_node_transform", "hala_rt_refit", "hala_envmap_build_distribution",

@@ -47,9 +47,23 @@ struct alignas(16) Tri {
 };
 static_assert(sizeof(Tri) == 48, "triangle is 48 B");
 
+// One texture of set 2 binding 0 (src/rt_renderer.rs:197-226): a full mip chain of linear RGBA32F texels in the
+// texture arena (8-bit sources are decoded once at upload; gen_mipmaps of gpu_uploader.rs:366-400 is a 2x2 box filter
+// kernel).  mip_offset[l] = first texel of level l, in float4 units from the arena base.
+constexpr uint32_t kMaxMips = 16;
+struct TexDesc {
+  uint32_t width, height, mips, pad;
+  uint32_t mip_offset[kMaxMips];
+};
+static_assert(sizeof(TexDesc) == 80, "texture descriptor is 80 B");
+
 // What every kernel of one update() sees (the "descriptor sets" of src/rt_renderer.rs:141-209, :671-745 as
 // plain device pointers).
 struct SceneView {
+  const TexDesc* textures;   // set 2 binding 0, indexed by the material's *_map_index
+  const float4* tex_arena;
+  uint32_t texture_count;
+  uint32_t pad0;
   const BvhNode* nodes;
   const Tri* tris;             // BVH order
   const Tri* tris_by_id;       // global-id order (for shading)
@@ -70,6 +84,7 @@ struct SceneView {
 struct FrameConst {
   hala_global_uniform u;  // the 112-B record itself (src/rt_renderer.rs:408-427)
   float aspect, tan_half;
+  float pixel_spread;  // angular size of one pixel: 2*tan_half / height (texture LOD, RENDER_SPEC §7.4)
   uint32_t width, height;
   // pixel-tile sharding (RENDER_SPEC §9)
   uint32_t tile_size, tiles_x, tiles_y, world, rank, tiles_per_rank, perm_a, perm_b;

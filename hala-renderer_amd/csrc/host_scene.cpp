@@ -71,6 +71,55 @@ std::string HostScene::assign(const hala_scene_desc* d) {
     if (m.type > 1u) return "Invalid material type.";      // HalaMaterialType::from_u8 panics (cpu/material.rs:14)
     if (m.medium_type > 3u) return "Invalid medium type.";  // HalaMediumType::from_u8 panics (cpu/material.rs:65)
   }
+  // textures: gpu_uploader.rs:334-403.  textures[i] = image2data[texture2image[i-th key]]; every image_data entry
+  // becomes one linear RGBA32F level-0 image (8-bit data decoded here once; the mip chain is built on the GPU).
+  images.clear(); texture_image.clear();
+  {
+    static float srgb_lut[256];
+    static bool lut_ready = false;
+    if (!lut_ready) {  // sRGB EOTF (the *_SRGB formats of gltf_loader.rs:395-396 are decoded by the sampler in the reference)
+      for (int i = 0; i < 256; ++i) {
+        const double c = i / 255.0;
+        srgb_lut[i] = (float)(c <= 0.04045 ? c / 12.92 : std::pow((c + 0.055) / 1.055, 2.4));
+      }
+      lut_ready = true;
+    }
+    for (uint32_t k = 0; k < d->image_data_count; ++k) {
+      const hala_image_desc& im = d->image_data[k];
+      if (!im.data || !im.width || !im.height) return "The image data is empty.";
+      HostImage32F out;
+      out.width = im.width; out.height = im.height;
+      const size_t n = (size_t)im.width * im.height;
+      out.rgba.resize(n * 4);
+      if (im.format == HALA_FORMAT_R32G32B32A32_SFLOAT) {
+        if (im.num_of_bytes < n * 16) return "The image data is too small.";
+        memcpy(out.rgba.data(), im.data, n * 16);
+      } else if (im.format == HALA_FORMAT_R8G8B8A8_UNORM || im.format == HALA_FORMAT_R8G8B8A8_SRGB || im.format == HALA_FORMAT_B8G8R8A8_UNORM) {
+        if (im.num_of_bytes < n * 4) return "The image data is too small.";
+        const uint8_t* p = static_cast<const uint8_t*>(im.data);
+        for (size_t i = 0; i < n; ++i) {
+          const uint8_t b0 = p[4 * i], b1 = p[4 * i + 1], b2 = p[4 * i + 2], b3 = p[4 * i + 3];
+          float* o = &out.rgba[4 * i];
+          if (im.format == HALA_FORMAT_R8G8B8A8_SRGB) { o[0] = srgb_lut[b0]; o[1] = srgb_lut[b1]; o[2] = srgb_lut[b2]; }
+          else if (im.format == HALA_FORMAT_B8G8R8A8_UNORM) { o[0] = (float)b2 / 255.0f; o[1] = (float)b1 / 255.0f; o[2] = (float)b0 / 255.0f; }  // cpu/image_data.rs:39-43
+          else { o[0] = (float)b0 / 255.0f; o[1] = (float)b1 / 255.0f; o[2] = (float)b2 / 255.0f; }
+          o[3] = (float)b3 / 255.0f;
+        }
+      } else return "Unsupported image format.";
+      images.push_back(std::move(out));
+    }
+    uint32_t prev_key = 0;
+    for (uint32_t i = 0; i < d->texture_count; ++i) {
+      const hala_index_pair& t = d->texture2image_mapping[i];
+      if (i > 0 && t.key <= prev_key) return "texture2image_mapping is not in ascending key order (BTreeMap).";
+      prev_key = t.key;
+      const hala_index_pair* hit = nullptr;
+      for (uint32_t j = 0; j < d->image_count; ++j) if (d->image2data_mapping[j].key == t.value) { hit = &d->image2data_mapping[j]; break; }
+      if (!hit) return "The image " + std::to_string(t.value) + " is not found.";  // gpu_uploader.rs:337
+      if (hit->value >= images.size()) return "The image data " + std::to_string(hit->value) + " is not found.";
+      texture_image.push_back(hit->value);
+    }
+  }
   lights_cpu.assign(d->lights, d->lights + d->light_count);
   for (const auto& l : lights_cpu) if (l.light_type > 4u) return "Invalid light type.";  // cpu/light.rs:20
   cameras_cpu.assign(d->cameras, d->cameras + d->camera_count);

@@ -30,8 +30,15 @@ struct HostPrimitive {
   uint32_t material_index = HALA_INVALID_INDEX;
 };
 
+struct HostImage32F {  // one cpu::HalaImageData decoded to linear RGBA32F (level 0 of its mip chain)
+  uint32_t width = 0, height = 0;
+  std::vector<float> rgba;
+};
+
 struct HostScene {
   // cpu::HalaScene
+  std::vector<HostImage32F> images;     // image_data, decoded
+  std::vector<uint32_t> texture_image;  // textures[i] -> index into images (gpu_uploader.rs:336-338, BTreeMap key order)
   std::vector<HostNode> nodes;
   std::vector<HostPrimitive> prims;       // all primitives of all meshes, mesh-major
   std::vector<uint32_t> mesh_first_prim;  // [mesh_count + 1]

@@ -363,7 +363,7 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(FrameConst fc, SceneVie
       L = L + T * env * w;
       if (depth == 0u) ps.albedo[slot] = make_float4(minf(env.x, 1.0f), minf(env.y, 1.0f), minf(env.z, 1.0f), 1.0f);
     } else {
-      const Surface sf = make_surface(sv, o, d, hv.x, hv.y, hv.z, hit_prim);
+      const Surface sf = make_surface(sv, fc.pixel_spread, o, d, hv.x, hv.y, hv.z, hit_prim);
       if (depth == 0u) {
         ps.albedo[slot] = make_float4(sf.mat.base.x, sf.mat.base.y, sf.mat.base.z, 1.0f);
         ps.normal[slot] = make_float4(sf.ns.x, sf.ns.y, sf.ns.z, 1.0f);
@@ -485,6 +485,13 @@ __global__ void __launch_bounds__(256) k_resolve(FrameConst fc, PathState ps, fl
   final_img[pslot] = make_float4(c.x, c.y, c.z, 1.0f);
 }
 
+// stand-alone texture fetch (tests): uvl = (u, v, lod) per sample
+__global__ void __launch_bounds__(256) k_sample_texture(SceneView sv, uint32_t tex, const float* __restrict__ uvl, uint32_t n, float4* __restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out[i] = tex_sample(sv, tex, uvl[3 * i], uvl[3 * i + 1], uvl[3 * i + 2]);
+}
+
 // tile-major gathered buffer [world][tiles_per_rank][ts][ts] -> row-major full image (RENDER_SPEC §9)
 __global__ void __launch_bounds__(256) k_scatter_tiles(FrameConst fc, const float4* __restrict__ gathered, float4* __restrict__ full) {
   const uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x;
@@ -542,6 +549,9 @@ void launch_shade(const FrameConst& fc, const SceneView& sv, const Queues& q, co
 }
 void launch_resolve(const FrameConst& fc, const PathState& ps, float4* accum, float4* albedo, float4* normal, float4* final_img, hipStream_t s) {
   hipLaunchKernelGGL(k_resolve, dim3(blocks_for(fc.pixel_slots, 256)), dim3(256), 0, s, fc, ps, accum, albedo, normal, final_img);
+}
+void launch_sample_texture(const SceneView& sv, uint32_t tex, const float* uvl, uint32_t n, float4* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_sample_texture, dim3(blocks_for(n, 256)), dim3(256), 0, s, sv, tex, uvl, n, out);
 }
 void launch_scatter_tiles(const FrameConst& fc, const float4* gathered, float4* full, hipStream_t s) {
   const uint32_t n = fc.tiles_per_rank * fc.tile_size * fc.tile_size * fc.world;

@@ -27,6 +27,10 @@ void launch_raygen(const FrameConst& fc, const SceneView& sv, const Queues& q, c
 void launch_shade(const FrameConst& fc, const SceneView& sv, const Queues& q, const PathState& ps, Control* ctl, uint32_t depth, hipStream_t s);
 void launch_resolve(const FrameConst& fc, const PathState& ps, float4* accum, float4* albedo, float4* normal, float4* final_img, hipStream_t s);
 void launch_scatter_tiles(const FrameConst& fc, const float4* gathered, float4* full, hipStream_t s);
+void launch_sample_texture(const SceneView& sv, uint32_t tex, const float* uvl, uint32_t n, float4* out, hipStream_t s);
+
+// texture.hip — K8: one level of the mip chain (2x2 box filter over linear RGBA32F texels)
+void launch_mip_downsample(const float4* src, uint32_t sw, uint32_t sh, float4* dst, uint32_t dw, uint32_t dh, hipStream_t s);
 
 // bvh_build.hip — K1/K3/K4: flatten instances to world space, LBVH build, refit
 struct BvhBuffers {

@@ -116,6 +116,9 @@ struct hala_rt_renderer {
   DeviceArray<hala_gpu_material> d_materials;
   DeviceArray<hala_gpu_mesh_data> d_instances;
   DeviceArray<uint32_t> d_inst_first_tri;
+  DeviceArray<float4> d_tex_arena;
+  DeviceArray<TexDesc> d_textures;
+  std::vector<TexDesc> host_textures;
 
   BvhBuffers bvh{};
   DeviceArray<Tri> d_tris_by_id, d_tris;
@@ -176,6 +179,7 @@ struct hala_rt_renderer {
     sv.nodes = d_nodes.ptr; sv.tris = d_tris.ptr; sv.tris_by_id = d_tris_by_id.ptr; sv.tri_instance = d_tri_instance.ptr;
     sv.inst_first_tri = d_inst_first_tri.ptr; sv.primitives = d_instances.ptr; sv.materials = d_materials.ptr;
     sv.lights = d_lights.ptr; sv.cameras = d_cameras.ptr;
+    sv.textures = d_textures.ptr; sv.tex_arena = d_tex_arena.ptr; sv.texture_count = (uint32_t)host_textures.size();
     sv.env_pixels = reinterpret_cast<const float*>(d_env.ptr); sv.env_marginal = d_marginal.ptr; sv.env_conditional = d_conditional.ptr;
     sv.node_count = bvh.node_count; sv.tri_count = bvh.tri_count; sv.lds_nodes = lds_nodes; sv.lds_tris = lds_tris;
     sv.ray_eps = ray_eps;
@@ -196,6 +200,7 @@ struct hala_rt_renderer {
     float sn = 0.0f, cs = 1.0f;
     if (!hs.cameras.empty()) h_sincos_rad(0.5f * hs.cameras[0].yfov, &sn, &cs);
     fc.tan_half = sn / cs;
+    fc.pixel_spread = 2.0f * fc.tan_half / u.resolution[1];
     fc.width = width; fc.height = height;
     fc.tile_size = tile_size; fc.tiles_x = tiles_x; fc.tiles_y = tiles_y; fc.world = world; fc.rank = rank;
     fc.tiles_per_rank = tiles_per_rank; fc.perm_a = perm_a_inv; fc.perm_b = perm_b;
@@ -318,6 +323,42 @@ int upload_packed(hala_rt_renderer* r) {
   RT_HIP(r->d_instances.upload(hs.instances.data(), hs.instances.size(), r->stream));
   RT_HIP(r->d_inst_first_tri.upload(hs.inst_first_tri.data(), hs.inst_first_tri.size(), r->stream));
   RT_HIP(hipStreamSynchronize(r->stream));
+  return HALA_OK;
+}
+
+// textures: upload level 0 of every image, build the mip chains on the GPU (gen_mipmaps, gpu_uploader.rs:400), publish
+// one TexDesc per texture.  mip count = ceil(log2(max(w,h))) + 1 (gpu_uploader.rs:366), capped at kMaxMips.
+int upload_textures(hala_rt_renderer* r) {
+  const HostScene& hs = r->hs;
+  std::vector<TexDesc> img_desc(hs.images.size());
+  size_t total = 0;
+  for (size_t k = 0; k < hs.images.size(); ++k) {
+    TexDesc& td = img_desc[k];
+    memset(&td, 0, sizeof(td));
+    td.width = hs.images[k].width; td.height = hs.images[k].height;
+    uint32_t m = std::max(td.width, td.height), p2 = 1, lg = 0;
+    while (p2 < m) { p2 <<= 1; ++lg; }
+    td.mips = std::min<uint32_t>(lg + 1, kMaxMips);
+    for (uint32_t l = 0; l < td.mips; ++l) {
+      if (total > 0xffffffffull) RT_FAIL("The texture arena exceeds 2^32 texels.");
+      td.mip_offset[l] = (uint32_t)total;
+      total += (size_t)std::max(1u, td.width >> l) * std::max(1u, td.height >> l);
+    }
+  }
+  RT_HIP(r->d_tex_arena.resize(total));
+  for (size_t k = 0; k < hs.images.size(); ++k) {
+    const TexDesc& td = img_desc[k];
+    RT_HIP(hipMemcpyAsync(r->d_tex_arena.ptr + td.mip_offset[0], hs.images[k].rgba.data(), (size_t)td.width * td.height * 16, hipMemcpyHostToDevice, r->stream));
+    for (uint32_t l = 1; l < td.mips; ++l)
+      launch_mip_downsample(r->d_tex_arena.ptr + td.mip_offset[l - 1], std::max(1u, td.width >> (l - 1)), std::max(1u, td.height >> (l - 1)),
+                            r->d_tex_arena.ptr + td.mip_offset[l], std::max(1u, td.width >> l), std::max(1u, td.height >> l), r->stream);
+  }
+  std::vector<TexDesc> tex(hs.texture_image.size());
+  for (size_t i = 0; i < tex.size(); ++i) tex[i] = img_desc[hs.texture_image[i]];
+  RT_HIP(r->d_textures.upload(tex.data(), tex.size(), r->stream));
+  RT_HIP(hipStreamSynchronize(r->stream));
+  RT_HIP(hipGetLastError());
+  r->host_textures = tex;
   return HALA_OK;
 }
 
@@ -485,6 +526,7 @@ int hala_rt_set_scene(hala_rt_renderer* r, const hala_scene_desc* scene) {
   const std::string e = r->hs.assign(scene);
   if (!e.empty()) RT_FAIL(e);
   if (upload_packed(r) != HALA_OK) return HALA_ERR;
+  if (upload_textures(r) != HALA_OK) return HALA_ERR;
   r->has_scene = true;
   return HALA_OK;
 }
@@ -730,6 +772,41 @@ int hala_rt_get_env_distribution(hala_rt_renderer* r, float* total_sum, float* m
   if (total_sum) *total_sum = r->env_total_sum;
   if (marginal) RT_HIP(hipMemcpy(marginal, r->d_marginal.ptr, (size_t)r->env_h * 4, hipMemcpyDeviceToHost));
   if (conditional) RT_HIP(hipMemcpy(conditional, r->d_conditional.ptr, (size_t)r->env_w * r->env_h * 4, hipMemcpyDeviceToHost));
+  return HALA_OK;
+}
+
+// ---- textures (set 2 binding 0) ---------------------------------------------------------------------------------------
+int hala_rt_get_texture_info(hala_rt_renderer* r, uint32_t texture, uint32_t* width, uint32_t* height, uint32_t* mips) {
+  if (!r) RT_FAIL("The renderer handle is null!");
+  if (!r->has_scene || texture >= r->host_textures.size()) RT_FAIL("The texture does not exist.");
+  const TexDesc& td = r->host_textures[texture];
+  if (width) *width = td.width;
+  if (height) *height = td.height;
+  if (mips) *mips = td.mips;
+  return HALA_OK;
+}
+int hala_rt_read_texture_level(hala_rt_renderer* r, uint32_t texture, uint32_t level, float* dst_rgba32f) {
+  if (ensure_device(r) != HALA_OK) return HALA_ERR;
+  if (!r->has_scene || texture >= r->host_textures.size() || !dst_rgba32f) RT_FAIL("The texture does not exist.");
+  const TexDesc& td = r->host_textures[texture];
+  if (level >= td.mips) RT_FAIL("The mip level does not exist.");
+  const size_t n = (size_t)std::max(1u, td.width >> level) * std::max(1u, td.height >> level);
+  RT_HIP(hipMemcpy(dst_rgba32f, r->d_tex_arena.ptr + td.mip_offset[level], n * 16, hipMemcpyDeviceToHost));
+  return HALA_OK;
+}
+int hala_rt_sample_texture_host(hala_rt_renderer* r, uint32_t texture, const float* uv_lod, uint32_t count, float* dst_rgba32f) {
+  if (ensure_device(r) != HALA_OK) return HALA_ERR;
+  if (!r->has_scene || texture >= r->host_textures.size()) RT_FAIL("The texture does not exist.");
+  if (!count) return HALA_OK;
+  if (!uv_lod || !dst_rgba32f) RT_FAIL("Invalid argument.");
+  DeviceArray<float> d_in;
+  DeviceArray<float4> d_out;
+  RT_HIP(d_in.upload(uv_lod, (size_t)count * 3, r->stream));
+  RT_HIP(d_out.resize(count));
+  launch_sample_texture(r->view(), texture, d_in.ptr, count, d_out.ptr, r->stream);
+  RT_HIP(hipMemcpyAsync(dst_rgba32f, d_out.ptr, (size_t)count * 16, hipMemcpyDeviceToHost, r->stream));
+  RT_HIP(hipStreamSynchronize(r->stream));
+  RT_HIP(hipGetLastError());
   return HALA_OK;
 }
 

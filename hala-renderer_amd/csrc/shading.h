@@ -387,11 +387,64 @@ RT_DI f3 transform_normal(const float* m, f3 n) {
   return det < 0.0f ? -r : r;
 }
 
+// ---- §7.4 textures: software trilinear fetch (K8; CDNA exposes no image sampler to HIP that could be relied on) ------
+// log2 of a positive finite float from its bit pattern: exponent + (mantissa - 1); piecewise linear, exact at powers
+// of two, max error 0.086 — plenty for level-of-detail selection and identical on every implementation.
+RT_DI float log2_approx(float x) {
+  const uint32_t b = __float_as_uint(x);
+  const float e = (float)((int)((b >> 23) & 255u) - 127);
+  const float m = __uint_as_float((b & 0x007fffffu) | 0x3f800000u);
+  return e + (m - 1.0f);
+}
+RT_DI float4 tex_bilinear(const SceneView& sv, const TexDesc& td, uint32_t level, float u, float v) {
+  const int w = max((int)(td.width >> level), 1), h = max((int)(td.height >> level), 1);
+  const float4* base = sv.tex_arena + td.mip_offset[level];
+  const float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
+  const float x0 = floorf(x), y0 = floorf(y);
+  const float fx = x - x0, fy = y - y0;
+  const int ix0 = wrapi((int)x0, w), iy0 = wrapi((int)y0, h);  // REPEAT (gpu_uploader.rs:346)
+  const int ix1 = wrapi(ix0 + 1, w), iy1 = wrapi(iy0 + 1, h);
+  const float4 c00 = base[(size_t)iy0 * w + ix0], c10 = base[(size_t)iy0 * w + ix1];
+  const float4 c01 = base[(size_t)iy1 * w + ix0], c11 = base[(size_t)iy1 * w + ix1];
+  const float gx = 1.0f - fx, gy = 1.0f - fy;
+  float4 r;
+  r.x = (c00.x * gx + c10.x * fx) * gy + (c01.x * gx + c11.x * fx) * fy;
+  r.y = (c00.y * gx + c10.y * fx) * gy + (c01.y * gx + c11.y * fx) * fy;
+  r.z = (c00.z * gx + c10.z * fx) * gy + (c01.z * gx + c11.z * fx) * fy;
+  r.w = (c00.w * gx + c10.w * fx) * gy + (c01.w * gx + c11.w * fx) * fy;
+  return r;
+}
+// linear / linear-mip / repeat sampler of gpu_uploader.rs:341-353; lod is clamped to the chain
+RT_DI float4 tex_sample(const SceneView& sv, uint32_t tex, float u, float v, float lod) {
+  const TexDesc& td = sv.textures[tex];
+  const float top = (float)(td.mips - 1u);
+  lod = lod < 0.0f ? 0.0f : (lod > top ? top : lod);
+  const float l0 = floorf(lod);
+  const float fl = lod - l0;
+  const uint32_t level = (uint32_t)l0;
+  float4 a = tex_bilinear(sv, td, level, u, v);
+  if (fl > 0.0f && level + 1u < td.mips) {
+    const float4 b = tex_bilinear(sv, td, level + 1u, u, v);
+    const float g = 1.0f - fl;
+    a.x = a.x * g + b.x * fl; a.y = a.y * g + b.y * fl; a.z = a.z * g + b.z * fl; a.w = a.w * g + b.w * fl;
+  }
+  return a;
+}
+// level of detail for texture `tex` given lod_base = 0.5*log2(footprint^2 * uv_area / world_area) (RENDER_SPEC §7.4)
+RT_DI float tex_lod(const SceneView& sv, uint32_t tex, float lod_base) {
+  const TexDesc& td = sv.textures[tex];
+  return lod_base + 0.5f * log2_approx((float)td.width * (float)td.height);
+}
+
 struct Surface {
   f3 P, ns, ng;
   MatView mat;
 };
-RT_DI Surface make_surface(const SceneView& sv, f3 o, f3 d, float t, float u, float v, uint32_t prim) {
+RT_DI f3 transform_vector(const float* m, f3 p) {
+  return mk3(__fmaf_rn(m[8], p.z, __fmaf_rn(m[4], p.y, m[0] * p.x)), __fmaf_rn(m[9], p.z, __fmaf_rn(m[5], p.y, m[1] * p.x)),
+             __fmaf_rn(m[10], p.z, __fmaf_rn(m[6], p.y, m[2] * p.x)));
+}
+RT_DI Surface make_surface(const SceneView& sv, float pixel_spread, f3 o, f3 d, float t, float u, float v, uint32_t prim) {
   Surface sf;
   const float4* tp = reinterpret_cast<const float4*>(sv.tris_by_id + prim);
   const float4 tb = tp[1], tc = tp[2];
@@ -406,9 +459,8 @@ RT_DI Surface make_surface(const SceneView& sv, f3 o, f3 d, float t, float u, fl
   float w0 = 1.0f - u - v;
   f3 nl = madd3(ld3(c.normal), v, madd3(ld3(b.normal), u, ld3(a.normal) * w0));
   sf.ns = normalize3(transform_normal(md.transform, nl));
-  sf.ng = normalize3(cross3(mk3(tb.x, tb.y, tb.z), mk3(tc.x, tc.y, tc.z)));
-  if (dot3(sf.ns, sf.ng) < 0.0f) sf.ng = -sf.ng;
-  if (dot3(sf.ng, d) > 0.0f) { sf.ns = -sf.ns; sf.ng = -sf.ng; }
+  const f3 gcross = cross3(mk3(tb.x, tb.y, tb.z), mk3(tc.x, tc.y, tc.z));
+  sf.ng = normalize3(gcross);
   sf.P = madd3(d, t, o);
   const hala_gpu_material& m = sv.materials[md.material_index];
   sf.mat.base = ld3(m.base_color);
@@ -417,6 +469,60 @@ RT_DI Surface make_surface(const SceneView& sv, f3 o, f3 d, float t, float u, fl
   sf.mat.metallic = m.metallic; sf.mat.roughness = m.roughness; sf.mat.specular_tint = m.specular_tint;
   sf.mat.sheen = m.sheen; sf.mat.sheen_tint = m.sheen_tint; sf.mat.clearcoat = m.clearcoat;
   sf.mat.clearcoat_roughness = m.clearcoat_roughness; sf.mat.ior = m.ior;
+  // texture maps (set 2; u32::MAX = none, gltf_loader.rs:346-353)
+  const uint32_t nt = sv.texture_count;
+  const bool has_base = m.base_color_map_index < nt, has_nrm = m.normal_map_index < nt;
+  const bool has_mr = m.metallic_roughness_map_index < nt, has_em = m.emission_map_index < nt;
+  if (has_base || has_nrm || has_mr || has_em) {
+    const float tu = __fmaf_rn(c.tex_coord[0], v, __fmaf_rn(b.tex_coord[0], u, a.tex_coord[0] * w0));
+    const float tv = __fmaf_rn(c.tex_coord[1], v, __fmaf_rn(b.tex_coord[1], u, a.tex_coord[1] * w0));
+    // footprint of one pixel's cone on the surface vs. the uv density of this triangle
+    const float du1 = b.tex_coord[0] - a.tex_coord[0], dv1 = b.tex_coord[1] - a.tex_coord[1];
+    const float du2 = c.tex_coord[0] - a.tex_coord[0], dv2 = c.tex_coord[1] - a.tex_coord[1];
+    const float uv_area = fabsf(du1 * dv2 - dv1 * du2);
+    const float world_area = sqrtf(dot3(gcross, gcross));
+    const float cosi = maxf(fabsf(dot3(d, sf.ng)), 0.1f);
+    const float foot = t * pixel_spread / cosi;
+    const float ratio = foot * foot * uv_area / world_area;
+    const float lod_base = (ratio > 0.0f && ratio < 3.0e38f) ? 0.5f * log2_approx(ratio) : 0.0f;
+    if (has_base) {
+      const float4 s = tex_sample(sv, m.base_color_map_index, tu, tv, tex_lod(sv, m.base_color_map_index, lod_base));
+      sf.mat.base = sf.mat.base * mk3(s.x, s.y, s.z);
+    }
+    if (has_em) {
+      const float4 s = tex_sample(sv, m.emission_map_index, tu, tv, tex_lod(sv, m.emission_map_index, lod_base));
+      sf.mat.emission = sf.mat.emission * mk3(s.x, s.y, s.z);
+    }
+    if (has_mr) {  // glTF: G = roughness, B = metallic
+      const float4 s = tex_sample(sv, m.metallic_roughness_map_index, tu, tv, tex_lod(sv, m.metallic_roughness_map_index, lod_base));
+      sf.mat.metallic = sf.mat.metallic * s.z;
+      if (m.type == 1u) {  // re-derive the packed alphas exactly like src/scene/gpu/material.rs:61-69
+        const float rl = sqrtf(m.roughness) * s.y;
+        const float r2 = rl * rl;
+        const float aspect = sqrtf(1.0f - clampf(m.anisotropic, 0.0f, 1.0f) * 0.9f);
+        sf.mat.roughness = r2;
+        sf.mat.ax = maxf(0.001f, r2 / aspect);
+        sf.mat.ay = maxf(0.001f, r2 * aspect);
+      }
+    }
+    if (has_nrm) {
+      const float4 s = tex_sample(sv, m.normal_map_index, tu, tv, tex_lod(sv, m.normal_map_index, lod_base));
+      const f3 tl = madd3(ld3(c.tangent), v, madd3(ld3(b.tangent), u, ld3(a.tangent) * w0));
+      f3 tw = transform_vector(md.transform, tl);
+      tw = tw - sf.ns * dot3(sf.ns, tw);  // Gram-Schmidt against the shading normal
+      const float tl2 = dot3(tw, tw);
+      if (tl2 > 0.0f) {
+        tw = tw * (1.0f / sqrtf(tl2));
+        const f3 bw = cross3(sf.ns, tw);
+        const f3 nts = mk3(s.x * 2.0f - 1.0f, s.y * 2.0f - 1.0f, s.z * 2.0f - 1.0f);
+        const f3 nn = to_world(nts, tw, bw, sf.ns);
+        const float nn2 = dot3(nn, nn);
+        if (nn2 > 0.0f) sf.ns = nn * (1.0f / sqrtf(nn2));
+      }
+    }
+  }
+  if (dot3(sf.ns, sf.ng) < 0.0f) sf.ng = -sf.ng;
+  if (dot3(sf.ng, d) > 0.0f) { sf.ns = -sf.ns; sf.ng = -sf.ng; }
   return sf;
 }
 

@@ -190,6 +190,26 @@ class HalaRenderer:
         self._check(self._lib.hala_rt_get_env_distribution(self._h, C.byref(total), marg.ctypes.data_as(C.POINTER(C.c_float)), cond.ctypes.data_as(C.POINTER(C.c_float))))
         return total.value, marg, cond
 
+    # -- textures (set 2 binding 0) ---------------------------------------------------------------------------------------
+    def texture_info(self, texture):
+        w, h, m = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self._check(self._lib.hala_rt_get_texture_info(self._h, C.c_uint32(texture), C.byref(w), C.byref(h), C.byref(m)))
+        return w.value, h.value, m.value
+
+    def read_texture_level(self, texture, level):
+        w, h, _ = self.texture_info(texture)
+        lw, lh = max(1, w >> level), max(1, h >> level)
+        out = np.empty((lh, lw, 4), dtype=np.float32)
+        self._check(self._lib.hala_rt_read_texture_level(self._h, C.c_uint32(texture), C.c_uint32(level), out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    def sample_texture(self, texture, uv_lod):
+        q = np.ascontiguousarray(uv_lod, dtype=np.float32).reshape(-1, 3)
+        out = np.empty((q.shape[0], 4), dtype=np.float32)
+        self._check(self._lib.hala_rt_sample_texture_host(self._h, C.c_uint32(texture), q.ctypes.data_as(C.POINTER(C.c_float)), C.c_uint32(q.shape[0]),
+                                                          out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
     # -- ray-batch operator / BVH introspection ----------------------------------------------------------------------
     def trace_rays_host(self, rays: np.ndarray, mode=0, count_steps=False):
         rays = np.ascontiguousarray(rays, dtype=A.RAY_DTYPE)

@@ -215,6 +215,66 @@ def sky_sun_envmap(width=2048, height=1024, sun_dir=(0.4, 0.6, 0.35), sun_radius
 
 
 # ---------------------------------------------------------------------------------------------------------
+# procedural textures (config 4: ">= 16 procedural 1024^2 textures (base colour + normal + MR) with mips")
+# ---------------------------------------------------------------------------------------------------------
+def _tile_noise(size, cells, seed):
+    """tileable value noise in [0,1], [size,size] float64"""
+    rng = np.random.RandomState(seed)
+    g = rng.rand(cells, cells)
+    t = np.arange(size) * (cells / size)
+    i0 = np.floor(t).astype(int) % cells
+    i1 = (i0 + 1) % cells
+    f = t - np.floor(t)
+    w = f * f * (3 - 2 * f)
+    a = g[i0][:, i0] * (1 - w)[None, :] + g[i0][:, i1] * w[None, :]
+    b = g[i1][:, i0] * (1 - w)[None, :] + g[i1][:, i1] * w[None, :]
+    return a * (1 - w)[:, None] + b * w[:, None]
+
+
+def procedural_texture_set(size=1024, seed=0, tint=(0.8, 0.7, 0.6)):
+    """returns (base_color sRGB8, normal UNORM8, metallic_roughness UNORM8) as HalaImageData"""
+    from .scene import HalaImageData
+    n = 0.55 * _tile_noise(size, 8, seed) + 0.3 * _tile_noise(size, 32, seed + 1) + 0.15 * _tile_noise(size, 128, seed + 2)
+    yy, xx = np.meshgrid(np.arange(size), np.arange(size), indexing="ij")
+    tiles = (((xx * 8 // size) + (yy * 8 // size)) % 2).astype(np.float64)
+    base = np.clip((0.55 + 0.45 * n)[..., None] * np.asarray(tint)[None, None, :] * (0.75 + 0.25 * tiles[..., None]), 0, 1)
+    base8 = np.concatenate([np.round(base * 255), np.full((size, size, 1), 255.0)], -1).astype(np.uint8)
+    hgt = n + 0.08 * tiles
+    dx = np.roll(hgt, -1, 1) - np.roll(hgt, 1, 1)
+    dy = np.roll(hgt, -1, 0) - np.roll(hgt, 1, 0)
+    nrm = np.stack([-dx * size / 64.0, -dy * size / 64.0, np.ones_like(dx)], -1)
+    nrm /= np.linalg.norm(nrm, axis=-1, keepdims=True)
+    nrm8 = np.concatenate([np.round((nrm * 0.5 + 0.5) * 255), np.full((size, size, 1), 255.0)], -1).astype(np.uint8)
+    rough = np.clip(0.35 + 0.6 * _tile_noise(size, 16, seed + 3), 0, 1)
+    metal = (tiles > 0.5).astype(np.float64) * (_tile_noise(size, 4, seed + 4) > 0.5)
+    mr8 = np.stack([np.zeros_like(rough), np.round(rough * 255), np.round(metal * 255), np.full_like(rough, 255.0)], -1).astype(np.uint8)
+    return (HalaImageData(A_FORMAT_SRGB, size, size, base8), HalaImageData(A_FORMAT_UNORM, size, size, nrm8), HalaImageData(A_FORMAT_UNORM, size, size, mr8))
+
+
+A_FORMAT_UNORM, A_FORMAT_SRGB, A_FORMAT_FLOAT, A_FORMAT_BGRA_TAG = 0, 1, 2, 3  # HALA_FORMAT_* of include/halart.h
+
+
+def attach_textures(scene: HalaScene, sets, size=1024, seed=100, every=1):
+    """generates `sets` texture triples and binds them round-robin to the scene's materials (every `every`-th material)"""
+    for k in range(sets):
+        tint = [(0.85, 0.8, 0.7), (0.7, 0.35, 0.3), (0.35, 0.5, 0.75), (0.45, 0.65, 0.4), (0.85, 0.75, 0.4)][k % 5]
+        for img in procedural_texture_set(size, seed + 10 * k, tint):
+            idx = len(scene.image_data)
+            scene.image_data.append(img)
+            scene.image2data_mapping[idx] = idx
+            scene.texture2image_mapping[idx] = idx
+    for i, m in enumerate(scene.materials):
+        if i % every:
+            continue
+        k = (i // every) % sets
+        m.base_color_map_index = 3 * k
+        m.normal_map_index = 3 * k + 1
+        if m.type == HalaMaterialType.DISNEY:
+            m.metallic_roughness_map_index = 3 * k + 2
+    return scene
+
+
+# ---------------------------------------------------------------------------------------------------------
 # Config 4/5: "Sponza-class" atrium, ~1 M triangles
 # ---------------------------------------------------------------------------------------------------------
 def _grid_mesh(nx, nz, fn):

@@ -225,8 +225,10 @@ typedef struct hala_camera_desc {
 
 /* src/scene/cpu/image_data.rs:14-20; format codes are this library's own small enum */
 #define HALA_FORMAT_R8G8B8A8_UNORM 0
-#define HALA_FORMAT_R8G8B8A8_SRGB 1
+#define HALA_FORMAT_R8G8B8A8_SRGB 1        /* glTF 8-bit RGB(A) images (src/scene/loader/gltf_loader.rs:395-396) */
 #define HALA_FORMAT_R32G32B32A32_SFLOAT 2
+#define HALA_FORMAT_B8G8R8A8_UNORM 3       /* files loaded through cpu::HalaImageData: RGBA bytes tagged BGRA without
+                                              a swizzle (src/scene/cpu/image_data.rs:39-43) — red and blue swap */
 typedef struct hala_image_desc {
   uint32_t format;
   uint32_t width;
@@ -382,6 +384,13 @@ int hala_rt_get_packed_materials(hala_rt_renderer* r, hala_gpu_material* dst, ui
 int hala_rt_get_packed_primitives(hala_rt_renderer* r, hala_gpu_mesh_data* dst, float* dst_instance_3x4, uint32_t capacity, uint32_t* count);
 /* env tables of set_envmap (src/envmap.rs:239-388): total_sum, marginal[H], conditional[W*H] */
 int hala_rt_get_env_distribution(hala_rt_renderer* r, float* total_sum, float* marginal, float* conditional);
+
+/* Textures of set 2 binding 0 (src/rt_renderer.rs:197-226) as uploaded by gpu_uploader.rs:334-403: every texture is a
+ * full mip chain (gen_mipmaps, :400) of linear RGBA32F texels; the sampler is linear / linear-mip / REPEAT (:341-353).
+ * Introspection + a stand-alone fetch for parity tests: uv_lod holds (u, v, lod) triples. */
+int hala_rt_get_texture_info(hala_rt_renderer* r, uint32_t texture, uint32_t* width, uint32_t* height, uint32_t* mips);
+int hala_rt_read_texture_level(hala_rt_renderer* r, uint32_t texture, uint32_t level, float* dst_rgba32f);
+int hala_rt_sample_texture_host(hala_rt_renderer* r, uint32_t texture, const float* uv_lod, uint32_t count, float* dst_rgba32f);
 
 /* Multi-GPU pixel-tile sharding (no reference equivalent; BASELINE.json north_star).  The frame is cut
  * into tile_size x tile_size tiles; tile t belongs to rank perm(t) % world (perm = fixed bijective

@@ -175,6 +175,11 @@ void orc_render(const orc_scene* s, const orc_render_params* p, uint32_t first_f
 void orc_generate_camera_rays(const orc_scene* s, uint32_t width, uint32_t height, uint32_t frame_index,
                               orc_ray* rays);
 
+// textures (RENDER_SPEC §7.4): mip chain + trilinear REPEAT fetch; uvl = (u, v, lod) triples
+int orc_scene_texture_info(const orc_scene* s, uint32_t tex, uint32_t* w, uint32_t* h, uint32_t* mips);
+void orc_scene_texture_level(const orc_scene* s, uint32_t tex, uint32_t level, float* out_rgba);
+void orc_scene_sample_texture(const orc_scene* s, uint32_t tex, const float* uvl, uint32_t n, float* out_rgba);
+
 // spec_math probes for tests (vectorised over n)
 void orc_probe_sincos_2pi(const float* u, float* s, float* c, size_t n);
 void orc_probe_acos(const float* x, float* out, size_t n);

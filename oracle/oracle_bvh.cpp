@@ -192,6 +192,56 @@ extern "C" orc_scene* orc_scene_create(const orc_scene_desc* desc) {
   V3 ext = v3(s->bounds_max[0] - s->bounds_min[0], s->bounds_max[1] - s->bounds_min[1], s->bounds_max[2] - s->bounds_min[2]);
   s->ray_eps = sqrtf(dot3(ext, ext)) * 1e-5f;  // RENDER_SPEC §3
   build_bvh(s);
+  // textures (RENDER_SPEC §7.4; gpu_uploader.rs:334-403): decode to linear RGBA32F, 2x2 box mips, texture -> image map
+  for (uint32_t k = 0; k < desc->image_data_count; ++k) {
+    const orc_image_desc& im = desc->image_data[k];
+    Image img;
+    img.width = im.width; img.height = im.height;
+    const size_t n = (size_t)im.width * im.height;
+    std::vector<float> l0(n * 4);
+    if (im.format == 2) memcpy(l0.data(), im.data, n * 16);
+    else {
+      const uint8_t* p = static_cast<const uint8_t*>(im.data);
+      for (size_t i = 0; i < n; ++i) {
+        for (int c = 0; c < 4; ++c) {
+          int src = c;
+          if (im.format == 3 && c < 3) src = 2 - c;  // RGBA bytes tagged BGRA (cpu/image_data.rs:39-43)
+          const uint8_t b = p[4 * i + src];
+          float v;
+          if (im.format == 1 && c < 3) { const double x = b / 255.0; v = (float)(x <= 0.04045 ? x / 12.92 : std::pow((x + 0.055) / 1.055, 2.4)); }
+          else v = (float)b / 255.0f;
+          l0[4 * i + c] = v;
+        }
+      }
+    }
+    uint32_t m = std::max(im.width, im.height), p2 = 1, lg = 0;
+    while (p2 < m) { p2 <<= 1; ++lg; }
+    img.mips = std::min<uint32_t>(lg + 1, 16);  // gpu_uploader.rs:366
+    img.levels.push_back(std::move(l0));
+    for (uint32_t l = 1; l < img.mips; ++l) {
+      const uint32_t sw = std::max(1u, im.width >> (l - 1)), sh = std::max(1u, im.height >> (l - 1));
+      const uint32_t dw = std::max(1u, im.width >> l), dh = std::max(1u, im.height >> l);
+      const std::vector<float>& src = img.levels[l - 1];
+      std::vector<float> dst((size_t)dw * dh * 4);
+      for (uint32_t y = 0; y < dh; ++y)
+        for (uint32_t x = 0; x < dw; ++x) {
+          const uint32_t x0 = std::min(2 * x, sw - 1), x1 = std::min(2 * x + 1, sw - 1), y0 = std::min(2 * y, sh - 1), y1 = std::min(2 * y + 1, sh - 1);
+          for (int c = 0; c < 4; ++c) {
+            const float a = src[((size_t)y0 * sw + x0) * 4 + c], b = src[((size_t)y0 * sw + x1) * 4 + c];
+            const float cc = src[((size_t)y1 * sw + x0) * 4 + c], d = src[((size_t)y1 * sw + x1) * 4 + c];
+            dst[((size_t)y * dw + x) * 4 + c] = ((a + b) + (cc + d)) * 0.25f;
+          }
+        }
+      img.levels.push_back(std::move(dst));
+    }
+    s->images.push_back(std::move(img));
+  }
+  for (uint32_t i = 0; i < desc->texture_count; ++i) {
+    uint32_t data = ORC_NONE;
+    for (uint32_t j = 0; j < desc->image_count; ++j)
+      if (desc->image2data_mapping[j].key == desc->texture2image_mapping[i].value) { data = desc->image2data_mapping[j].value; break; }
+    s->texture_image.push_back(data);
+  }
   s->materials.resize(desc->material_count);
   for (uint32_t i = 0; i < desc->material_count; ++i) orc_pack_material(&desc->materials[i], &s->materials[i]);
   s->camera_count = orc_pack_cameras(desc, s->cameras);

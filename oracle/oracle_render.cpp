@@ -29,7 +29,7 @@ constexpr float kTwoPiSq = 19.7392088021787172376f;  // 2*pi^2
 struct Frame {
   const orc_scene* s;
   orc_render_params p;
-  float res_w, res_h, aspect, tan_half;
+  float res_w, res_h, aspect, tan_half, pixel_spread;
   float env_rotation;  // degrees / 360 (src/rt_renderer.rs:420)
   uint32_t env_type;
 };
@@ -377,7 +377,7 @@ static float intersect_light(const orc_gpu_light& l, V3 o, V3 d, float* pdf) {
 }
 
 // ---- RENDER_SPEC §6 surface reconstruction ----------------------------------------------------------------------
-struct Surface { V3 P, ns, ng; const orc_gpu_material* mat; V3 base; };
+struct Surface { V3 P, ns, ng; orc_gpu_material m; V3 base; };  // m: the packed material after texture modulation
 
 static inline V3 transform_normal(const float* m, V3 n) {
   // inverse-transpose of the upper 3x3 = cofactor matrix / det; columns c0,c1,c2 of M
@@ -389,7 +389,56 @@ static inline V3 transform_normal(const float* m, V3 n) {
   return det < 0.0f ? -r : r;
 }
 
-static Surface make_surface(const orc_scene* s, V3 o, V3 d, const Hit& h) {
+// ---- RENDER_SPEC §7.4 textures ----------------------------------------------------------------------------------
+struct C4 { float x, y, z, w; };
+static inline float log2_approx(float x) {
+  uint32_t b;
+  memcpy(&b, &x, 4);
+  float e = (float)((int)((b >> 23) & 255u) - 127);
+  uint32_t mb = (b & 0x007fffffu) | 0x3f800000u;
+  float m;
+  memcpy(&m, &mb, 4);
+  return e + (m - 1.0f);
+}
+static C4 tex_bilinear(const Image& img, uint32_t level, float u, float v) {
+  int w = std::max((int)(img.width >> level), 1), h = std::max((int)(img.height >> level), 1);
+  const float* base = img.levels[level].data();
+  float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
+  float x0 = floorf(x), y0 = floorf(y);
+  float fx = x - x0, fy = y - y0;
+  int ix0 = wrapi((int)x0, w), iy0 = wrapi((int)y0, h);
+  int ix1 = wrapi(ix0 + 1, w), iy1 = wrapi(iy0 + 1, h);
+  const float* c00 = base + 4 * ((size_t)iy0 * w + ix0); const float* c10 = base + 4 * ((size_t)iy0 * w + ix1);
+  const float* c01 = base + 4 * ((size_t)iy1 * w + ix0); const float* c11 = base + 4 * ((size_t)iy1 * w + ix1);
+  float gx = 1.0f - fx, gy = 1.0f - fy;
+  float r[4];
+  for (int k = 0; k < 4; ++k) r[k] = (c00[k] * gx + c10[k] * fx) * gy + (c01[k] * gx + c11[k] * fx) * fy;
+  return C4{r[0], r[1], r[2], r[3]};
+}
+static C4 tex_sample(const orc_scene* s, uint32_t tex, float u, float v, float lod) {
+  const Image& img = s->images[s->texture_image[tex]];
+  float top = (float)(img.mips - 1u);
+  lod = lod < 0.0f ? 0.0f : (lod > top ? top : lod);
+  float l0 = floorf(lod);
+  float fl = lod - l0;
+  uint32_t level = (uint32_t)l0;
+  C4 a = tex_bilinear(img, level, u, v);
+  if (fl > 0.0f && level + 1u < img.mips) {
+    C4 b = tex_bilinear(img, level + 1u, u, v);
+    float g = 1.0f - fl;
+    a.x = a.x * g + b.x * fl; a.y = a.y * g + b.y * fl; a.z = a.z * g + b.z * fl; a.w = a.w * g + b.w * fl;
+  }
+  return a;
+}
+static float tex_lod(const orc_scene* s, uint32_t tex, float lod_base) {
+  const Image& img = s->images[s->texture_image[tex]];
+  return lod_base + 0.5f * log2_approx((float)img.width * (float)img.height);
+}
+static inline V3 transform_vector(const float* m, V3 p) {
+  return v3(fmaf(m[8], p.z, fmaf(m[4], p.y, m[0] * p.x)), fmaf(m[9], p.z, fmaf(m[5], p.y, m[1] * p.x)), fmaf(m[10], p.z, fmaf(m[6], p.y, m[2] * p.x)));
+}
+
+static Surface make_surface(const orc_scene* s, float pixel_spread, V3 o, V3 d, const Hit& h) {
   Surface sf;
   const Tri& tr = s->tris_by_id[h.prim];
   const Instance& inst = s->instances[s->tri_instance[h.prim]];
@@ -400,12 +449,66 @@ static Surface make_surface(const orc_scene* s, V3 o, V3 d, const Hit& h) {
   float w0 = 1.0f - h.u - h.v;
   V3 nl = madd3(ld3(c.normal), h.v, madd3(ld3(b.normal), h.u, ld3(a.normal) * w0));
   sf.ns = normalize3(transform_normal(inst.transform, nl));
-  sf.ng = normalize3(cross3(ld3(tr.e1), ld3(tr.e2)));
+  V3 gcross = cross3(ld3(tr.e1), ld3(tr.e2));
+  sf.ng = normalize3(gcross);
+  sf.P = madd3(d, h.t, o);
+  sf.m = s->materials[inst.material_index];
+  orc_gpu_material& m = sf.m;
+  sf.base = ld3(m.base_color);
+  const orc_gpu_material& pm = s->materials[inst.material_index];  // as packed (the maps modulate a copy)
+  const uint32_t nt = (uint32_t)s->texture_image.size();
+  bool has_base = pm.base_color_map_index < nt, has_nrm = pm.normal_map_index < nt;
+  bool has_mr = pm.metallic_roughness_map_index < nt, has_em = pm.emission_map_index < nt;
+  if (has_base || has_nrm || has_mr || has_em) {
+    float tu = fmaf(c.tex_coord[0], h.v, fmaf(b.tex_coord[0], h.u, a.tex_coord[0] * w0));
+    float tv = fmaf(c.tex_coord[1], h.v, fmaf(b.tex_coord[1], h.u, a.tex_coord[1] * w0));
+    float du1 = b.tex_coord[0] - a.tex_coord[0], dv1 = b.tex_coord[1] - a.tex_coord[1];
+    float du2 = c.tex_coord[0] - a.tex_coord[0], dv2 = c.tex_coord[1] - a.tex_coord[1];
+    float uv_area = fabsf(du1 * dv2 - dv1 * du2);
+    float world_area = sqrtf(dot3(gcross, gcross));
+    float cosi = maxf(fabsf(dot3(d, sf.ng)), 0.1f);
+    float foot = h.t * pixel_spread / cosi;
+    float ratio = foot * foot * uv_area / world_area;
+    float lod_base = (ratio > 0.0f && ratio < 3.0e38f) ? 0.5f * log2_approx(ratio) : 0.0f;
+    if (has_base) {
+      C4 t = tex_sample(s, pm.base_color_map_index, tu, tv, tex_lod(s, pm.base_color_map_index, lod_base));
+      sf.base = sf.base * v3(t.x, t.y, t.z);
+    }
+    if (has_em) {
+      C4 t = tex_sample(s, pm.emission_map_index, tu, tv, tex_lod(s, pm.emission_map_index, lod_base));
+      V3 e = ld3(m.emission) * v3(t.x, t.y, t.z);
+      m.emission[0] = e.x; m.emission[1] = e.y; m.emission[2] = e.z;
+    }
+    if (has_mr) {
+      C4 t = tex_sample(s, pm.metallic_roughness_map_index, tu, tv, tex_lod(s, pm.metallic_roughness_map_index, lod_base));
+      m.metallic = m.metallic * t.z;
+      if (pm.type == 1u) {
+        float rl = sqrtf(pm.roughness) * t.y;
+        float r2 = rl * rl;
+        float aspect = sqrtf(1.0f - clampf(pm.anisotropic, 0.0f, 1.0f) * 0.9f);
+        m.roughness = r2;
+        m.ax = maxf(0.001f, r2 / aspect);
+        m.ay = maxf(0.001f, r2 * aspect);
+      }
+    }
+    if (has_nrm) {
+      C4 t = tex_sample(s, pm.normal_map_index, tu, tv, tex_lod(s, pm.normal_map_index, lod_base));
+      V3 tl = madd3(ld3(c.tangent), h.v, madd3(ld3(b.tangent), h.u, ld3(a.tangent) * w0));
+      V3 tw = transform_vector(inst.transform, tl);
+      tw = tw - sf.ns * dot3(sf.ns, tw);
+      float tl2 = dot3(tw, tw);
+      if (tl2 > 0.0f) {
+        tw = tw * (1.0f / sqrtf(tl2));
+        V3 bw = cross3(sf.ns, tw);
+        V3 nts = v3(t.x * 2.0f - 1.0f, t.y * 2.0f - 1.0f, t.z * 2.0f - 1.0f);
+        V3 nn = to_world(nts, tw, bw, sf.ns);
+        float nn2 = dot3(nn, nn);
+        if (nn2 > 0.0f) sf.ns = nn * (1.0f / sqrtf(nn2));
+      }
+    }
+  }
   if (dot3(sf.ns, sf.ng) < 0.0f) sf.ng = -sf.ng;
   if (dot3(sf.ng, d) > 0.0f) { sf.ns = -sf.ns; sf.ng = -sf.ng; }
-  sf.P = madd3(d, h.t, o);
-  sf.mat = &s->materials[inst.material_index];
-  sf.base = ld3(sf.mat->base_color);
   return sf;
 }
 
@@ -452,9 +555,9 @@ static PixelOut trace_path(const Frame& f, uint32_t px, uint32_t py, uint32_t fr
       if (depth == 0) out.albedo = v3(minf(env.x, 1.0f), minf(env.y, 1.0f), minf(env.z, 1.0f));
       break;
     }
-    Surface sf = make_surface(s, o, d, h);
+    Surface sf = make_surface(s, f.pixel_spread, o, d, h);
     if (depth == 0) { out.albedo = sf.base; out.normal = sf.ns; }
-    V3 em = ld3(sf.mat->emission);
+    V3 em = ld3(sf.m.emission);
     if (em.x > 0.0f || em.y > 0.0f || em.z > 0.0f) L = L + T * em;
     V3 wo = -d;
     // next-event estimation: one light
@@ -464,7 +567,7 @@ static PixelOut trace_path(const Frame& f, uint32_t px, uint32_t py, uint32_t fr
       LightSample ls = sample_light(s->lights[idx], sf.P, r1, r2);
       if (ls.valid) {
         V3 fb; float pdf_b;
-        bsdf_eval(*sf.mat, sf.base, wo, ls.wi, sf.ns, &fb, &pdf_b);
+        bsdf_eval(sf.m, sf.base, wo, ls.wi, sf.ns, &fb, &pdf_b);
         if (pdf_b > 0.0f) {
           float side = dot3(ls.wi, sf.ng) >= 0.0f ? s->ray_eps : -s->ray_eps;
           V3 so = madd3(sf.ng, side, sf.P);
@@ -491,7 +594,7 @@ static PixelOut trace_path(const Frame& f, uint32_t px, uint32_t py, uint32_t fr
       V3 wi; float pdf_e;
       if (env_map_sample(f, r1, r2, &wi, &pdf_e)) {
         V3 fb; float pdf_b;
-        bsdf_eval(*sf.mat, sf.base, wo, wi, sf.ns, &fb, &pdf_b);
+        bsdf_eval(sf.m, sf.base, wo, wi, sf.ns, &fb, &pdf_b);
         if (pdf_b > 0.0f) {
           float side = dot3(wi, sf.ng) >= 0.0f ? s->ray_eps : -s->ray_eps;
           V3 so = madd3(sf.ng, side, sf.P);
@@ -509,7 +612,7 @@ static PixelOut trace_path(const Frame& f, uint32_t px, uint32_t py, uint32_t fr
     // continue the path
     float r1 = rng_next(&rng), r2 = rng_next(&rng), r3 = rng_next(&rng);
     V3 wi, fb; float pdf_b;
-    if (!bsdf_sample(*sf.mat, sf.base, wo, sf.ns, r1, r2, r3, &wi, &fb, &pdf_b)) break;
+    if (!bsdf_sample(sf.m, sf.base, wo, sf.ns, r1, r2, r3, &wi, &fb, &pdf_b)) break;
     T = T * fb * (fabsf(dot3(sf.ns, wi)) / pdf_b);
     prev_pdf = pdf_b;
     if (depth >= f.p.rr_depth) {
@@ -547,6 +650,7 @@ static Frame make_frame(const orc_scene* s, const orc_render_params* p) {
   float sn, cs;
   sincos_rad(0.5f * s->cameras[0].yfov, &sn, &cs);
   f.tan_half = sn / cs;
+  f.pixel_spread = 2.0f * f.tan_half / f.res_h;
   f.env_rotation = p->env_rotation_degrees / 360.0f;
   f.env_type = s->env.width > 0 ? 1u : 0u;
   return f;
@@ -602,6 +706,23 @@ extern "C" void orc_generate_camera_rays(const orc_scene* s, uint32_t width, uin
       r.origin[0] = o.x; r.origin[1] = o.y; r.origin[2] = o.z; r.tmin = 0.0f;
       r.direction[0] = d.x; r.direction[1] = d.y; r.direction[2] = d.z; r.tmax = kTMax;
     }
+}
+
+extern "C" int orc_scene_texture_info(const orc_scene* s, uint32_t tex, uint32_t* w, uint32_t* h, uint32_t* mips) {
+  if (tex >= s->texture_image.size()) return 1;
+  const Image& img = s->images[s->texture_image[tex]];
+  *w = img.width; *h = img.height; *mips = img.mips;
+  return 0;
+}
+extern "C" void orc_scene_texture_level(const orc_scene* s, uint32_t tex, uint32_t level, float* out) {
+  const std::vector<float>& l = s->images[s->texture_image[tex]].levels[level];
+  memcpy(out, l.data(), l.size() * sizeof(float));
+}
+extern "C" void orc_scene_sample_texture(const orc_scene* s, uint32_t tex, const float* uvl, uint32_t n, float* out) {
+  for (uint32_t i = 0; i < n; ++i) {
+    C4 c = tex_sample(s, tex, uvl[3 * i], uvl[3 * i + 1], uvl[3 * i + 2]);
+    out[4 * i] = c.x; out[4 * i + 1] = c.y; out[4 * i + 2] = c.z; out[4 * i + 3] = c.w;
+  }
 }
 
 extern "C" void orc_tile_assignment(uint32_t tiles_x, uint32_t tiles_y, uint32_t world, uint32_t* owner, uint32_t* slot) {

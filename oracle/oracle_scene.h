@@ -34,6 +34,12 @@ struct Instance {
   const uint32_t* indices;
 };
 
+// RENDER_SPEC §7.4: one image decoded to linear RGBA32F with its full 2x2-box mip chain
+struct Image {
+  uint32_t width = 0, height = 0, mips = 0;
+  std::vector<std::vector<float>> levels;  // RGBA32F per level
+};
+
 struct EnvMap {
   uint32_t width = 0, height = 0;
   std::vector<float> pixels;  // RGBA32F
@@ -59,6 +65,8 @@ struct orc_scene {
   std::vector<std::vector<orc_vertex>> owned_vertices;
   std::vector<std::vector<uint32_t>> owned_indices;
   orc::EnvMap env;
+  std::vector<orc::Image> images;       // per cpu::HalaImageData
+  std::vector<uint32_t> texture_image;  // texture index -> image (gpu_uploader.rs:336-338)
 };
 
 namespace orc {

@@ -185,6 +185,23 @@ class OracleScene:
         lib().orc_trace_rays(self._h, C.c_void_p(rays.ctypes.data), C.c_void_p(hits.ctypes.data), C.c_uint32(rays.shape[0]), C.c_int(mode), ctr)
         return (hits, (ctr[0], ctr[1])) if count_steps else hits
 
+    def texture_info(self, tex):
+        w, h, m = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        assert lib().orc_scene_texture_info(self._h, C.c_uint32(tex), C.byref(w), C.byref(h), C.byref(m)) == 0
+        return w.value, h.value, m.value
+
+    def texture_level(self, tex, level):
+        w, h, _ = self.texture_info(tex)
+        out = np.empty((max(1, h >> level), max(1, w >> level), 4), dtype=np.float32)
+        lib().orc_scene_texture_level(self._h, C.c_uint32(tex), C.c_uint32(level), fptr(out))
+        return out
+
+    def sample_texture(self, tex, uv_lod):
+        q = np.ascontiguousarray(uv_lod, dtype=np.float32).reshape(-1, 3)
+        out = np.empty((q.shape[0], 4), dtype=np.float32)
+        lib().orc_scene_sample_texture(self._h, C.c_uint32(tex), fptr(q), C.c_uint32(q.shape[0]), fptr(out))
+        return out
+
     def camera_rays(self, width, height, frame_index=0):
         rays = np.empty(width * height, dtype=A.RAY_DTYPE)
         lib().orc_generate_camera_rays(self._h, C.c_uint32(width), C.c_uint32(height), C.c_uint32(frame_index), C.c_void_p(rays.ctypes.data))

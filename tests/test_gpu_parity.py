@@ -364,6 +364,42 @@ def test_render_disney_materials_bit_exact(halart, oracle):
     r.close()
 
 
+def test_textures_mips_fetch_and_render_bit_exact(halart, oracle):
+    """K8 / A6 / A14: upload + GPU mip chain + software trilinear REPEAT fetch + the four material maps"""
+    from test_oracle_render import textured_scene
+    s = textured_scene(size=64, fmt_variant=True)
+    r = make_renderer(halart, s, 72, 72)
+    osc = oracle.OracleScene(s)
+    rng = np.random.RandomState(3)
+    for tex in range(8):
+        assert r.texture_info(tex) == osc.texture_info(tex)
+        for level in range(r.texture_info(tex)[2]):
+            assert r.read_texture_level(tex, level).tobytes() == osc.texture_level(tex, level).tobytes(), (tex, level)
+        q = np.concatenate([(rng.rand(3000, 2) * 4 - 1.5), rng.rand(3000, 1) * 9 - 1], 1).astype(f32)
+        assert r.sample_texture(tex, q).tobytes() == osc.sample_texture(tex, q).tobytes()
+    r.update_batch(3); r.render()
+    imgs, _ = osc.render(72, 72, frames=3)
+    assert_images_equal(r, imgs)
+    r.close()
+    # the atrium with 16 textures on DISNEY + DIFFUSE materials under instancing
+    s = scenes.attach_textures(scenes.sponza_class(target_triangles=30000, aspect=96 / 54), sets=5, size=128)
+    assert len(s.image_data) >= 15
+    r = make_renderer(halart, s, 96, 54)
+    r.update_batch(2); r.render()
+    imgs, _ = oracle.OracleScene(s).render(96, 54, frames=2)
+    assert_images_equal(r, imgs)
+    r.close()
+
+
+def test_texture_errors(halart):
+    s = scenes.cornell_box()
+    s.texture2image_mapping[0] = 5  # image 5 does not exist
+    r = halart.HalaRenderer("tex", 16, 16, 2, 1, False, False, False, 0)
+    with pytest.raises(halart.HalaRendererError, match="The image 5 is not found."):  # gpu_uploader.rs:337
+        r.set_scene(s)
+    r.close()
+
+
 def test_render_orthographic_and_thin_lens(halart, oracle):
     s = scenes.cornell_box()
     s.cameras = [H.HalaOrthographicCamera(xmag=300.0, ymag=300.0)]

@@ -176,6 +176,94 @@ def test_env_is_matches_brute_force_mean(oracle):
     assert abs(a[..., :3].mean() - b[..., :3].mean()) / b[..., :3].mean() < 0.05
 
 
+def textured_scene(size=64, disney=True, fmt_variant=False):
+    """Cornell-like room with textured (base colour + normal + metallic-roughness) blocks and an emissive-mapped wall"""
+    s = scenes.cornell_box()
+    if disney:
+        for m in s.materials[:3] + s.materials[4:]:
+            m.type = 1; m.metallic = 0.5 if m is s.materials[4] else 0.0; m.roughness = 0.6
+    scenes.attach_textures(s, sets=2, size=size, seed=5)
+    rng = np.random.RandomState(9)
+    em = H.HalaImageData(scenes.A_FORMAT_FLOAT, 16, 8, (rng.rand(8, 16, 4) * 2).astype(f32))          # RGBA32F
+    bg = H.HalaImageData(scenes.A_FORMAT_BGRA_TAG, 33, 17, (rng.rand(17, 33, 4) * 255).astype(np.uint8))  # odd size, BGRA-tag quirk
+    for img in (em, bg):
+        k = len(s.image_data)
+        s.image_data.append(img); s.image2data_mapping[k] = k; s.texture2image_mapping[k] = k
+    s.materials[1].emission = (0.4, 0.4, 0.4); s.materials[1].emission_map_index = 6
+    if fmt_variant:
+        s.materials[2].base_color_map_index = 7
+    return s
+
+
+def test_texture_mips_and_fetch_vs_independent_numpy(oracle):
+    s = textured_scene(size=32)
+    osc = oracle.OracleScene(s)
+    for tex in (0, 1, 6, 7):
+        w, h, mips = osc.texture_info(tex)
+        img = s.image_data[tex]
+        assert (w, h) == (img.width, img.height)
+        assert mips == int(np.ceil(np.log2(max(w, h)))) + 1  # gpu_uploader.rs:366
+        # level 0 decode
+        d = np.asarray(img.data)
+        if img.format == scenes.A_FORMAT_FLOAT:
+            l0 = d.astype(f32)
+        else:
+            x = d.astype(np.float64) / 255.0
+            if img.format == scenes.A_FORMAT_SRGB:
+                rgb = np.where(x[..., :3] <= 0.04045, x[..., :3] / 12.92, ((x[..., :3] + 0.055) / 1.055) ** 2.4)
+                l0 = np.concatenate([rgb, x[..., 3:]], -1).astype(f32)
+                l0[..., 3] = (d[..., 3].astype(f32) / f32(255))
+            else:
+                l0 = (d.astype(f32) / f32(255))
+                if img.format == scenes.A_FORMAT_BGRA_TAG:
+                    l0 = l0[..., [2, 1, 0, 3]]
+        got0 = osc.texture_level(tex, 0)
+        assert np.abs(got0 - l0).max() <= 1.2e-7  # sRGB pow(): libm vs numpy, <= 1 ulp
+        # every further level is the 2x2 box filter of the previous one (edge-clamped), bit-exact
+        prev = got0
+        for l in range(1, mips):
+            sh, sw = prev.shape[:2]
+            dh, dw = max(1, h >> l), max(1, w >> l)
+            ys0 = np.minimum(2 * np.arange(dh), sh - 1); ys1 = np.minimum(2 * np.arange(dh) + 1, sh - 1)
+            xs0 = np.minimum(2 * np.arange(dw), sw - 1); xs1 = np.minimum(2 * np.arange(dw) + 1, sw - 1)
+            a, b = prev[ys0][:, xs0], prev[ys0][:, xs1]
+            c, dd = prev[ys1][:, xs0], prev[ys1][:, xs1]
+            exp = ((a + b).astype(f32) + (c + dd).astype(f32)).astype(f32) * f32(0.25)
+            cur = osc.texture_level(tex, l)
+            assert cur.tobytes() == exp.astype(f32).tobytes(), (tex, l)
+            prev = cur
+        # bilinear REPEAT fetch at level 0 against an independent float32 emulation
+        rng = np.random.RandomState(tex)
+        uv = (rng.rand(200, 2) * 3 - 1).astype(f32)
+        got = osc.sample_texture(tex, np.concatenate([uv, np.zeros((200, 1), f32)], 1))
+        for k in range(200):
+            x = f32(f32(uv[k, 0] * f32(w)) - f32(0.5)); y = f32(f32(uv[k, 1] * f32(h)) - f32(0.5))
+            x0, y0 = np.floor(x), np.floor(y)
+            fx, fy = f32(x - x0), f32(y - y0)
+            ix0, iy0 = int(x0) % w, int(y0) % h
+            ix1, iy1 = (ix0 + 1) % w, (iy0 + 1) % h
+            gx, gy = f32(f32(1) - fx), f32(f32(1) - fy)
+            top = (got0[iy0, ix0] * gx).astype(f32) + (got0[iy0, ix1] * fx).astype(f32)
+            bot = (got0[iy1, ix0] * gx).astype(f32) + (got0[iy1, ix1] * fx).astype(f32)
+            exp = (top.astype(f32) * gy).astype(f32) + (bot.astype(f32) * fy).astype(f32)
+            assert got[k].tobytes() == exp.astype(f32).tobytes()
+    # trilinear: lod 1.5 = mean of levels 1 and 2; lod beyond the chain clamps to the last level
+    q = np.array([[0.3, 0.6, 1.0], [0.3, 0.6, 2.0], [0.3, 0.6, 1.5], [0.3, 0.6, 99.0], [0.3, 0.6, -3.0], [0.3, 0.6, 0.0]], f32)
+    r = osc.sample_texture(0, q)
+    assert np.array_equal(r[2], (r[0] * f32(0.5) + r[1] * f32(0.5)).astype(f32))
+    assert np.array_equal(r[3], osc.texture_level(0, osc.texture_info(0)[2] - 1)[0, 0]) and np.array_equal(r[4], r[5])
+
+
+def test_textured_render_changes_image_and_is_deterministic(oracle):
+    s = textured_scene(size=32)
+    a = oracle.OracleScene(s).render(40, 40, frames=2)[0]
+    b = oracle.OracleScene(s).render(40, 40, frames=2)[0]
+    plain = scenes.cornell_box()
+    c = oracle.OracleScene(plain).render(40, 40, frames=2)[0]
+    assert a[0].tobytes() == b[0].tobytes() and not np.array_equal(a[0], c[0])
+    assert np.isfinite(a[0]).all() and not np.array_equal(a[2], c[2])  # normal AOV shows the normal maps
+
+
 def test_tile_assignment_is_a_balanced_partition(oracle):
     for tx, ty, world in [(60, 34, 8), (60, 34, 2), (7, 5, 4), (120, 68, 8), (3, 1, 8)]:
         owner, slot = oracle.tile_assignment(tx, ty, world)
