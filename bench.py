@@ -77,13 +77,21 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libhalart has no CPU path")
+    # rehearsal knobs for a 1-GPU box (not used by the driver): BENCH_SINGLE_DEVICE=1 puts every rank on cuda:0 and
+    # BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device) so that the N>1 code path can be exercised
+    if os.environ.get("BENCH_SINGLE_DEVICE"):
+        local_rank = 0
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     kx, ky = grid_for(world)
     W, Hh = BASE_W * kx, BASE_H * ky

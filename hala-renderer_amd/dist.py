@@ -100,7 +100,10 @@ class TileGather:
     def gather(self):
         self.r.wait_idle()  # the renderer works on its own HIP stream
         for _, src, dst, _ in self.bufs:
-            self.dist.all_gather_into_tensor(dst, src, group=self.group)
+            if self.dist.get_backend(self.group) == "gloo":  # rehearsal on a 1-GPU box; same buffer layout
+                self.dist.all_gather(list(dst.view(self.world, -1).unbind(0)), src, group=self.group)
+            else:
+                self.dist.all_gather_into_tensor(dst, src, group=self.group)
         self.torch.cuda.synchronize()
         for which, _, dst, nbytes in self.bufs:
             self.r.scatter_gathered_tiles(which, dst.data_ptr(), nbytes * self.world)

@@ -90,7 +90,9 @@ def main():
         env = scenes.sky_sun_envmap(1024, 512, sun_gain=50.0)
         t0 = time.perf_counter()
         s = scenes.sponza_class(target_triangles=1_000_000)
-        print(json.dumps({"scene_gen_s": round(time.perf_counter() - t0, 1), "triangles": s.triangle_count()}), flush=True)
+        if not os.environ.get("HALART_NO_TEXTURES"):
+            scenes.attach_textures(s, sets=6, size=1024)  # 18 procedural 1024^2 textures: base colour + normal + MR
+        print(json.dumps({"scene_gen_s": round(time.perf_counter() - t0, 1), "triangles": s.triangle_count(), "textures": len(s.image_data)}), flush=True)
         img = run("config4_atrium1M_1080p_4spp", s, 1920, 1080, 4, env=env, steps=2)
         if args.save:
             np.save(os.path.join(args.save, "config4.npy"), img[::2, ::2, :3].astype(np.float16))
