@@ -128,6 +128,13 @@ class HalaScene:
     lights: List[HalaLight] = field(default_factory=list)
     cameras: list = field(default_factory=list)
 
+    @staticmethod
+    def new(path) -> "HalaScene":
+        """cpu::HalaScene::new(path) (src/scene/cpu/scene.rs:40-55): glTF only; world transforms are computed by the
+        library when the scene is handed to set_scene (update_node_hierarchies, :99-114)."""
+        from .gltf_loader import scene_from_file
+        return scene_from_file(path)
+
     # src/scene/cpu/scene.rs:59-95
     def has_light(self) -> bool:
         return len(self.lights) > 0

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""LBVH (GPU builder) vs binned-SAH (oracle's CPU builder): traversal steps per ray on the same rays."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import hala_renderer_amd as H
+from hala_renderer_amd import scenes
+import oracle_lib as O
+for name, s in [("blob82k", scenes.bunny_class(subdivisions=6)), ("atrium250k", scenes.sponza_class(target_triangles=250000, disney=False))]:
+    r = H.HalaRenderer("q", 64, 64, 5, 3, False, False, False, 0)
+    r.set_scene(s); r.commit()
+    nodes, tris = r.download_bvh()
+    osc = O.OracleScene(s)
+    rays = osc.camera_rays(480, 270, 0)
+    hits = osc.trace(rays, 0)
+    ok = hits["prim"] != 0xFFFFFFFF
+    # incoherent secondary rays: from the hit points into random directions
+    rng = np.random.RandomState(0)
+    P = rays["origin"][ok] + rays["direction"][ok] * hits["t"][ok][:, None]
+    d = rng.randn(len(P), 3); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    sec = np.zeros(len(P), dtype=H._abi.RAY_DTYPE)
+    sec["origin"] = P + d * 1e-3; sec["direction"] = d; sec["tmax"] = 3e38
+    for label, rr in (("primary", rays), ("secondary", sec)):
+        _, c_sah = osc.trace(rr, 0, count_steps=True)
+        _, c_lbvh = O.trace_on_bvh(nodes, tris, rr, 0)
+        n = len(rr)
+        print(f"{name} {label}: SAH nodes/ray {c_sah[0]/n:.2f} tris/ray {c_sah[1]/n:.2f} | LBVH nodes/ray {c_lbvh[0]/n:.2f} tris/ray {c_lbvh[1]/n:.2f} | oracle nodes {osc.node_count} gpu nodes {len(nodes)//16}")
+    r.close()

@@ -391,6 +391,22 @@ def test_textures_mips_fetch_and_render_bit_exact(halart, oracle):
     r.close()
 
 
+def test_gltf_scene_renders_like_the_procedural_one(halart, oracle, tmp_path):
+    """config 1's plumbing: cpu::HalaScene::new(path) -> set_scene -> commit -> update, via the glTF mirror"""
+    from gltf_writer import write_gltf
+    s = scenes.cornell_box()
+    scenes.attach_textures(s, sets=1, size=32)
+    write_gltf(s, str(tmp_path / "cornell.gltf"))
+    loaded = halart.HalaScene.new(str(tmp_path / "cornell.gltf"))
+    r = make_renderer(halart, loaded, 48, 48)
+    r.update_batch(2); r.render()
+    imgs, _ = oracle.OracleScene(loaded).render(48, 48, frames=2)
+    assert_images_equal(r, imgs)
+    ref, _ = oracle.OracleScene(s).render(48, 48, frames=2)  # only the QUAD light intensity takes a /(0.5wh) * (0.5wh) round trip
+    assert np.abs(imgs[0] - ref[0]).max() <= 1e-5 * max(1.0, float(ref[0].max()))
+    r.close()
+
+
 def test_texture_errors(halart):
     s = scenes.cornell_box()
     s.texture2image_mapping[0] = 5  # image 5 does not exist
