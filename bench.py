@@ -110,7 +110,9 @@ def main():
     gather = None
     if world > 1:
         from hala_renderer_amd.dist import TileGather
-        gather = TileGather(r, local_rank, aovs=(r.ACCUM, r.ALBEDO, r.NORMAL))
+        # one all-gather per finished frame: the accumulated colour image; albedo/normal are gathered the
+        # same way when save_images needs them (TileGather(aovs=(0, 1, 2)))
+        gather = TileGather(r, local_rank, aovs=(r.ACCUM,))
 
     def step():
         # a frame restarts the accumulation: frame_index 0..SPP-1 (same work every step)
@@ -191,7 +193,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"configs[1]: procedural Cornell box (32 triangles), {W}x{Hh} ({BASE_W}x{BASE_H} pixels per GPU), {SPP} spp, diffuse-only closest hit",
                        "resolution": [W, Hh], "spp": SPP, "max_depth": MAX_DEPTH, "rr_depth": RR_DEPTH,
-                       "parallelism": f"pixel-tile shard {TILE}x{TILE} over {world} rank(s)" + (", RCCL all-gather of 3 AOVs per frame" if world > 1 else ""),
+                       "parallelism": f"pixel-tile shard {TILE}x{TILE} over {world} rank(s)" + (", one RCCL all-gather of the accumulated image per frame" if world > 1 else ""),
                        "rays_per_frame": int(rays_all / args.steps), "ms_per_frame": round(dt_all / args.steps * 1e3, 4)},
             "roofline": {"bound": "hbm", "kernel": "rt::k_trace_batch<false,false> (closest-hit traversal)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -94,6 +94,8 @@ class TileGather:
         for which in aovs:
             ptr, nbytes = renderer.tile_buffer(which)
             src = torch.as_tensor(_DeviceView(ptr, nbytes // 4), device=f"cuda:{device_index}")
+            if src.data_ptr() != ptr:
+                raise RuntimeError("TileGather: torch copied the tile buffer instead of aliasing it")
             dst = torch.empty(self.world * (nbytes // 4), dtype=torch.float32, device=f"cuda:{device_index}")
             self.bufs.append((which, src, dst, nbytes))
 
@@ -105,5 +107,7 @@ class TileGather:
             else:
                 self.dist.all_gather_into_tensor(dst, src, group=self.group)
         self.torch.cuda.synchronize()
+        if self.world == 1:
+            return  # an unsharded frame is already row-major
         for which, _, dst, nbytes in self.bufs:
             self.r.scatter_gathered_tiles(which, dst.data_ptr(), nbytes * self.world)

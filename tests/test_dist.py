@@ -76,6 +76,30 @@ def test_gloo_world2_all_gather_deinterleave():
 
 
 @pytest.mark.gpu
+def test_rccl_all_gather_aliases_library_memory(halart):
+    """the RCCL leg with the ranks this box has (one): TileGather must alias the library's device buffer (no copy) and
+    all_gather_into_tensor must deliver it"""
+    import torch
+    import torch.distributed as dist
+    from hala_renderer_amd.dist import TileGather
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        r = halart.HalaRenderer("rccl", 96, 64, 4, 2, False, False, False, 0)
+        r.set_scene(scenes.cornell_box(aspect=1.5))
+        r.commit()
+        g = TileGather(r, 0, aovs=(r.ACCUM,))
+        r.update_batch(2)
+        g.gather()
+        got = g.bufs[0][2].cpu().numpy().reshape(64, 96, 4)
+        assert np.array_equal(got, r.read_image(r.ACCUM))
+        r.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("world", [2, 8])
 def test_sharded_render_equals_unsharded(halart, world):
     """RNG is keyed by the global pixel id, so the union of the ranks' tiles is bit-identical to a 1-GPU render.
