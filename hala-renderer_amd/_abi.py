@@ -153,7 +153,8 @@ class RtStatistics(C.Structure):
 
 class BvhInfo(C.Structure):
     _fields_ = [("node_count", C.c_uint32), ("triangle_count", C.c_uint32), ("max_depth", C.c_uint32),
-                ("lds_node_count", C.c_uint32), ("scene_min", C.c_float * 3), ("scene_max", C.c_float * 3)]
+                ("lds_node_count", C.c_uint32), ("scene_min", C.c_float * 3), ("scene_max", C.c_float * 3),
+                ("node_width", C.c_uint32)]
 
 
 class RtProgDescInfo(C.Structure):

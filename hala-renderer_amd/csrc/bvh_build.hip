@@ -258,13 +258,96 @@ __global__ void k_emit_single(const Box6* __restrict__ leaf_box, uint32_t n, Bvh
   nodes[0] = nd;
 }
 
+// depth of every kept node (root = 1); is4[i] = kept node on an odd level = root of a 4-wide node: a 4-node is a kept
+// binary node together with its kept children, its own children are the (up to four) grandchildren.  All ancestors of a
+// kept node are kept (triangle counts grow towards the root), so the odd levels tile the kept tree exactly.
 __global__ void __launch_bounds__(256) k_depth(const uint32_t* __restrict__ node_parent, const uint32_t* __restrict__ keep, uint32_t n_internal,
-                                                uint32_t* __restrict__ max_depth) {
+                                                uint32_t* __restrict__ max_depth, uint32_t* __restrict__ is4) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_internal || !keep[i]) return;
+  if (i >= n_internal) return;
+  if (!keep[i]) { is4[i] = 0u; return; }
   uint32_t d = 1, p = node_parent[i];
   while (p != kAbsent) { ++d; p = node_parent[p]; }
+  is4[i] = d & 1u;
   atomicMax(max_depth, d);
+}
+
+// ---- 4-wide compressed emission (RENDER_SPEC §4.1b) ---------------------------------------------------------------
+struct Child4 { Box6 box; uint32_t ref; };
+
+RT_DI uint32_t leaf_ref(uint32_t first, uint32_t count) { return kLeafRef | ((count - 1u) << 28) | first; }
+
+// quantum exponent of one axis: the smallest power of two s = 2^e with extent / s <= 255 (never below 2^-100)
+RT_DI int quantum_exponent(float lo, float hi) {
+  const double q = ((double)hi - (double)lo) / 255.0;
+  if (!(q > 0.0)) return -100;
+  const int e = (int)((__double_as_longlong(q) >> 52) & 0x7ff) - 1022;  // q = m * 2^e, m in [0.5, 1): 2^e > q or m == 0.5
+  return e < -100 ? -100 : (e > 100 ? 100 : e);
+}
+
+RT_DI BvhNode4 pack_node4(const Child4* ch, int n) {
+  BvhNode4 nd{};
+  Box6 all = ch[0].box;
+  for (int c = 1; c < n; ++c) all = box_union(all, ch[c].box);
+  int e[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    nd.pmin[a] = all.mn[a];
+    e[a] = quantum_exponent(all.mn[a], all.mx[a]);
+    nd.exps |= (uint32_t)(e[a] + 127) << (8 * a);
+  }
+  for (int c = 0; c < 4; ++c) {
+    if (c >= n) { nd.ref[c] = kAbsent; continue; }
+    nd.ref[c] = ch[c].ref;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const double s = __longlong_as_double((long long)(e[a] + 1023) << 52), base = (double)all.mn[a];
+      double lo = floor(((double)ch[c].box.mn[a] - base) / s), hi = ceil(((double)ch[c].box.mx[a] - base) / s);
+      if (base + lo * s > (double)ch[c].box.mn[a]) lo -= 1.0;  // rounding of the subtraction must not shrink the box
+      if (base + hi * s < (double)ch[c].box.mx[a]) hi += 1.0;
+      lo = fmin(fmax(lo, 0.0), 255.0); hi = fmin(fmax(hi, 0.0), 255.0);
+      nd.qlo[a] |= (uint32_t)lo << (8 * c);
+      nd.qhi[a] |= (uint32_t)hi << (8 * c);
+    }
+  }
+  return nd;
+}
+
+__global__ void __launch_bounds__(256) k_emit4(const uint32_t* __restrict__ left, const uint32_t* __restrict__ right,
+                                                const uint32_t* __restrict__ first, const uint32_t* __restrict__ last,
+                                                const uint32_t* __restrict__ keep, const uint32_t* __restrict__ is4,
+                                                const uint32_t* __restrict__ index4, const Box6* __restrict__ leaf_box,
+                                                const Box6* __restrict__ node_box, uint32_t n_internal, BvhNode4* __restrict__ nodes) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_internal || !is4[i]) return;
+  Child4 ch[4];
+  int n = 0;
+  auto add = [&](uint32_t r) {  // r: child reference of the binary tree that is not an absorbed kept node
+    if (r & kLeafBit) { ch[n].box = leaf_box[r & ~kLeafBit]; ch[n].ref = leaf_ref(r & ~kLeafBit, 1u); }
+    else if (!keep[r]) { ch[n].box = node_box[r]; ch[n].ref = leaf_ref(first[r], last[r] - first[r] + 1u); }
+    else { ch[n].box = node_box[r]; ch[n].ref = index4[r]; }
+    ++n;
+  };
+  const uint32_t refs[2] = {left[i], right[i]};
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const uint32_t r = refs[c];
+    if (!(r & kLeafBit) && keep[r]) { add(left[r]); add(right[r]); } else add(r);
+  }
+  nodes[index4[i]] = pack_node4(ch, n);
+}
+
+// scene of <= leaf_max triangles: one 4-node with a single leaf child
+__global__ void k_emit_single4(const Box6* __restrict__ leaf_box, uint32_t n, BvhNode4* __restrict__ nodes) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  Child4 ch[1];
+  ch[0].box = Box6{};
+  if (n > 0) {
+    ch[0].box = leaf_box[0];
+    for (uint32_t k = 1; k < n; ++k) ch[0].box = box_union(ch[0].box, leaf_box[k]);
+  }
+  ch[0].ref = n > 0 ? leaf_ref(0u, n) : kAbsent;
+  nodes[0] = pack_node4(ch, 1);
 }
 
 struct DevBuf {
@@ -282,6 +365,7 @@ inline uint32_t nblk(uint32_t n) { return (n + 255u) / 256u; }
 struct BvhTopology {
   uint32_t n = 0, leaf_max = 0;
   DevBuf left, right, first, last, node_parent, leaf_parent, keep, new_index, sorted_ids, tri_box, leaf_box, node_box, arrivals, scene_ord;
+  DevBuf is4, index4;  // 4-wide emission: roots of the 4-nodes and their output indices
 };
 
 static std::string flatten_and_bounds(BvhBuffers& b, BvhTopology& t, hipStream_t s) {
@@ -305,9 +389,11 @@ static std::string fit_and_emit(BvhBuffers& b, BvhTopology& t, hipStream_t s) {
   if (n) hipLaunchKernelGGL(k_leaf_boxes, dim3(nblk(n)), dim3(256), 0, s, t.tri_box.as<Box6>(), t.sorted_ids.as<uint32_t>(), n,
                             t.leaf_box.as<Box6>(), b.tris_by_id, b.tris);
   if (n <= t.leaf_max || n < 2) {
-    hipLaunchKernelGGL(k_emit_single, dim3(1), dim3(64), 0, s, t.leaf_box.as<Box6>(), n, b.nodes);
+    if (b.wide) hipLaunchKernelGGL(k_emit_single4, dim3(1), dim3(64), 0, s, t.leaf_box.as<Box6>(), n, reinterpret_cast<BvhNode4*>(b.nodes));
+    else hipLaunchKernelGGL(k_emit_single, dim3(1), dim3(64), 0, s, t.leaf_box.as<Box6>(), n, b.nodes);
     b.node_count = 1;
     b.max_depth = 1;
+    b.stack_need = 1;
     HIP_TRY(hipStreamSynchronize(s));
     return "";
   }
@@ -315,9 +401,14 @@ static std::string fit_and_emit(BvhBuffers& b, BvhTopology& t, hipStream_t s) {
   HIP_TRY(hipMemsetAsync(t.arrivals.p, 0, (size_t)ni * 4, s));
   hipLaunchKernelGGL(k_fit, dim3(nblk(n)), dim3(256), 0, s, t.left.as<uint32_t>(), t.right.as<uint32_t>(), t.node_parent.as<uint32_t>(),
                      t.leaf_parent.as<uint32_t>(), t.leaf_box.as<Box6>(), t.node_box.as<Box6>(), t.arrivals.as<uint32_t>(), n);
-  hipLaunchKernelGGL(k_emit, dim3(nblk(ni)), dim3(256), 0, s, t.left.as<uint32_t>(), t.right.as<uint32_t>(), t.first.as<uint32_t>(),
-                     t.last.as<uint32_t>(), t.keep.as<uint32_t>(), t.new_index.as<uint32_t>(), t.leaf_box.as<Box6>(), t.node_box.as<Box6>(), ni,
-                     b.nodes);
+  if (b.wide)
+    hipLaunchKernelGGL(k_emit4, dim3(nblk(ni)), dim3(256), 0, s, t.left.as<uint32_t>(), t.right.as<uint32_t>(), t.first.as<uint32_t>(),
+                       t.last.as<uint32_t>(), t.keep.as<uint32_t>(), t.is4.as<uint32_t>(), t.index4.as<uint32_t>(), t.leaf_box.as<Box6>(),
+                       t.node_box.as<Box6>(), ni, reinterpret_cast<BvhNode4*>(b.nodes));
+  else
+    hipLaunchKernelGGL(k_emit, dim3(nblk(ni)), dim3(256), 0, s, t.left.as<uint32_t>(), t.right.as<uint32_t>(), t.first.as<uint32_t>(),
+                       t.last.as<uint32_t>(), t.keep.as<uint32_t>(), t.new_index.as<uint32_t>(), t.leaf_box.as<Box6>(), t.node_box.as<Box6>(), ni,
+                       b.nodes);
   HIP_TRY(hipStreamSynchronize(s));
   HIP_TRY(hipGetLastError());
   return "";
@@ -338,8 +429,9 @@ std::string bvh_build(BvhBuffers& b, uint32_t leaf_max, hipStream_t s) {
   ALLOC(left, ni * 4); ALLOC(right, ni * 4); ALLOC(first, ni * 4); ALLOC(last, ni * 4); ALLOC(node_parent, ni * 4);
   ALLOC(leaf_parent, (size_t)n * 4); ALLOC(keep, ni * 4); ALLOC(new_index, ni * 4); ALLOC(sorted_ids, (size_t)n * 4);
   ALLOC(tri_box, (size_t)n * sizeof(Box6)); ALLOC(leaf_box, (size_t)n * sizeof(Box6)); ALLOC(node_box, ni * sizeof(Box6));
-  ALLOC(arrivals, ni * 4); ALLOC(scene_ord, 6 * 4);
+  ALLOC(arrivals, ni * 4); ALLOC(scene_ord, 6 * 4); ALLOC(is4, ni * 4); ALLOC(index4, ni * 4);
 #undef ALLOC
+  if (b.wide && (leaf_max > 8u || n >= (1u << 28))) return "bvh_build: the 4-wide node format holds leaves of <= 8 triangles and < 2^28 triangles";
   if (!(e = flatten_and_bounds(b, t, s)).empty()) return e;
   if (n >= 2) {
     DevBuf keys_in, keys_out, ids_in, tmp;
@@ -370,15 +462,21 @@ std::string bvh_build(BvhBuffers& b, uint32_t leaf_max, hipStream_t s) {
     DevBuf md;
     if (!(e = md.alloc(4)).empty()) return e;
     HIP_TRY(hipMemsetAsync(md.p, 0, 4, s));
-    hipLaunchKernelGGL(k_depth, dim3(nblk(n - 1)), dim3(256), 0, s, t.node_parent.as<uint32_t>(), t.keep.as<uint32_t>(), n - 1, md.as<uint32_t>());
+    hipLaunchKernelGGL(k_depth, dim3(nblk(n - 1)), dim3(256), 0, s, t.node_parent.as<uint32_t>(), t.keep.as<uint32_t>(), n - 1, md.as<uint32_t>(),
+                       t.is4.as<uint32_t>());
+    HIP_TRY(rocprim::exclusive_scan(tmp2.p, tmp2_bytes, t.is4.as<uint32_t>(), t.index4.as<uint32_t>(), 0u, n - 1, rocprim::plus<uint32_t>(), s));
+    const uint32_t* flag = b.wide ? t.is4.as<uint32_t>() : t.keep.as<uint32_t>();
+    const uint32_t* index = b.wide ? t.index4.as<uint32_t>() : t.new_index.as<uint32_t>();
     uint32_t last_idx = 0, last_keep = 0, depth = 0;
-    HIP_TRY(hipMemcpyAsync(&last_idx, t.new_index.as<uint32_t>() + (n - 2), 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(&last_keep, t.keep.as<uint32_t>() + (n - 2), 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&last_idx, index + (n - 2), 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&last_keep, flag + (n - 2), 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(&depth, md.p, 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     b.node_count = last_idx + last_keep;
-    b.max_depth = depth;
-    if (n <= leaf_max) { b.node_count = 1; b.max_depth = 1; }
+    // a 4-node visit defers at most three siblings, a 2-node visit one
+    if (b.wide) { b.max_depth = (depth + 1u) / 2u; b.stack_need = 3u * b.max_depth; }
+    else { b.max_depth = depth; b.stack_need = depth; }
+    if (n <= leaf_max) { b.node_count = 1; b.max_depth = 1; b.stack_need = 1; }
   } else if (n == 1) {
     static const uint32_t zero = 0;
     HIP_TRY(hipMemcpyAsync(t.sorted_ids.p, &zero, 4, hipMemcpyHostToDevice, s));
@@ -393,9 +491,9 @@ std::string bvh_refit(BvhBuffers& b, hipStream_t s) {
   if (t.n != b.tri_count) return "bvh_refit: triangle count changed, rebuild required";
   std::string e;
   if (!(e = flatten_and_bounds(b, t, s)).empty()) return e;
-  const uint32_t nc = b.node_count, md = b.max_depth;
+  const uint32_t nc = b.node_count, md = b.max_depth, sn = b.stack_need;
   if (!(e = fit_and_emit(b, t, s)).empty()) return e;
-  if (b.tri_count > t.leaf_max && b.tri_count >= 2) { b.node_count = nc; b.max_depth = md; }
+  if (b.tri_count > t.leaf_max && b.tri_count >= 2) { b.node_count = nc; b.max_depth = md; b.stack_need = sn; }
   return "";
 }
 

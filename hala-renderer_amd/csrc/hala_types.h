@@ -39,6 +39,21 @@ struct alignas(16) BvhNode {
 };
 static_assert(sizeof(BvhNode) == 64, "BVH node is 64 B");
 
+// 64-B compressed BVH4 node (RENDER_SPEC §4.1b): up to four children in the bytes of one BVH2 node.  Child boxes are
+// 8-bit quantised against the node's own box: lo = pmin + qlo * 2^e, hi = pmin + qhi * 2^e per axis (lo rounded down,
+// hi rounded up, so the quantised box always contains the true one).  Halves the dependent fetches per ray and the
+// node bytes per ray of the BVH2 format — the two things a latency/gather-bound traversal pays for.
+struct alignas(16) BvhNode4 {
+  float pmin[3];
+  uint32_t exps;     // byte a = biased float exponent of the quantum of axis a: quantum = uint_as_float(byte << 23)
+  uint32_t qlo[3];   // byte c of qlo[a] = quantised low plane of child c on axis a (v_cvt_f32_ubyte{c} unpacks it)
+  uint32_t qhi[3];
+  uint32_t pad[2];
+  uint32_t ref[4];   // 0xffffffff absent | bit31: leaf, bits 30..28 = count-1, bits 27..0 = first triangle | node index
+};
+static_assert(sizeof(BvhNode4) == 64, "BVH4 node is 64 B");
+constexpr uint32_t kLeafRef = 0x80000000u;
+
 // 48-B triangle (RENDER_SPEC §4.1): v0|global id, e1 = v1-v0, e2 = v2-v0 in world space.
 struct alignas(16) Tri {
   float v0[3]; uint32_t id;
@@ -78,6 +93,7 @@ struct SceneView {
   const float* env_conditional;  // set 0 binding 7[1]
   uint32_t node_count, tri_count, lds_nodes, lds_tris;
   float ray_eps;
+  uint32_t wide;  // 0: `nodes` are BvhNode (BVH2); 1: they are BvhNode4
 };
 
 // per-update constants derived on the host from HalaGlobalUniform + camera 0 (RENDER_SPEC §5)

@@ -183,6 +183,7 @@ struct hala_rt_renderer {
     sv.env_pixels = reinterpret_cast<const float*>(d_env.ptr); sv.env_marginal = d_marginal.ptr; sv.env_conditional = d_conditional.ptr;
     sv.node_count = bvh.node_count; sv.tri_count = bvh.tri_count; sv.lds_nodes = lds_nodes; sv.lds_tris = lds_tris;
     sv.ray_eps = ray_eps;
+    sv.wide = bvh.wide;
     return sv;
   }
   Queues queues() const {
@@ -371,7 +372,7 @@ int configure_traversal(hala_rt_renderer* r) {
   if (nb + tb <= kLdsStageBudget) { r->lds_nodes = r->bvh.node_count; r->lds_tris = r->bvh.tri_count; }
   else { r->lds_nodes = (uint32_t)std::min<size_t>(r->bvh.node_count, partial / 64); r->lds_tris = 0; }
   const size_t smem = (size_t)r->lds_nodes * 64 + (size_t)r->lds_tris * 48 + traverse_stack_bytes();
-  uint32_t per_cu = traverse_blocks_per_cu(smem);
+  uint32_t per_cu = traverse_blocks_per_cu(smem, r->bvh.wide != 0);
   if (per_cu == 0) RT_FAIL("The traversal kernel does not fit on a compute unit with the requested LDS staging.");
   per_cu = std::min(per_cu, 8u);
   r->lcfg.persistent_blocks = r->cu_count * per_cu;
@@ -380,8 +381,8 @@ int configure_traversal(hala_rt_renderer* r) {
   // refilling once half the wave is idle is best when node fetches go to L2 / Infinity Cache
   r->lcfg.refill = (r->lds_nodes == r->bvh.node_count) ? 64u : kRefillThreshold;
   if (const char* e = getenv("HALART_REFILL")) r->lcfg.refill = std::min(64u, std::max(1u, (uint32_t)strtoul(e, nullptr, 10)));  // tuning knob
-  if (r->bvh.max_depth > traverse_stack_lds_levels()) {
-    if (r->bvh.max_depth > traverse_stack_lds_levels() + traverse_stack_spill_levels())
+  if (r->bvh.stack_need > traverse_stack_lds_levels()) {
+    if (r->bvh.stack_need > traverse_stack_lds_levels() + traverse_stack_spill_levels())
       RT_FAIL("The BVH is deeper than the traversal stack supports (" + std::to_string(r->bvh.max_depth) + " levels).");
     RT_HIP(r->d_spill.resize((size_t)r->lcfg.persistent_blocks * 256 * traverse_stack_spill_levels()));
     r->lcfg.spill = r->d_spill.ptr;
@@ -398,6 +399,8 @@ int build_bvh(hala_rt_renderer* r) {
   r->bvh.primitives = r->d_instances.ptr; r->bvh.inst_first_tri = r->d_inst_first_tri.ptr;
   r->bvh.instance_count = (uint32_t)r->hs.instances.size(); r->bvh.tri_count = n;
   r->bvh.tris_by_id = r->d_tris_by_id.ptr; r->bvh.tris = r->d_tris.ptr; r->bvh.tri_instance = r->d_tri_instance.ptr; r->bvh.nodes = r->d_nodes.ptr;
+  r->bvh.wide = 1;
+  if (const char* e = getenv("HALART_BVH_WIDTH")) r->bvh.wide = atoi(e) == 2 ? 0u : 1u;  // 2: plain BVH2 nodes (A/B knob), default compressed BVH4
   const std::string e = bvh_build(r->bvh, kLeafMax, r->stream);
   if (!e.empty()) RT_FAIL(e);
   return configure_traversal(r);
@@ -890,6 +893,7 @@ int hala_rt_get_bvh_info(hala_rt_renderer* r, hala_bvh_info* out) {
   if (!r || !out) RT_FAIL("The renderer handle is null!");
   if (!r->committed) RT_FAIL("The top level acceleration structure is none!");
   out->node_count = r->bvh.node_count; out->triangle_count = r->bvh.tri_count; out->max_depth = r->bvh.max_depth; out->lds_node_count = r->lds_nodes;
+  out->node_width = r->bvh.wide ? 4u : 2u;
   memcpy(out->scene_min, r->bvh.scene_min, 12); memcpy(out->scene_max, r->bvh.scene_max, 12);
   return HALA_OK;
 }

@@ -190,6 +190,126 @@ RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint32_t* spil
   return false;
 }
 
+// ---- §4.4b: the same state machine over 64-B compressed BVH4 nodes ------------------------------------------------
+RT_DI float ubyte_f32(uint32_t w, int c) { return (float)((w >> (8 * c)) & 0xffu); }  // v_cvt_f32_ubyte{c}
+RT_DI void sort2(uint32_t& a, uint32_t& b) { const uint32_t lo = min(a, b), hi = max(a, b); a = lo; b = hi; }
+
+// closest-hit / any-hit test of one leaf (count <= 8 triangles from `first`, storage order, fetched in pairs)
+template <bool ANY>
+RT_DI bool leaf_test(const SceneView& sv, const TraverseLds& lds, const RayPre& r, float tmax, HitRec& best, uint32_t first, uint32_t count) {
+  const float4* gtris = reinterpret_cast<const float4*>(sv.tris);
+  for (uint32_t i = 0; i < count; i += 2u) {
+    const uint32_t ti = first + i;
+    const bool two = i + 1u < count;
+    float4 a0, b0, c0, a1, b1, c1;
+    if (ti < sv.lds_tris) {
+      const float4* p = lds.tris + (size_t)ti * 3;
+      a0 = p[0]; b0 = p[1]; c0 = p[2];
+      if (two) { a1 = p[3]; b1 = p[4]; c1 = p[5]; }
+    } else {
+      const float4* p = gtris + (size_t)ti * 3;
+      a0 = p[0]; b0 = p[1]; c0 = p[2];
+      if (two) { a1 = p[3]; b1 = p[4]; c1 = p[5]; }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (j == 1 && !two) break;
+      const float4 a = j ? a1 : a0, b = j ? b1 : b0, c = j ? c1 : c0;
+      float t, u, v;
+      if (!tri_test(r, a, b, c, &t, &u, &v)) continue;
+      const uint32_t id = __float_as_uint(a.w);
+      if (ANY) {
+        if (t > r.tmin && t < tmax) { best.t = t; best.u = u; best.v = v; best.prim = id; return true; }
+      } else if (t > r.tmin && (t < best.t || (t == best.t && id < best.prim))) {
+        best.t = t; best.u = u; best.v = v; best.prim = id;
+      }
+    }
+  }
+  return false;
+}
+
+template <bool ANY, bool COUNT>
+RT_DI bool trav_step4(const SceneView& sv, const TraverseLds& lds, uint32_t* spill, Trav& t, uint32_t& n_nodes, uint32_t& n_tris) {
+  const float4* gnodes = reinterpret_cast<const float4*>(sv.nodes);
+  uint32_t* stack = lds.stack + threadIdx.x;
+  const RayPre& r = t.r;
+  HitRec& best = t.best;
+  const uint32_t cur = t.cur;
+  int sp = t.sp;
+  float4 q0, q1, q2, q3;
+  if (cur < sv.lds_nodes) {
+    const float4* p = lds.nodes + (size_t)cur * 4;
+    q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
+  } else {
+    const float4* p = gnodes + (size_t)cur * 4;
+    q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
+  }
+  if (COUNT) n_nodes++;
+  // plane distances without materialising the planes: t = q * (2^e * idir) + (pmin * idir - o * idir)
+  const uint32_t ex = __float_as_uint(q0.w);
+  const float kx = __uint_as_float((ex & 0xffu) << 23) * r.idir.x, ky = __uint_as_float(((ex >> 8) & 0xffu) << 23) * r.idir.y,
+              kz = __uint_as_float(((ex >> 16) & 0xffu) << 23) * r.idir.z;
+  const float ax = __fmaf_rn(q0.x, r.idir.x, -r.ood.x), ay = __fmaf_rn(q0.y, r.idir.y, -r.ood.y), az = __fmaf_rn(q0.z, r.idir.z, -r.ood.z);
+  const uint32_t lox = __float_as_uint(q1.x), loy = __float_as_uint(q1.y), loz = __float_as_uint(q1.z);
+  const uint32_t hix = __float_as_uint(q1.w), hiy = __float_as_uint(q2.x), hiz = __float_as_uint(q2.y);
+  const uint32_t ref[4] = {__float_as_uint(q3.x), __float_as_uint(q3.y), __float_as_uint(q3.z), __float_as_uint(q3.w)};
+  // ordering key: entry distance with the child slot in its two low mantissa bits (ties -> lower slot); misses sort last
+  uint32_t key[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float x0 = __fmaf_rn(ubyte_f32(lox, c), kx, ax), x1 = __fmaf_rn(ubyte_f32(hix, c), kx, ax);
+    const float y0 = __fmaf_rn(ubyte_f32(loy, c), ky, ay), y1 = __fmaf_rn(ubyte_f32(hiy, c), ky, ay);
+    const float z0 = __fmaf_rn(ubyte_f32(loz, c), kz, az), z1 = __fmaf_rn(ubyte_f32(hiz, c), kz, az);
+    const float tn = maxf(maxf(minf(x0, x1), minf(y0, y1)), maxf(minf(z0, z1), r.tmin));
+    const float tf = minf(minf(maxf(x0, x1), maxf(y0, y1)), minf(maxf(z0, z1), best.t));
+    const bool hit = ref[c] != kAbsent && tn <= tf * 1.0000004f;
+    key[c] = hit ? ((__float_as_uint(maxf(tn, 0.0f)) & ~3u) | (uint32_t)c) : 0xffffffffu;
+  }
+  sort2(key[0], key[1]); sort2(key[2], key[3]); sort2(key[0], key[2]); sort2(key[1], key[3]); sort2(key[1], key[2]);
+  // leaves first, nearest first (each one can shrink best.t for the ones after it) ...
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (key[k] == 0xffffffffu) break;
+    const uint32_t slot = key[k] & 3u;
+    const uint32_t rf = slot == 0u ? ref[0] : (slot == 1u ? ref[1] : (slot == 2u ? ref[2] : ref[3]));
+    if (!(rf & kLeafRef)) continue;
+    if (!(__uint_as_float(key[k] & ~3u) <= best.t)) continue;
+    const uint32_t count = ((rf >> 28) & 7u) + 1u;
+    if (COUNT) n_tris += count;
+    if (leaf_test<ANY>(sv, lds, r, t.tmax, best, rf & 0x0fffffffu, count)) return true;
+  }
+  // ... then the inner children still in reach, farthest pushed first so that the nearest is visited next
+  uint32_t next = kAbsent;
+#pragma unroll
+  for (int k = 3; k >= 0; --k) {
+    if (key[k] == 0xffffffffu) continue;
+    const uint32_t slot = key[k] & 3u;
+    const uint32_t rf = slot == 0u ? ref[0] : (slot == 1u ? ref[1] : (slot == 2u ? ref[2] : ref[3]));
+    if (rf & kLeafRef) continue;
+    if (!(__uint_as_float(key[k] & ~3u) <= best.t)) continue;
+    if (next != kAbsent) {
+      if (sp < kStackLds) stack[sp * kTraverseThreads] = next; else spill[sp - kStackLds] = next;
+      ++sp;
+    }
+    next = rf;
+  }
+  if (next == kAbsent) {
+    if (sp == 0) return true;
+    --sp;
+    next = sp < kStackLds ? stack[sp * kTraverseThreads] : spill[sp - kStackLds];
+  }
+  t.cur = next;
+  t.sp = sp;
+  return false;
+}
+
+// one node visit in whichever node format the scene was built with (uniform branch)
+template <bool ANY, bool COUNT, bool WIDE>
+RT_DI bool trav_visit(const SceneView& sv, const TraverseLds& lds, uint32_t* spill, Trav& t, uint32_t& n_nodes, uint32_t& n_tris) {
+  if (WIDE) return trav_step4<ANY, COUNT>(sv, lds, spill, t, n_nodes, n_tris);
+  return trav_step<ANY, COUNT>(sv, lds, spill, t, n_nodes, n_tris);
+}
+
 // whole-ray form (one lane runs its ray to completion)
 template <bool ANY, bool COUNT>
 RT_DI bool traverse(const SceneView& sv, const TraverseLds& lds, uint32_t* spill, const RayPre& r, float tmax, HitRec& best,

@@ -433,7 +433,9 @@ int hala_rt_trace_rays_indirect(hala_rt_renderer* r, const hala_ray* d_rays, hal
 int hala_rt_trace_rays_host(hala_rt_renderer* r, const hala_ray* rays, hala_hit* hits, uint32_t count,
                             int mode, uint64_t counters[2]);
 
-/* BVH introspection for the oracle cross-check: 64-B nodes + 48-B triangles as laid out in HBM. */
+/* BVH introspection for the oracle cross-check: 64-B nodes + 48-B triangles as laid out in HBM.
+ * node_width 4: compressed 4-wide nodes (docs/RENDER_SPEC.md §4.1b, the default); 2: BVH2 nodes (§4.1,
+ * HALART_BVH_WIDTH=2). */
 typedef struct hala_bvh_info {
   uint32_t node_count;
   uint32_t triangle_count;
@@ -441,6 +443,7 @@ typedef struct hala_bvh_info {
   uint32_t lds_node_count; /* nodes staged in LDS by the traversal kernel */
   float scene_min[3];
   float scene_max[3];
+  uint32_t node_width;
 } hala_bvh_info;
 int hala_rt_get_bvh_info(hala_rt_renderer* r, hala_bvh_info* out);
 int hala_rt_download_bvh(hala_rt_renderer* r, void* nodes_64B, void* triangles_48B);

@@ -150,6 +150,11 @@ void orc_trace_rays_on_bvh(const void* nodes64, uint32_t node_count, const void*
 // triangles, no cycles. Returns 0 if valid, else a non-zero code; *max_depth receives the tree depth.
 int orc_validate_bvh(const void* nodes64, uint32_t node_count, const void* tris48, uint32_t tri_count,
                      const float* ref_triangles9, uint32_t* max_depth);
+/* the same two checks for the product's compressed 4-wide node format (RENDER_SPEC §4.1b / §4.4b) */
+void orc_trace_rays_on_bvh4(const void* nodes64, uint32_t node_count, const void* tris48, uint32_t tri_count,
+                            const orc_ray* rays, orc_hit* hits, uint32_t count, int mode, uint64_t* counters);
+int orc_validate_bvh4(const void* nodes64, uint32_t node_count, const void* tris48, uint32_t tri_count,
+                      const float* ref9, uint32_t* max_depth);
 
 // ---- the integrator (RENDER_SPEC §5-§8) ------------------------------------------------------------------------
 typedef struct {

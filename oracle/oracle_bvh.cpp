@@ -357,6 +357,78 @@ static inline bool traverse(const Node* nodes, const Tri* tris, const RayPre& r,
   return best->prim != ORC_NONE;
 }
 
+// RENDER_SPEC §4.4b: the same traversal over compressed 4-wide nodes.
+static inline float bits_f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline uint32_t f_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+template <bool ANY>
+static inline bool leaf_test(const Tri* tris, const RayPre& r, float tmax, Hit* best, uint32_t first, uint32_t count) {
+  for (uint32_t i = 0; i < count; ++i) {
+    const Tri& tr = tris[first + i];
+    float t, u, v;
+    if (!tri_test(r, tr, &t, &u, &v)) continue;
+    if (ANY) {
+      if (t > r.tmin && t < tmax) { best->t = t; best->prim = tr.id; best->u = u; best->v = v; return true; }
+    } else if (t > r.tmin && (t < best->t || (t == best->t && tr.id < best->prim))) {
+      best->t = t; best->u = u; best->v = v; best->prim = tr.id;
+    }
+  }
+  return false;
+}
+
+template <bool ANY>
+static inline bool traverse4(const Node4* nodes, const Tri* tris, const RayPre& r, float tmax, Hit* best, Counters* c) {
+  best->t = tmax; best->prim = ORC_NONE; best->u = 0.0f; best->v = 0.0f;
+  uint32_t stack[1024]; int sp = 0;
+  uint32_t cur = 0;
+  for (;;) {
+    const Node4& n = nodes[cur];
+    if (c) c->nodes++;
+    const float idir[3] = {r.idir.x, r.idir.y, r.idir.z}, ood[3] = {r.ood.x, r.ood.y, r.ood.z};
+    float k[3], adj[3];
+    for (int a = 0; a < 3; ++a) {
+      k[a] = bits_f(((n.exps >> (8 * a)) & 0xffu) << 23) * idir[a];
+      adj[a] = fmaf(n.pmin[a], idir[a], -ood[a]);
+    }
+    uint32_t key[4];
+    for (int ci = 0; ci < 4; ++ci) {
+      float t0[3], t1[3];
+      for (int a = 0; a < 3; ++a) {
+        t0[a] = fmaf((float)((n.qlo[a] >> (8 * ci)) & 0xffu), k[a], adj[a]);
+        t1[a] = fmaf((float)((n.qhi[a] >> (8 * ci)) & 0xffu), k[a], adj[a]);
+      }
+      float tn = maxf(maxf(minf(t0[0], t1[0]), minf(t0[1], t1[1])), maxf(minf(t0[2], t1[2]), r.tmin));
+      float tf = minf(minf(maxf(t0[0], t1[0]), maxf(t0[1], t1[1])), minf(maxf(t0[2], t1[2]), best->t));
+      bool hit = n.ref[ci] != kAbsent && tn <= tf * 1.0000004f;
+      key[ci] = hit ? ((f_bits(maxf(tn, 0.0f)) & ~3u) | (uint32_t)ci) : 0xffffffffu;
+    }
+    std::sort(key, key + 4);
+    for (int i = 0; i < 4 && key[i] != 0xffffffffu; ++i) {  // leaves, nearest first
+      uint32_t rf = n.ref[key[i] & 3u];
+      if (!(rf & 0x80000000u)) continue;
+      if (!(bits_f(key[i] & ~3u) <= best->t)) continue;
+      uint32_t count = ((rf >> 28) & 7u) + 1u;
+      if (c) c->tris += count;
+      if (leaf_test<ANY>(tris, r, tmax, best, rf & 0x0fffffffu, count)) return true;
+    }
+    uint32_t next = kAbsent;
+    for (int i = 3; i >= 0; --i) {  // inner children still in reach, farthest pushed first
+      if (key[i] == 0xffffffffu) continue;
+      uint32_t rf = n.ref[key[i] & 3u];
+      if (rf & 0x80000000u) continue;
+      if (!(bits_f(key[i] & ~3u) <= best->t)) continue;
+      if (next != kAbsent) stack[sp++] = next;
+      next = rf;
+    }
+    if (next == kAbsent) {
+      if (sp == 0) break;
+      next = stack[--sp];
+    }
+    cur = next;
+  }
+  return best->prim != ORC_NONE;
+}
+
 Hit trace_closest(const Node* nodes, const Tri* tris, V3 o, V3 d, float tmin, float tmax, Counters* c) {
   RayPre r = make_ray(o, d, tmin);
   Hit h;
@@ -395,6 +467,28 @@ extern "C" void orc_trace_rays(const orc_scene* s, const orc_ray* rays, orc_hit*
 extern "C" void orc_trace_rays_on_bvh(const void* nodes64, uint32_t, const void* tris48, uint32_t, const orc_ray* rays,
                                       orc_hit* hits, uint32_t count, int mode, uint64_t* counters) {
   trace_batch((const Node*)nodes64, (const Tri*)tris48, rays, hits, count, mode, counters);
+}
+
+extern "C" void orc_trace_rays_on_bvh4(const void* nodes64, uint32_t, const void* tris48, uint32_t, const orc_ray* rays,
+                                       orc_hit* hits, uint32_t count, int mode, uint64_t* counters) {
+  const Node4* nodes = (const Node4*)nodes64;
+  const Tri* tris = (const Tri*)tris48;
+  uint64_t cn = 0, ct = 0;
+#pragma omp parallel for schedule(dynamic, 4096) reduction(+ : cn, ct)
+  for (int64_t i = 0; i < (int64_t)count; ++i) {
+    const orc_ray& ry = rays[i];
+    Counters c;
+    RayPre r = make_ray(v3(ry.origin[0], ry.origin[1], ry.origin[2]), v3(ry.direction[0], ry.direction[1], ry.direction[2]), ry.tmin);
+    Hit h;
+    if (mode == 0) {
+      if (traverse4<false>(nodes, tris, r, ry.tmax, &h, &c)) hits[i] = orc_hit{h.t, h.u, h.v, h.prim};
+      else hits[i] = orc_hit{-1.0f, 0.0f, 0.0f, ORC_NONE};
+    } else {
+      hits[i] = orc_hit{traverse4<true>(nodes, tris, r, ry.tmax, &h, &c) ? 1.0f : -1.0f, 0.0f, 0.0f, ORC_NONE};
+    }
+    cn += c.nodes; ct += c.tris;
+  }
+  if (counters) { counters[0] += cn; counters[1] += ct; }
 }
 
 extern "C" void orc_trace_rays_brute(const orc_scene* s, const orc_ray* rays, orc_hit* hits, uint32_t count, int mode) {
@@ -473,6 +567,85 @@ extern "C" int orc_validate_bvh(const void* nodes64, uint32_t node_count, const 
           for (int c = 0; c < 3; ++c) {
             const float* pv = ref9 ? ref9 + 9 * (size_t)tr.id + 3 * c : v[c];
             for (int k = 0; k < 3; ++k) if (pv[k] < mn[k] || pv[k] > mx[k]) return 9;
+          }
+        }
+      }
+    }
+  }
+  for (uint32_t i = 0; i < tri_count; ++i) if (!seen_tri[i]) return 10;
+  if (max_depth) *max_depth = md;
+  return 0;
+}
+
+// the same for compressed 4-wide nodes: every child's DEQUANTISED box (evaluated in double, i.e. exactly) must contain
+// what hangs below it — the triangles of a leaf, the dequantised child boxes of an inner node
+extern "C" int orc_validate_bvh4(const void* nodes64, uint32_t node_count, const void* tris48, uint32_t tri_count,
+                                 const float* ref9, uint32_t* max_depth) {
+  const Node4* nodes = (const Node4*)nodes64;
+  const Tri* tris = (const Tri*)tris48;
+  if (max_depth) *max_depth = 0;
+  if (node_count == 0) return 1;
+  auto child_box = [&](const Node4& n, int ci, double* mn, double* mx) {
+    for (int a = 0; a < 3; ++a) {
+      const int e = (int)((n.exps >> (8 * a)) & 0xffu) - 127;
+      const double s = std::ldexp(1.0, e);
+      mn[a] = (double)n.pmin[a] + (double)((n.qlo[a] >> (8 * ci)) & 0xffu) * s;
+      mx[a] = (double)n.pmin[a] + (double)((n.qhi[a] >> (8 * ci)) & 0xffu) * s;
+    }
+  };
+  std::vector<uint8_t> seen_tri(tri_count, 0), seen_node(node_count, 0), seen_slot(tri_count, 0);
+  struct Item { uint32_t node, depth; };
+  std::vector<Item> st{{0, 1}};
+  uint32_t md = 0;
+  while (!st.empty()) {
+    Item it = st.back(); st.pop_back();
+    if (it.node >= node_count) return 2;
+    if (seen_node[it.node]) return 3;
+    seen_node[it.node] = 1;
+    md = std::max(md, it.depth);
+    const Node4& n = nodes[it.node];
+    for (int ci = 0; ci < 4; ++ci) {
+      const uint32_t rf = n.ref[ci];
+      if (rf == kAbsent) continue;
+      double mn[3], mx[3];
+      child_box(n, ci, mn, mx);
+      if (!(rf & 0x80000000u)) {
+        if (rf >= node_count) return 2;
+        const Node4& cn = nodes[rf];
+        for (int cj = 0; cj < 4; ++cj) {
+          if (cn.ref[cj] == kAbsent) continue;
+          double gmn[3], gmx[3];
+          child_box(cn, cj, gmn, gmx);
+          // a grandchild box is quantised against ITS parent's origin, so it may stick out of this (also quantised) box
+          // by less than one quantum of the child node; what must hold exactly is containment of the geometry (below)
+          for (int a = 0; a < 3; ++a) {
+            const double q = std::ldexp(1.0, (int)((cn.exps >> (8 * a)) & 0xffu) - 127);
+            if (gmn[a] < mn[a] - q || gmx[a] > mx[a] + q) return 4;
+          }
+        }
+        st.push_back({rf, it.depth + 1});
+      } else {
+        const uint32_t first = rf & 0x0fffffffu, count = ((rf >> 28) & 7u) + 1u;
+        if ((uint64_t)first + count > tri_count) return 5;
+        for (uint32_t i = 0; i < count; ++i) {
+          if (seen_slot[first + i]) return 6;
+          seen_slot[first + i] = 1;
+          const Tri& tr = tris[first + i];
+          if (tr.id >= tri_count || seen_tri[tr.id]) return 7;
+          seen_tri[tr.id] = 1;
+          float v[3][3];
+          for (int k = 0; k < 3; ++k) { v[0][k] = tr.v0[k]; v[1][k] = tr.v0[k] + tr.e1[k]; v[2][k] = tr.v0[k] + tr.e2[k]; }
+          if (ref9) {
+            const float* rv = ref9 + 9 * (size_t)tr.id;
+            for (int k = 0; k < 3; ++k) {
+              if (tr.v0[k] != rv[k]) return 8;
+              if (tr.e1[k] != rv[3 + k] - rv[k]) return 8;
+              if (tr.e2[k] != rv[6 + k] - rv[k]) return 8;
+            }
+          }
+          for (int cc = 0; cc < 3; ++cc) {
+            const float* pv = ref9 ? ref9 + 9 * (size_t)tr.id + 3 * cc : v[cc];
+            for (int k = 0; k < 3; ++k) if ((double)pv[k] < mn[k] || (double)pv[k] > mx[k]) return 9;
           }
         }
       }

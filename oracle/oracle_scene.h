@@ -18,6 +18,17 @@ struct Node {
 };
 static_assert(sizeof(Node) == 64, "node is 64 B");
 
+// RENDER_SPEC §4.1b — 64-B compressed 4-wide node as the product lays it out in HBM
+struct Node4 {
+  float pmin[3];
+  uint32_t exps;    // byte a: biased exponent of the quantum of axis a
+  uint32_t qlo[3];  // byte c: child c's quantised low plane on axis a
+  uint32_t qhi[3];
+  uint32_t pad[2];
+  uint32_t ref[4];  // 0xffffffff absent | bit31 leaf, bits 30..28 count-1, bits 27..0 first triangle | node index
+};
+static_assert(sizeof(Node4) == 64, "4-wide node is 64 B");
+
 // RENDER_SPEC §4.1 — 48-B triangle: v0 | global id, e1 = v1 - v0 | 0, e2 = v2 - v0 | 0
 struct Tri {
   float v0[3]; uint32_t id;

@@ -141,7 +141,8 @@ def test_bvh_structure_and_flattening(halart, oracle, name):
     omn, omx = osc.bounds()
     assert list(info.scene_min) == list(omn) and list(info.scene_max) == list(omx)
     nodes, tris = r.download_bvh()
-    rc, depth = oracle.validate_bvh(nodes, tris, osc.triangles())  # also checks v0/e1/e2 bit-exact vs RENDER_SPEC §3
+    assert info.node_width == 4  # compressed 4-wide nodes are the default format (RENDER_SPEC §4.1b)
+    rc, depth = oracle.validate_bvh(nodes, tris, osc.triangles(), width=4)  # also checks v0/e1/e2 bit-exact vs RENDER_SPEC §3
     assert rc == 0, f"validate_bvh code {rc}"
     assert depth == info.max_depth
     r.close()
@@ -178,7 +179,7 @@ def test_traversal_step_counts_match_oracle_on_same_bvh(halart, oracle):
     nodes, tris = r.download_bvh()
     for mode in (0, 1):
         hits, cnt = r.trace_rays_host(rays, mode, count_steps=True)
-        ohits, ocnt = oracle.trace_on_bvh(nodes, tris, rays, mode)
+        ohits, ocnt = oracle.trace_on_bvh(nodes, tris, rays, mode, width=r.bvh_info().node_width)
         assert cnt == ocnt
         assert np.array_equal(hits["t"], ohits["t"])
     r.close()
@@ -242,7 +243,7 @@ def test_refit_after_node_transform(halart, oracle):
     s.nodes[2].local_transform = m
     osc = oracle.OracleScene(s)
     nodes, tris = r.download_bvh()
-    rc, _ = oracle.validate_bvh(nodes, tris, osc.triangles())
+    rc, _ = oracle.validate_bvh(nodes, tris, osc.triangles(), width=r.bvh_info().node_width)
     assert rc == 0
     rays = osc.camera_rays(128, 128, 0)
     assert r.trace_rays_host(rays, 0).tobytes() == osc.trace(rays, 0).tobytes()
@@ -402,8 +403,9 @@ def test_gltf_scene_renders_like_the_procedural_one(halart, oracle, tmp_path):
     r.update_batch(2); r.render()
     imgs, _ = oracle.OracleScene(loaded).render(48, 48, frames=2)
     assert_images_equal(r, imgs)
-    ref, _ = oracle.OracleScene(s).render(48, 48, frames=2)  # only the QUAD light intensity takes a /(0.5wh) * (0.5wh) round trip
-    assert np.abs(imgs[0] - ref[0]).max() <= 1e-5 * max(1.0, float(ref[0].max()))
+    # (not equal to a render of `s` itself: the loader tags every 8-bit image *_SRGB like gltf_loader.rs:395-396, the
+    # procedural normal / MR maps of `s` are UNORM)
+    assert [i.format for i in loaded.image_data] == [1, 1, 1]
     r.close()
 
 
