@@ -4,9 +4,11 @@
 //   flatten   every instance (node x primitive, in the reference's instance order gpu_uploader.rs:843-875) is
 //             transformed to world space once -> one triangle soup, one BVH (288 GB of HBM make the copy free and
 //             single-level traversal needs no per-instance ray transform)
-//   build     63-bit Morton codes -> rocPRIM radix sort -> Karras 2012 hierarchy -> bottom-up AABB fit with
-//             arrival counters -> subtrees of <= leaf_max triangles collapsed into leaves -> compacted 64-B nodes
-//   refit     (north_star; the reference only rebuilds) re-flatten + bottom-up fit on the frozen topology
+//   build     60-bit Morton codes (+ 2-bit size class) -> rocPRIM radix sort -> Karras 2012 binary hierarchy ->
+//             bottom-up AABB fit with arrival counters -> subtrees of <= leaf_max triangles become leaves ->
+//             top-down collapse into 4-wide nodes, breadth-first, by surface area -> 64-B compressed nodes
+//             (8-bit child boxes quantised conservatively against the node's own box, RENDER_SPEC §4.1b)
+//   refit     (north_star; the reference only rebuilds) re-flatten + bottom-up fit + re-pack on the frozen topology
 // Results are validated against the oracle through traversal results and a structural check, never topology.
 #include <hip/hip_runtime.h>
 
@@ -215,63 +217,6 @@ __global__ void __launch_bounds__(256) k_keep_flags(const uint32_t* __restrict__
   keep[i] = (last[i] - first[i] + 1u) > leaf_max ? 1u : 0u;
 }
 
-__global__ void __launch_bounds__(256) k_emit(const uint32_t* __restrict__ left, const uint32_t* __restrict__ right,
-                                               const uint32_t* __restrict__ first, const uint32_t* __restrict__ last,
-                                               const uint32_t* __restrict__ keep, const uint32_t* __restrict__ new_index,
-                                               const Box6* __restrict__ leaf_box, const Box6* __restrict__ node_box, uint32_t n_internal,
-                                               BvhNode* __restrict__ nodes) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_internal || !keep[i]) return;
-  BvhNode nd;
-  uint32_t refs[2] = {left[i], right[i]};
-#pragma unroll
-  for (int c = 0; c < 2; ++c) {
-    const uint32_t r = refs[c];
-    Box6 b;
-    uint32_t child, count;
-    if (r & kLeafBit) { b = leaf_box[r & ~kLeafBit]; child = r & ~kLeafBit; count = 1u; }
-    else {
-      b = node_box[r];
-      if (keep[r]) { child = new_index[r]; count = 0u; }
-      else { child = first[r]; count = last[r] - first[r] + 1u; }
-    }
-    float* mn = c == 0 ? nd.c0min : nd.c1min;
-    float* mx = c == 0 ? nd.c0max : nd.c1max;
-    for (int k = 0; k < 3; ++k) { mn[k] = b.mn[k]; mx[k] = b.mx[k]; }
-    if (c == 0) { nd.child0 = child; nd.count0 = count; } else { nd.child1 = child; nd.count1 = count; }
-  }
-  nodes[new_index[i]] = nd;
-}
-
-// scene of <= leaf_max triangles: one root node with a single leaf child
-__global__ void k_emit_single(const Box6* __restrict__ leaf_box, uint32_t n, BvhNode* __restrict__ nodes) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  BvhNode nd{};
-  Box6 b{};
-  if (n > 0) {
-    b = leaf_box[0];
-    for (uint32_t k = 1; k < n; ++k) b = box_union(b, leaf_box[k]);
-    nd.child0 = 0; nd.count0 = n;
-  } else { nd.child0 = kAbsent; nd.count0 = 0; }
-  for (int k = 0; k < 3; ++k) { nd.c0min[k] = b.mn[k]; nd.c0max[k] = b.mx[k]; nd.c1min[k] = 0.0f; nd.c1max[k] = 0.0f; }
-  nd.child1 = kAbsent; nd.count1 = 0;
-  nodes[0] = nd;
-}
-
-// depth of every kept node (root = 1); is4[i] = kept node on an odd level = root of a 4-wide node: a 4-node is a kept
-// binary node together with its kept children, its own children are the (up to four) grandchildren.  All ancestors of a
-// kept node are kept (triangle counts grow towards the root), so the odd levels tile the kept tree exactly.
-__global__ void __launch_bounds__(256) k_depth(const uint32_t* __restrict__ node_parent, const uint32_t* __restrict__ keep, uint32_t n_internal,
-                                                uint32_t* __restrict__ max_depth, uint32_t* __restrict__ is4) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_internal) return;
-  if (!keep[i]) { is4[i] = 0u; return; }
-  uint32_t d = 1, p = node_parent[i];
-  while (p != kAbsent) { ++d; p = node_parent[p]; }
-  is4[i] = d & 1u;
-  atomicMax(max_depth, d);
-}
-
 // ---- 4-wide compressed emission (RENDER_SPEC §4.1b) ---------------------------------------------------------------
 struct Child4 { Box6 box; uint32_t ref; };
 
@@ -313,28 +258,83 @@ RT_DI BvhNode4 pack_node4(const Child4* ch, int n) {
   return nd;
 }
 
-__global__ void __launch_bounds__(256) k_emit4(const uint32_t* __restrict__ left, const uint32_t* __restrict__ right,
-                                                const uint32_t* __restrict__ first, const uint32_t* __restrict__ last,
-                                                const uint32_t* __restrict__ keep, const uint32_t* __restrict__ is4,
+// Top-down collapse of the binary tree into 4-wide nodes, one BFS level per launch, so that node indices come out in
+// breadth-first order (the first `lds_nodes` nodes — the slice the traversal kernels stage in LDS — are the top of the
+// tree, which every ray visits).  The 4-node rooted at binary node i starts with i's two children and opens, while a
+// slot is free, (1) the kept inner child of largest surface area, then (2) the collapsed leaf of largest surface area
+// (splitting a leaf costs no bytes: the slot exists anyway, and two tighter boxes cull more triangle tests).
+// refs4[node] = the binary-tree references its slots were filled from — the frozen topology refit re-packs from.
+RT_DI float half_area(const Box6& b) {
+  const float dx = b.mx[0] - b.mn[0], dy = b.mx[1] - b.mn[1], dz = b.mx[2] - b.mn[2];
+  return dx * dy + dy * dz + dz * dx;
+}
+__global__ void __launch_bounds__(256) k_collapse_level(const uint32_t* __restrict__ root_of, uint32_t base, uint32_t size,
+                                                         const uint32_t* __restrict__ left, const uint32_t* __restrict__ right,
+                                                         const uint32_t* __restrict__ keep, const Box6* __restrict__ node_box,
+                                                         uint4* __restrict__ refs4, uint32_t* __restrict__ cnt) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= size) return;
+  const uint32_t i = root_of[base + j];
+  uint32_t c[4] = {left[i], right[i], kAbsent, kAbsent};
+  int n = 2;
+  for (int phase = 0; phase < 2; ++phase) {
+    while (n < 4) {
+      int pick = -1;
+      float best = -1.0f;
+      for (int k = 0; k < n; ++k) {
+        const uint32_t r = c[k];
+        if (r & kLeafBit) continue;
+        if ((keep[r] != 0u) != (phase == 0)) continue;
+        const float a = half_area(node_box[r]);
+        if (a > best) { best = a; pick = k; }
+      }
+      if (pick < 0) break;
+      const uint32_t r = c[pick];
+      for (int k = n; k > pick + 1; --k) c[k] = c[k - 1];
+      c[pick] = left[r]; c[pick + 1] = right[r];
+      ++n;
+    }
+  }
+  refs4[base + j] = make_uint4(c[0], c[1], c[2], c[3]);
+  uint32_t inner = 0;
+  for (int k = 0; k < n; ++k) inner += (!(c[k] & kLeafBit) && keep[c[k]]) ? 1u : 0u;
+  cnt[j] = inner;
+}
+__global__ void __launch_bounds__(256) k_scatter_level(uint32_t* __restrict__ root_of, uint32_t base, uint32_t size, const uint4* __restrict__ refs4,
+                                                        const uint32_t* __restrict__ keep, const uint32_t* __restrict__ off,
+                                                        uint32_t* __restrict__ index4) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= size) return;
+  const uint4 q = refs4[base + j];
+  const uint32_t c[4] = {q.x, q.y, q.z, q.w};
+  uint32_t pos = base + size + off[j];
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t r = c[k];
+    if ((r & kLeafBit) || !keep[r]) continue;
+    root_of[pos] = r;
+    index4[r] = pos;
+    ++pos;
+  }
+}
+__global__ void __launch_bounds__(256) k_pack4(const uint4* __restrict__ refs4, uint32_t node_count, const uint32_t* __restrict__ first,
+                                                const uint32_t* __restrict__ last, const uint32_t* __restrict__ keep,
                                                 const uint32_t* __restrict__ index4, const Box6* __restrict__ leaf_box,
-                                                const Box6* __restrict__ node_box, uint32_t n_internal, BvhNode4* __restrict__ nodes) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_internal || !is4[i]) return;
+                                                const Box6* __restrict__ node_box, BvhNode4* __restrict__ nodes) {
+  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= node_count) return;
+  const uint4 q = refs4[idx];
+  const uint32_t c[4] = {q.x, q.y, q.z, q.w};
   Child4 ch[4];
   int n = 0;
-  auto add = [&](uint32_t r) {  // r: child reference of the binary tree that is not an absorbed kept node
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t r = c[k];
+    if (r == kAbsent) continue;
     if (r & kLeafBit) { ch[n].box = leaf_box[r & ~kLeafBit]; ch[n].ref = leaf_ref(r & ~kLeafBit, 1u); }
     else if (!keep[r]) { ch[n].box = node_box[r]; ch[n].ref = leaf_ref(first[r], last[r] - first[r] + 1u); }
     else { ch[n].box = node_box[r]; ch[n].ref = index4[r]; }
     ++n;
-  };
-  const uint32_t refs[2] = {left[i], right[i]};
-#pragma unroll
-  for (int c = 0; c < 2; ++c) {
-    const uint32_t r = refs[c];
-    if (!(r & kLeafBit) && keep[r]) { add(left[r]); add(right[r]); } else add(r);
   }
-  nodes[index4[i]] = pack_node4(ch, n);
+  nodes[idx] = pack_node4(ch, n);
 }
 
 // scene of <= leaf_max triangles: one 4-node with a single leaf child
@@ -364,8 +364,11 @@ inline uint32_t nblk(uint32_t n) { return (n + 255u) / 256u; }
 // Persistent topology kept for refit.
 struct BvhTopology {
   uint32_t n = 0, leaf_max = 0;
-  DevBuf left, right, first, last, node_parent, leaf_parent, keep, new_index, sorted_ids, tri_box, leaf_box, node_box, arrivals, scene_ord;
-  DevBuf is4, index4;  // 4-wide emission: roots of the 4-nodes and their output indices
+  DevBuf left, right, first, last, node_parent, leaf_parent, keep, sorted_ids, tri_box, leaf_box, node_box, arrivals, scene_ord;
+  // 4-wide collapse: binary root of every 4-node (BFS order), the binary refs its slots were filled from, the 4-node
+  // index of every binary root, per-level scratch
+  DevBuf root_of, refs4, index4, cnt, off;
+  bool collapsed = false;
 };
 
 static std::string flatten_and_bounds(BvhBuffers& b, BvhTopology& t, hipStream_t s) {
@@ -389,8 +392,7 @@ static std::string fit_and_emit(BvhBuffers& b, BvhTopology& t, hipStream_t s) {
   if (n) hipLaunchKernelGGL(k_leaf_boxes, dim3(nblk(n)), dim3(256), 0, s, t.tri_box.as<Box6>(), t.sorted_ids.as<uint32_t>(), n,
                             t.leaf_box.as<Box6>(), b.tris_by_id, b.tris);
   if (n <= t.leaf_max || n < 2) {
-    if (b.wide) hipLaunchKernelGGL(k_emit_single4, dim3(1), dim3(64), 0, s, t.leaf_box.as<Box6>(), n, reinterpret_cast<BvhNode4*>(b.nodes));
-    else hipLaunchKernelGGL(k_emit_single, dim3(1), dim3(64), 0, s, t.leaf_box.as<Box6>(), n, b.nodes);
+    hipLaunchKernelGGL(k_emit_single4, dim3(1), dim3(64), 0, s, t.leaf_box.as<Box6>(), n, b.nodes);
     b.node_count = 1;
     b.max_depth = 1;
     b.stack_need = 1;
@@ -401,14 +403,39 @@ static std::string fit_and_emit(BvhBuffers& b, BvhTopology& t, hipStream_t s) {
   HIP_TRY(hipMemsetAsync(t.arrivals.p, 0, (size_t)ni * 4, s));
   hipLaunchKernelGGL(k_fit, dim3(nblk(n)), dim3(256), 0, s, t.left.as<uint32_t>(), t.right.as<uint32_t>(), t.node_parent.as<uint32_t>(),
                      t.leaf_parent.as<uint32_t>(), t.leaf_box.as<Box6>(), t.node_box.as<Box6>(), t.arrivals.as<uint32_t>(), n);
-  if (b.wide)
-    hipLaunchKernelGGL(k_emit4, dim3(nblk(ni)), dim3(256), 0, s, t.left.as<uint32_t>(), t.right.as<uint32_t>(), t.first.as<uint32_t>(),
-                       t.last.as<uint32_t>(), t.keep.as<uint32_t>(), t.is4.as<uint32_t>(), t.index4.as<uint32_t>(), t.leaf_box.as<Box6>(),
-                       t.node_box.as<Box6>(), ni, reinterpret_cast<BvhNode4*>(b.nodes));
-  else
-    hipLaunchKernelGGL(k_emit, dim3(nblk(ni)), dim3(256), 0, s, t.left.as<uint32_t>(), t.right.as<uint32_t>(), t.first.as<uint32_t>(),
-                       t.last.as<uint32_t>(), t.keep.as<uint32_t>(), t.new_index.as<uint32_t>(), t.leaf_box.as<Box6>(), t.node_box.as<Box6>(), ni,
-                       b.nodes);
+  if (!t.collapsed) {  // first build: choose the 4-wide topology from the fitted boxes; refit keeps it
+    static const uint32_t zero = 0;
+    HIP_TRY(hipMemcpyAsync(t.root_of.p, &zero, 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(t.index4.p, &zero, 4, hipMemcpyHostToDevice, s));
+    DevBuf tmp;
+    size_t tmp_bytes = 0;
+    HIP_TRY(rocprim::exclusive_scan(nullptr, tmp_bytes, t.cnt.as<uint32_t>(), t.off.as<uint32_t>(), 0u, ni, rocprim::plus<uint32_t>(), s));
+    std::string e = tmp.alloc(tmp_bytes);
+    if (!e.empty()) return e;
+    uint32_t base = 0, size = 1, levels = 0;
+    while (size > 0) {
+      hipLaunchKernelGGL(k_collapse_level, dim3(nblk(size)), dim3(256), 0, s, t.root_of.as<uint32_t>(), base, size, t.left.as<uint32_t>(),
+                         t.right.as<uint32_t>(), t.keep.as<uint32_t>(), t.node_box.as<Box6>(), t.refs4.as<uint4>(), t.cnt.as<uint32_t>());
+      size_t tb = tmp_bytes;
+      HIP_TRY(rocprim::exclusive_scan(tmp.p, tb, t.cnt.as<uint32_t>(), t.off.as<uint32_t>(), 0u, size, rocprim::plus<uint32_t>(), s));
+      hipLaunchKernelGGL(k_scatter_level, dim3(nblk(size)), dim3(256), 0, s, t.root_of.as<uint32_t>(), base, size, t.refs4.as<uint4>(),
+                         t.keep.as<uint32_t>(), t.off.as<uint32_t>(), t.index4.as<uint32_t>());
+      uint32_t last_off = 0, last_cnt = 0;
+      HIP_TRY(hipMemcpyAsync(&last_off, t.off.as<uint32_t>() + (size - 1), 4, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipMemcpyAsync(&last_cnt, t.cnt.as<uint32_t>() + (size - 1), 4, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      base += size;
+      size = last_off + last_cnt;
+      ++levels;
+    }
+    b.node_count = base;
+    b.max_depth = levels;
+    b.stack_need = 3u * levels;  // a 4-node visit defers at most three siblings
+    t.collapsed = true;
+  }
+  hipLaunchKernelGGL(k_pack4, dim3(nblk(b.node_count)), dim3(256), 0, s, t.refs4.as<uint4>(), b.node_count, t.first.as<uint32_t>(),
+                     t.last.as<uint32_t>(), t.keep.as<uint32_t>(), t.index4.as<uint32_t>(), t.leaf_box.as<Box6>(), t.node_box.as<Box6>(),
+                     b.nodes);
   HIP_TRY(hipStreamSynchronize(s));
   HIP_TRY(hipGetLastError());
   return "";
@@ -427,11 +454,12 @@ std::string bvh_build(BvhBuffers& b, uint32_t leaf_max, hipStream_t s) {
   const size_t ni = n > 1 ? n - 1 : 1;
 #define ALLOC(buf, bytes) if (!(e = t.buf.alloc(bytes)).empty()) return e
   ALLOC(left, ni * 4); ALLOC(right, ni * 4); ALLOC(first, ni * 4); ALLOC(last, ni * 4); ALLOC(node_parent, ni * 4);
-  ALLOC(leaf_parent, (size_t)n * 4); ALLOC(keep, ni * 4); ALLOC(new_index, ni * 4); ALLOC(sorted_ids, (size_t)n * 4);
+  ALLOC(leaf_parent, (size_t)n * 4); ALLOC(keep, ni * 4); ALLOC(sorted_ids, (size_t)n * 4);
   ALLOC(tri_box, (size_t)n * sizeof(Box6)); ALLOC(leaf_box, (size_t)n * sizeof(Box6)); ALLOC(node_box, ni * sizeof(Box6));
-  ALLOC(arrivals, ni * 4); ALLOC(scene_ord, 6 * 4); ALLOC(is4, ni * 4); ALLOC(index4, ni * 4);
+  ALLOC(arrivals, ni * 4); ALLOC(scene_ord, 6 * 4);
+  ALLOC(root_of, ni * 4); ALLOC(refs4, ni * 16); ALLOC(index4, ni * 4); ALLOC(cnt, ni * 4); ALLOC(off, ni * 4);
 #undef ALLOC
-  if (b.wide && (leaf_max > 8u || n >= (1u << 28))) return "bvh_build: the 4-wide node format holds leaves of <= 8 triangles and < 2^28 triangles";
+  if (leaf_max > 8u || n >= (1u << 28)) return "bvh_build: the 4-wide node format holds leaves of <= 8 triangles and < 2^28 triangles";
   if (!(e = flatten_and_bounds(b, t, s)).empty()) return e;
   if (n >= 2) {
     DevBuf keys_in, keys_out, ids_in, tmp;
@@ -453,30 +481,6 @@ std::string bvh_build(BvhBuffers& b, uint32_t leaf_max, hipStream_t s) {
                        t.leaf_parent.as<uint32_t>());
     hipLaunchKernelGGL(k_keep_flags, dim3(nblk(n - 1)), dim3(256), 0, s, t.first.as<uint32_t>(), t.last.as<uint32_t>(), n - 1, leaf_max,
                        t.keep.as<uint32_t>());
-    DevBuf tmp2;
-    size_t tmp2_bytes = 0;
-    HIP_TRY(rocprim::exclusive_scan(nullptr, tmp2_bytes, t.keep.as<uint32_t>(), t.new_index.as<uint32_t>(), 0u, n - 1, rocprim::plus<uint32_t>(), s));
-    if (!(e = tmp2.alloc(tmp2_bytes)).empty()) return e;
-    HIP_TRY(rocprim::exclusive_scan(tmp2.p, tmp2_bytes, t.keep.as<uint32_t>(), t.new_index.as<uint32_t>(), 0u, n - 1, rocprim::plus<uint32_t>(), s));
-    // node count = new_index[last] + keep[last]; depth over kept nodes
-    DevBuf md;
-    if (!(e = md.alloc(4)).empty()) return e;
-    HIP_TRY(hipMemsetAsync(md.p, 0, 4, s));
-    hipLaunchKernelGGL(k_depth, dim3(nblk(n - 1)), dim3(256), 0, s, t.node_parent.as<uint32_t>(), t.keep.as<uint32_t>(), n - 1, md.as<uint32_t>(),
-                       t.is4.as<uint32_t>());
-    HIP_TRY(rocprim::exclusive_scan(tmp2.p, tmp2_bytes, t.is4.as<uint32_t>(), t.index4.as<uint32_t>(), 0u, n - 1, rocprim::plus<uint32_t>(), s));
-    const uint32_t* flag = b.wide ? t.is4.as<uint32_t>() : t.keep.as<uint32_t>();
-    const uint32_t* index = b.wide ? t.index4.as<uint32_t>() : t.new_index.as<uint32_t>();
-    uint32_t last_idx = 0, last_keep = 0, depth = 0;
-    HIP_TRY(hipMemcpyAsync(&last_idx, index + (n - 2), 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(&last_keep, flag + (n - 2), 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(&depth, md.p, 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    b.node_count = last_idx + last_keep;
-    // a 4-node visit defers at most three siblings, a 2-node visit one
-    if (b.wide) { b.max_depth = (depth + 1u) / 2u; b.stack_need = 3u * b.max_depth; }
-    else { b.max_depth = depth; b.stack_need = depth; }
-    if (n <= leaf_max) { b.node_count = 1; b.max_depth = 1; b.stack_need = 1; }
   } else if (n == 1) {
     static const uint32_t zero = 0;
     HIP_TRY(hipMemcpyAsync(t.sorted_ids.p, &zero, 4, hipMemcpyHostToDevice, s));

@@ -30,19 +30,10 @@ namespace rt {
 constexpr uint32_t kAbsent = 0xffffffffu;
 constexpr float kTMax = 3.402823466e+38f;
 
-// 64-B BVH2 node (docs/RENDER_SPEC.md §4.1): both child boxes, two child refs, two counts.
-// count == 0 -> `child` is a node index; count > 0 -> `child` is the first triangle of a leaf (BVH order);
-// child == kAbsent && count == 0 -> no child.
-struct alignas(16) BvhNode {
-  float c0min[3], c0max[3], c1min[3], c1max[3];
-  uint32_t child0, child1, count0, count1;
-};
-static_assert(sizeof(BvhNode) == 64, "BVH node is 64 B");
-
-// 64-B compressed BVH4 node (RENDER_SPEC §4.1b): up to four children in the bytes of one BVH2 node.  Child boxes are
+// 64-B compressed BVH4 node (RENDER_SPEC §4.1b): up to four children in the bytes a plain BVH2 node would take.  Child boxes are
 // 8-bit quantised against the node's own box: lo = pmin + qlo * 2^e, hi = pmin + qhi * 2^e per axis (lo rounded down,
 // hi rounded up, so the quantised box always contains the true one).  Halves the dependent fetches per ray and the
-// node bytes per ray of the BVH2 format — the two things a latency/gather-bound traversal pays for.
+// node bytes per ray of a BVH2 — measured +25-34 % rays/s on the 82 k and 1 M triangle scenes (profiles/r01_h_bvh_width.txt).
 struct alignas(16) BvhNode4 {
   float pmin[3];
   uint32_t exps;     // byte a = biased float exponent of the quantum of axis a: quantum = uint_as_float(byte << 23)
@@ -79,7 +70,7 @@ struct SceneView {
   const float4* tex_arena;
   uint32_t texture_count;
   uint32_t pad0;
-  const BvhNode* nodes;
+  const BvhNode4* nodes;
   const Tri* tris;             // BVH order
   const Tri* tris_by_id;       // global-id order (for shading)
   const uint32_t* tri_instance;  // global id -> instance
@@ -93,7 +84,7 @@ struct SceneView {
   const float* env_conditional;  // set 0 binding 7[1]
   uint32_t node_count, tri_count, lds_nodes, lds_tris;
   float ray_eps;
-  uint32_t wide;  // 0: `nodes` are BvhNode (BVH2); 1: they are BvhNode4
+  uint32_t staged;  // 1: the whole BVH fits the LDS budget (lds_nodes == node_count, lds_tris == tri_count) and is staged per workgroup
 };
 
 // per-update constants derived on the host from HalaGlobalUniform + camera 0 (RENDER_SPEC §5)

@@ -145,8 +145,8 @@ RT_DI uint32_t work_take(WorkCounters* wc, WorkCursor& c, uint32_t n, uint32_t w
 // (and the queue is not dry) the wave dequeues exactly that many rays and hands them to its idle lanes by ballot rank
 // — consecutive queue entries go to consecutive idle lanes, so refill loads stay as coalesced as the holes allow.
 // Source: load(i, &o, &d, &tmin, &tmax) fetches queue entry i; done(i, trav, found) consumes the result.
-template <bool ANY, bool COUNT, bool WIDE, class Source>
-RT_DI void persistent_trace(const SceneView& sv, const TraverseLds& lds, uint32_t* spill, WorkCounters* work, uint32_t n, uint32_t refill,
+template <bool ANY, bool COUNT, bool STAGED, class Source>
+RT_DI void persistent_trace(const SceneView& sv, const TraverseLds& lds, uint2* spill, WorkCounters* work, uint32_t n, uint32_t refill,
                             Source& src, uint32_t& cn, uint32_t& ct) {
   WorkCursor cur = work_begin(n);
   bool more = n > 0u;  // wave-uniform: some shard may still hold rays
@@ -174,7 +174,7 @@ RT_DI void persistent_trace(const SceneView& sv, const TraverseLds& lds, uint32_
     if (__ballot(has) == 0ull) { if (!more) break; continue; }
     for (;;) {
       if (has) {
-        if (trav_visit<ANY, COUNT, WIDE>(sv, lds, spill, t, cn, ct)) { src.done(idx, t, pay); has = false; }
+        if (trav_step<ANY, COUNT, STAGED>(sv, lds, spill, t, cn, ct)) { src.done(idx, t, pay); has = false; }
       }
       const uint32_t nidle = (uint32_t)__popcll(__ballot(!has));
       if (nidle == 64u || (more && nidle >= refill)) break;
@@ -227,20 +227,20 @@ extern __shared__ __attribute__((aligned(16))) unsigned char g_smem[];
 // ---------------------------------------------------------------------------------------------------------
 // K5a: persistent closest-hit traversal over a compact ray queue (coalesced 32-B ray reads, 16-B hit writes)
 // ---------------------------------------------------------------------------------------------------------
-template <bool ANY, bool COUNT, bool WIDE>
+template <bool ANY, bool COUNT, bool STAGED>
 __global__ void __launch_bounds__(kTraverseThreads, kTraverseWavesPerSimd)
 k_trace_batch(SceneView sv, const hala_ray* __restrict__ rays, hala_hit* __restrict__ hits, const uint32_t* __restrict__ n_ptr,
-              uint32_t n_imm, WorkCounters* __restrict__ work, uint32_t* __restrict__ spill_base, Control* __restrict__ ctl, int account,
+              uint32_t n_imm, WorkCounters* __restrict__ work, uint2* __restrict__ spill_base, Control* __restrict__ ctl, int account,
               uint32_t refill) {
-  const TraverseLds lds = stage_bvh(sv, g_smem);
+  const TraverseLds lds = stage_bvh<STAGED>(sv, g_smem);
   const uint32_t n = n_ptr ? *n_ptr : n_imm;
-  uint32_t* spill = spill_base ? spill_base + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * kStackSpill : nullptr;
+  uint2* spill = spill_base ? spill_base + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * kStackSpill : nullptr;
   uint32_t cn = 0, ct = 0;
   if (account && blockIdx.x == 0 && threadIdx.x == 0) {
     if (ANY) ctl->rays_shadow += n; else ctl->rays_closest += n;
   }
   BatchSource src{rays, hits, ANY};
-  persistent_trace<ANY, COUNT, WIDE>(sv, lds, spill, work, n, refill, src, cn, ct);
+  persistent_trace<ANY, COUNT, STAGED>(sv, lds, spill, work, n, refill, src, cn, ct);
   if (COUNT) {
     cn = wave_sum(cn); ct = wave_sum(ct);
     if (lane_id() == 0u) { atomicAdd(&ctl->steps[ANY ? 1 : 0][0], (unsigned long long)cn); atomicAdd(&ctl->steps[ANY ? 1 : 0][1], (unsigned long long)ct); }
@@ -251,16 +251,16 @@ k_trace_batch(SceneView sv, const hala_ray* __restrict__ rays, hala_hit* __restr
 // K5c: shadow traversal of the NEE connections of one bounce; unoccluded contributions are added to the
 // path's radiance in the fixed order light, environment (RENDER_SPEC §6)
 // ---------------------------------------------------------------------------------------------------------
-template <bool COUNT, bool WIDE>
+template <bool COUNT, bool STAGED>
 __global__ void __launch_bounds__(kTraverseThreads, kTraverseWavesPerSimd)
-k_trace_shadow(SceneView sv, Queues q, PathState ps, Control* __restrict__ ctl, uint32_t depth, uint32_t kind, uint32_t* __restrict__ spill_base,
+k_trace_shadow(SceneView sv, Queues q, PathState ps, Control* __restrict__ ctl, uint32_t depth, uint32_t kind, uint2* __restrict__ spill_base,
                uint32_t refill) {
-  const TraverseLds lds = stage_bvh(sv, g_smem);
+  const TraverseLds lds = stage_bvh<STAGED>(sv, g_smem);
   const uint32_t n = ctl->n_shadow[kind][depth];
-  uint32_t* spill = spill_base ? spill_base + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * kStackSpill : nullptr;
+  uint2* spill = spill_base ? spill_base + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * kStackSpill : nullptr;
   uint32_t cn = 0, ct = 0;
   ShadowSource src{q.shadow[kind], ps.radiance_rng};
-  persistent_trace<true, COUNT, WIDE>(sv, lds, spill, &ctl->work_shadow[kind], n, refill, src, cn, ct);
+  persistent_trace<true, COUNT, STAGED>(sv, lds, spill, &ctl->work_shadow[kind], n, refill, src, cn, ct);
   if (COUNT) {
     cn = wave_sum(cn); ct = wave_sum(ct);
     if (lane_id() == 0u) { atomicAdd(&ctl->steps[1][0], (unsigned long long)cn); atomicAdd(&ctl->steps[1][1], (unsigned long long)ct); }
@@ -509,29 +509,31 @@ __global__ void __launch_bounds__(256) k_scatter_tiles(FrameConst fc, const floa
 // ---------------------------------------------------------------------------------------------------------
 static inline uint32_t blocks_for(uint32_t n, uint32_t per) { return (n + per - 1) / per; }
 
-size_t traverse_stack_bytes() { return (size_t)kStackLds * kTraverseThreads * 4; }
+size_t traverse_stack_bytes() { return (size_t)kStackLds * kTraverseThreads * 8; }
 uint32_t traverse_stack_lds_levels() { return kStackLds; }
 uint32_t traverse_stack_spill_levels() { return kStackSpill; }
-uint32_t traverse_blocks_per_cu(size_t dynamic_lds_bytes, bool wide) {
+uint32_t traverse_blocks_per_cu(size_t dynamic_lds_bytes, bool staged) {
   int a = 0, b = 0;
-  const hipError_t ea = wide ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_batch<false, false, true>, kTraverseThreads, dynamic_lds_bytes)
-                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_batch<false, false, false>, kTraverseThreads, dynamic_lds_bytes);
-  const hipError_t eb = wide ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_trace_shadow<false, true>, kTraverseThreads, dynamic_lds_bytes)
-                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_trace_shadow<false, false>, kTraverseThreads, dynamic_lds_bytes);
+  const hipError_t ea = staged ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_batch<false, false, true>, kTraverseThreads, dynamic_lds_bytes)
+                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_batch<false, false, false>, kTraverseThreads, dynamic_lds_bytes);
+  const hipError_t eb = staged ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_trace_shadow<false, true>, kTraverseThreads, dynamic_lds_bytes)
+                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_trace_shadow<false, false>, kTraverseThreads, dynamic_lds_bytes);
   if (ea != hipSuccess || eb != hipSuccess) return 0;
   return (uint32_t)std::max(0, std::min(a, b));
 }
+static size_t traverse_smem(const SceneView& sv) {
+  return traverse_stack_bytes() + (sv.staged ? (size_t)sv.lds_nodes * 64 + (size_t)sv.lds_tris * 48 : 0);
+}
 
-// the traversal kernels are compiled per (any-hit, counting, node format); all three are launch-time constants
-template <bool ANY, bool COUNT, bool WIDE>
+// the traversal kernels are compiled per (any-hit, counting, BVH staged in LDS); all three are launch-time constants
+template <bool ANY, bool COUNT, bool STAGED>
 static void launch_trace_batch_t(const LaunchCfg& lc, const SceneView& sv, const hala_ray* rays, hala_hit* hits, const uint32_t* n_ptr,
                                  uint32_t n_imm, WorkCounters* work, Control* ctl, int acc, size_t smem, hipStream_t s) {
-  hipLaunchKernelGGL((k_trace_batch<ANY, COUNT, WIDE>), dim3(lc.persistent_blocks), dim3(kTraverseThreads), smem, s, sv, rays, hits, n_ptr, n_imm,
+  hipLaunchKernelGGL((k_trace_batch<ANY, COUNT, STAGED>), dim3(lc.persistent_blocks), dim3(kTraverseThreads), smem, s, sv, rays, hits, n_ptr, n_imm,
                      work, lc.spill, ctl, acc, lc.refill);
 }
 void launch_trace_batch(const LaunchCfg& lc, const SceneView& sv, const hala_ray* rays, hala_hit* hits, const uint32_t* n_ptr,
                         uint32_t n_imm, WorkCounters* work, Control* ctl, bool any, bool count, bool account, hipStream_t s) {
-  const size_t smem = (size_t)sv.lds_nodes * 64 + (size_t)sv.lds_tris * 48 + (size_t)kStackLds * kTraverseThreads * 4;
   const int acc = account ? 1 : 0;
   using Fn = void (*)(const LaunchCfg&, const SceneView&, const hala_ray*, hala_hit*, const uint32_t*, uint32_t, WorkCounters*, Control*, int, size_t,
                       hipStream_t);
@@ -539,14 +541,14 @@ void launch_trace_batch(const LaunchCfg& lc, const SceneView& sv, const hala_ray
                               launch_trace_batch_t<false, true, false>,  launch_trace_batch_t<false, true, true>,
                               launch_trace_batch_t<true, false, false>,  launch_trace_batch_t<true, false, true>,
                               launch_trace_batch_t<true, true, false>,   launch_trace_batch_t<true, true, true>};
-  table[(any ? 4 : 0) | (count ? 2 : 0) | (sv.wide ? 1 : 0)](lc, sv, rays, hits, n_ptr, n_imm, work, ctl, acc, smem, s);
+  table[(any ? 4 : 0) | (count ? 2 : 0) | (sv.staged ? 1 : 0)](lc, sv, rays, hits, n_ptr, n_imm, work, ctl, acc, traverse_smem(sv), s);
 }
 
 void launch_trace_shadow(const LaunchCfg& lc, const SceneView& sv, const Queues& q, const PathState& ps, Control* ctl, uint32_t depth,
                          uint32_t kind, bool count, hipStream_t s) {
-  const size_t smem = (size_t)sv.lds_nodes * 64 + (size_t)sv.lds_tris * 48 + (size_t)kStackLds * kTraverseThreads * 4;
+  const size_t smem = traverse_smem(sv);
   dim3 grid(lc.persistent_blocks), block(kTraverseThreads);
-  if (sv.wide) {
+  if (sv.staged) {
     if (count) hipLaunchKernelGGL((k_trace_shadow<true, true>), grid, block, smem, s, sv, q, ps, ctl, depth, kind, lc.spill, lc.refill);
     else hipLaunchKernelGGL((k_trace_shadow<false, true>), grid, block, smem, s, sv, q, ps, ctl, depth, kind, lc.spill, lc.refill);
   } else {

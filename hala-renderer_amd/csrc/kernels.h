@@ -10,15 +10,15 @@ namespace rt {
 
 struct LaunchCfg {
   uint32_t persistent_blocks;  // grid of the persistent traversal kernels
-  uint32_t* spill;             // global stack spill area or nullptr (tree depth <= kStackLds)
+  uint2* spill;                // global stack spill area or nullptr (stack need <= kStackLds)
   uint32_t refill;             // a wave refills its idle lanes once this many are idle (64 = whole-wave batches)
 };
 
 // integrator.hip
 size_t traverse_stack_bytes();          // LDS bytes of the per-lane traversal stacks of one workgroup
-uint32_t traverse_stack_lds_levels();   // stack levels kept in LDS
-uint32_t traverse_stack_spill_levels(); // deeper levels spilled to global scratch
-uint32_t traverse_blocks_per_cu(size_t dynamic_lds_bytes, bool wide);  // resident workgroups per CU (occupancy query)
+uint32_t traverse_stack_lds_levels();    // stack entries kept in LDS
+uint32_t traverse_stack_spill_levels();  // deeper entries spilled to global scratch (8 B each, per lane)
+uint32_t traverse_blocks_per_cu(size_t dynamic_lds_bytes, bool staged);  // resident workgroups per CU (occupancy query)
 void launch_trace_batch(const LaunchCfg& lc, const SceneView& sv, const hala_ray* rays, hala_hit* hits, const uint32_t* n_ptr,
                         uint32_t n_imm, WorkCounters* work, Control* ctl, bool any, bool count, bool account, hipStream_t s);
 void launch_trace_shadow(const LaunchCfg& lc, const SceneView& sv, const Queues& q, const PathState& ps, Control* ctl, uint32_t depth,
@@ -43,8 +43,7 @@ struct BvhBuffers {
   Tri* tris_by_id;         // [tri_count]
   Tri* tris;               // [tri_count] BVH order
   uint32_t* tri_instance;  // [tri_count]
-  BvhNode* nodes;          // [max(tri_count,2)-1 .. ] capacity >= max(tri_count - 1, 1)
-  uint32_t wide = 1;       // 1: emit 64-B compressed BVH4 nodes (BvhNode4) into `nodes`; 0: BVH2 nodes
+  BvhNode4* nodes;         // capacity >= max(tri_count - 1, 1)
   void* topology = nullptr;  // builder state kept for refit (freed with bvh_free_topology)
   // results
   uint32_t node_count;

@@ -25,7 +25,6 @@ namespace {
 
 constexpr uint32_t kLeafMax = 4;
 constexpr size_t kLdsStageBudget = 40 * 1024;  // a BVH up to this size is staged whole in LDS (next to the 24-KB stack)
-constexpr size_t kLdsPartialStage = 2 * 1024;  // larger BVHs: bytes of top-of-tree nodes staged per workgroup
 constexpr uint32_t kRefillThreshold = 32;      // idle lanes that trigger a refill of the wave (persistent_trace)
 constexpr int kStatRing = 16;
 constexpr uint32_t kMaxSampleBatch = 16;  // frames per wavefront pass in hala_rt_update_batch (~250 B of state per path)
@@ -123,10 +122,11 @@ struct hala_rt_renderer {
   BvhBuffers bvh{};
   DeviceArray<Tri> d_tris_by_id, d_tris;
   DeviceArray<uint32_t> d_tri_instance;
-  DeviceArray<BvhNode> d_nodes;
+  DeviceArray<BvhNode4> d_nodes;
   uint32_t lds_nodes = 0, lds_tris = 0;
+  bool staged = false;  // whole BVH staged in LDS by the traversal kernels
   float ray_eps = 0.0f;
-  DeviceArray<uint32_t> d_spill;
+  DeviceArray<uint2> d_spill;
   LaunchCfg lcfg{};
 
   bool has_env = false;
@@ -183,7 +183,7 @@ struct hala_rt_renderer {
     sv.env_pixels = reinterpret_cast<const float*>(d_env.ptr); sv.env_marginal = d_marginal.ptr; sv.env_conditional = d_conditional.ptr;
     sv.node_count = bvh.node_count; sv.tri_count = bvh.tri_count; sv.lds_nodes = lds_nodes; sv.lds_tris = lds_tris;
     sv.ray_eps = ray_eps;
-    sv.wide = bvh.wide;
+    sv.staged = staged ? 1u : 0u;
     return sv;
   }
   Queues queues() const {
@@ -365,21 +365,22 @@ int upload_textures(hala_rt_renderer* r) {
 
 int configure_traversal(hala_rt_renderer* r) {
   const size_t nb = (size_t)r->bvh.node_count * 64, tb = (size_t)r->bvh.tri_count * 48;
-  // Whole BVH in LDS when it fits the budget; otherwise only a small top-of-tree slice: occupancy (waves that hide
-  // the L2 / Infinity-Cache latency of the node fetches) is worth more than a larger staged slice.
-  size_t partial = kLdsPartialStage;
-  if (const char* e = getenv("HALART_LDS_STAGE_BYTES")) partial = (size_t)strtoul(e, nullptr, 10);  // tuning knob
-  if (nb + tb <= kLdsStageBudget) { r->lds_nodes = r->bvh.node_count; r->lds_tris = r->bvh.tri_count; }
-  else { r->lds_nodes = (uint32_t)std::min<size_t>(r->bvh.node_count, partial / 64); r->lds_tris = 0; }
+  // Whole BVH in LDS when it fits the budget (the STAGED kernel variants read it with ds_read only); otherwise nothing
+  // is staged: a top-of-tree slice measured no gain (profiles/r01_h_stage_sweep.txt), the caches already hold it.
+  size_t budget = kLdsStageBudget;
+  if (const char* e = getenv("HALART_LDS_STAGE_BYTES")) budget = (size_t)strtoul(e, nullptr, 10);  // tuning knob
+  r->staged = nb + tb <= budget;
+  r->lds_nodes = r->staged ? r->bvh.node_count : 0u;
+  r->lds_tris = r->staged ? r->bvh.tri_count : 0u;
   const size_t smem = (size_t)r->lds_nodes * 64 + (size_t)r->lds_tris * 48 + traverse_stack_bytes();
-  uint32_t per_cu = traverse_blocks_per_cu(smem, r->bvh.wide != 0);
+  uint32_t per_cu = traverse_blocks_per_cu(smem, r->staged);
   if (per_cu == 0) RT_FAIL("The traversal kernel does not fit on a compute unit with the requested LDS staging.");
   per_cu = std::min(per_cu, 8u);
   r->lcfg.persistent_blocks = r->cu_count * per_cu;
   r->lcfg.spill = nullptr;
   // measured (profiles/r01_c_refill_sweep.txt): whole-wave refills are best when the BVH lives in LDS (uniform, cheap rays);
   // refilling once half the wave is idle is best when node fetches go to L2 / Infinity Cache
-  r->lcfg.refill = (r->lds_nodes == r->bvh.node_count) ? 64u : kRefillThreshold;
+  r->lcfg.refill = r->staged ? 64u : kRefillThreshold;
   if (const char* e = getenv("HALART_REFILL")) r->lcfg.refill = std::min(64u, std::max(1u, (uint32_t)strtoul(e, nullptr, 10)));  // tuning knob
   if (r->bvh.stack_need > traverse_stack_lds_levels()) {
     if (r->bvh.stack_need > traverse_stack_lds_levels() + traverse_stack_spill_levels())
@@ -399,8 +400,6 @@ int build_bvh(hala_rt_renderer* r) {
   r->bvh.primitives = r->d_instances.ptr; r->bvh.inst_first_tri = r->d_inst_first_tri.ptr;
   r->bvh.instance_count = (uint32_t)r->hs.instances.size(); r->bvh.tri_count = n;
   r->bvh.tris_by_id = r->d_tris_by_id.ptr; r->bvh.tris = r->d_tris.ptr; r->bvh.tri_instance = r->d_tri_instance.ptr; r->bvh.nodes = r->d_nodes.ptr;
-  r->bvh.wide = 1;
-  if (const char* e = getenv("HALART_BVH_WIDTH")) r->bvh.wide = atoi(e) == 2 ? 0u : 1u;  // 2: plain BVH2 nodes (A/B knob), default compressed BVH4
   const std::string e = bvh_build(r->bvh, kLeafMax, r->stream);
   if (!e.empty()) RT_FAIL(e);
   return configure_traversal(r);
@@ -893,7 +892,7 @@ int hala_rt_get_bvh_info(hala_rt_renderer* r, hala_bvh_info* out) {
   if (!r || !out) RT_FAIL("The renderer handle is null!");
   if (!r->committed) RT_FAIL("The top level acceleration structure is none!");
   out->node_count = r->bvh.node_count; out->triangle_count = r->bvh.tri_count; out->max_depth = r->bvh.max_depth; out->lds_node_count = r->lds_nodes;
-  out->node_width = r->bvh.wide ? 4u : 2u;
+  out->node_width = 4u;
   memcpy(out->scene_min, r->bvh.scene_min, 12); memcpy(out->scene_max, r->bvh.scene_max, 12);
   return HALA_OK;
 }

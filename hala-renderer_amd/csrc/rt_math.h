@@ -37,6 +37,10 @@ RT_DI f3 normalize3(f3 a) {
 }
 RT_DI float maxf(float a, float b) { return a > b ? a : b; }
 RT_DI float minf(float a, float b) { return a < b ? a : b; }
+// IEEE-754 minNum / maxNum with -0 < +0: ONE v_min_f32 / v_max_f32 (the select forms above cost a compare and a
+// select each); used where the spec says so (RENDER_SPEC §4.3b: the slab tests of the compressed BVH4 nodes)
+RT_DI float hw_minf(float a, float b) { return __builtin_fminf(a, b); }
+RT_DI float hw_maxf(float a, float b) { return __builtin_fmaxf(a, b); }
 RT_DI float clampf(float x, float lo, float hi) { return minf(maxf(x, lo), hi); }
 RT_DI float max3f(f3 a) { return maxf(a.x, maxf(a.y, a.z)); }
 

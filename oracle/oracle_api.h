@@ -142,15 +142,10 @@ void orc_trace_rays(const orc_scene* s, const orc_ray* rays, orc_hit* hits, uint
                     uint64_t* counters);
 // Brute force over all triangles (no BVH): the BVH-independent truth for closest hits.
 void orc_trace_rays_brute(const orc_scene* s, const orc_ray* rays, orc_hit* hits, uint32_t count, int mode);
-// Same traversal rule but over an externally supplied BVH in the product's HBM layout (64-B nodes, 48-B
-// triangles: RENDER_SPEC §4.1) — used to check the GPU-built BVH and to count nodes/triangles on it.
-void orc_trace_rays_on_bvh(const void* nodes64, uint32_t node_count, const void* tris48, uint32_t tri_count,
-                           const orc_ray* rays, orc_hit* hits, uint32_t count, int mode, uint64_t* counters);
-// Structural validation of such a BVH: every triangle id appears exactly once, child boxes contain their
-// triangles, no cycles. Returns 0 if valid, else a non-zero code; *max_depth receives the tree depth.
-int orc_validate_bvh(const void* nodes64, uint32_t node_count, const void* tris48, uint32_t tri_count,
-                     const float* ref_triangles9, uint32_t* max_depth);
-/* the same two checks for the product's compressed 4-wide node format (RENDER_SPEC §4.1b / §4.4b) */
+// The traversal rule of RENDER_SPEC §4.4b over an externally supplied BVH in the product's HBM layout (64-B compressed
+// 4-wide nodes §4.1b, 48-B triangles) — used to check the GPU-built BVH and to count nodes/triangles on it — and the
+// structural validation of such a BVH: every triangle id appears exactly once, the dequantised child boxes contain
+// their triangles, no cycles.  Returns 0 if valid, else a non-zero code; *max_depth receives the tree depth.
 void orc_trace_rays_on_bvh4(const void* nodes64, uint32_t node_count, const void* tris48, uint32_t tri_count,
                             const orc_ray* rays, orc_hit* hits, uint32_t count, int mode, uint64_t* counters);
 int orc_validate_bvh4(const void* nodes64, uint32_t node_count, const void* tris48, uint32_t tri_count,

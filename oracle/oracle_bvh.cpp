@@ -277,7 +277,7 @@ static inline float safe_inv(float d) {
   return 1.0f / dd;
 }
 static inline RayPre make_ray(V3 o, V3 d, float tmin) {
-  RayPre r; r.o = o; r.d = d; r.tmin = tmin;
+  RayPre r; r.o = o; r.d = d; r.tmin = maxf(tmin, 0.0f);  // RENDER_SPEC §4.2: rays start at or after their origin
   r.idir = v3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
   r.ood = r.o * r.idir;
   return r;
@@ -376,10 +376,26 @@ static inline bool leaf_test(const Tri* tris, const RayPre& r, float tmax, Hit* 
   return false;
 }
 
+// IEEE-754 minNum / maxNum with -0 < +0: what v_min_f32 / v_max_f32 compute (RENDER_SPEC §4.3b)
+static inline float hw_minf(float a, float b) {
+  if (a != a) return b;
+  if (b != b) return a;
+  if (a == 0.0f && b == 0.0f) return std::signbit(a) ? a : b;
+  return a < b ? a : b;
+}
+static inline float hw_maxf(float a, float b) {
+  if (a != a) return b;
+  if (b != b) return a;
+  if (a == 0.0f && b == 0.0f) return std::signbit(a) ? b : a;
+  return a > b ? a : b;
+}
+static inline float key_tn(uint32_t key) { return bits_f(key & ~3u); }
+
 template <bool ANY>
 static inline bool traverse4(const Node4* nodes, const Tri* tris, const RayPre& r, float tmax, Hit* best, Counters* c) {
   best->t = tmax; best->prim = ORC_NONE; best->u = 0.0f; best->v = 0.0f;
-  uint32_t stack[1024]; int sp = 0;
+  struct Entry { uint32_t key, ref; };
+  Entry stack[1024]; int sp = 0;
   uint32_t cur = 0;
   for (;;) {
     const Node4& n = nodes[cur];
@@ -390,43 +406,44 @@ static inline bool traverse4(const Node4* nodes, const Tri* tris, const RayPre& 
       k[a] = bits_f(((n.exps >> (8 * a)) & 0xffu) << 23) * idir[a];
       adj[a] = fmaf(n.pmin[a], idir[a], -ood[a]);
     }
-    uint32_t key[4];
+    Entry e[4];
     for (int ci = 0; ci < 4; ++ci) {
       float t0[3], t1[3];
       for (int a = 0; a < 3; ++a) {
         t0[a] = fmaf((float)((n.qlo[a] >> (8 * ci)) & 0xffu), k[a], adj[a]);
         t1[a] = fmaf((float)((n.qhi[a] >> (8 * ci)) & 0xffu), k[a], adj[a]);
       }
-      float tn = maxf(maxf(minf(t0[0], t1[0]), minf(t0[1], t1[1])), maxf(minf(t0[2], t1[2]), r.tmin));
-      float tf = minf(minf(maxf(t0[0], t1[0]), maxf(t0[1], t1[1])), minf(maxf(t0[2], t1[2]), best->t));
+      float tn = hw_maxf(hw_maxf(hw_minf(t0[0], t1[0]), hw_minf(t0[1], t1[1])), hw_maxf(hw_minf(t0[2], t1[2]), r.tmin));
+      float tf = hw_minf(hw_minf(hw_maxf(t0[0], t1[0]), hw_maxf(t0[1], t1[1])), hw_minf(hw_maxf(t0[2], t1[2]), best->t));
       bool hit = n.ref[ci] != kAbsent && tn <= tf * 1.0000004f;
-      key[ci] = hit ? ((f_bits(maxf(tn, 0.0f)) & ~3u) | (uint32_t)ci) : 0xffffffffu;
+      e[ci].key = hit ? ((f_bits(tn) & ~3u) | (uint32_t)ci) : 0xffffffffu;
+      e[ci].ref = n.ref[ci];
     }
-    std::sort(key, key + 4);
-    for (int i = 0; i < 4 && key[i] != 0xffffffffu; ++i) {  // leaves, nearest first
-      uint32_t rf = n.ref[key[i] & 3u];
+    std::sort(e, e + 4, [](const Entry& a, const Entry& b) { return a.key < b.key; });  // keys of hits are distinct (slot bits)
+    // inner children: nearest next, the others stacked farthest first with their keys
+    uint32_t next = kAbsent, next_key = 0;
+    for (int i = 3; i >= 0; --i) {
+      if (e[i].key == 0xffffffffu || (e[i].ref & 0x80000000u)) continue;
+      if (next != kAbsent) stack[sp++] = Entry{next_key, next};
+      next = e[i].ref; next_key = e[i].key;
+    }
+    // leaves, nearest first
+    for (int i = 0; i < 4 && e[i].key != 0xffffffffu; ++i) {
+      uint32_t rf = e[i].ref;
       if (!(rf & 0x80000000u)) continue;
-      if (!(bits_f(key[i] & ~3u) <= best->t)) continue;
+      if (!(key_tn(e[i].key) <= best->t)) continue;
       uint32_t count = ((rf >> 28) & 7u) + 1u;
       if (c) c->tris += count;
       if (leaf_test<ANY>(tris, r, tmax, best, rf & 0x0fffffffu, count)) return true;
     }
-    uint32_t next = kAbsent;
-    for (int i = 3; i >= 0; --i) {  // inner children still in reach, farthest pushed first
-      if (key[i] == 0xffffffffu) continue;
-      uint32_t rf = n.ref[key[i] & 3u];
-      if (rf & 0x80000000u) continue;
-      if (!(bits_f(key[i] & ~3u) <= best->t)) continue;
-      if (next != kAbsent) stack[sp++] = next;
-      next = rf;
-    }
-    if (next == kAbsent) {
-      if (sp == 0) break;
-      next = stack[--sp];
+    if (next != kAbsent && !(key_tn(next_key) <= best->t)) next = kAbsent;
+    while (next == kAbsent) {
+      if (sp == 0) return best->prim != ORC_NONE;
+      Entry t = stack[--sp];
+      if (key_tn(t.key) <= best->t) next = t.ref;
     }
     cur = next;
   }
-  return best->prim != ORC_NONE;
 }
 
 Hit trace_closest(const Node* nodes, const Tri* tris, V3 o, V3 d, float tmin, float tmax, Counters* c) {
@@ -464,11 +481,6 @@ static void trace_batch(const Node* nodes, const Tri* tris, const orc_ray* rays,
 extern "C" void orc_trace_rays(const orc_scene* s, const orc_ray* rays, orc_hit* hits, uint32_t count, int mode, uint64_t* counters) {
   trace_batch(s->nodes.data(), s->tris.data(), rays, hits, count, mode, counters);
 }
-extern "C" void orc_trace_rays_on_bvh(const void* nodes64, uint32_t, const void* tris48, uint32_t, const orc_ray* rays,
-                                      orc_hit* hits, uint32_t count, int mode, uint64_t* counters) {
-  trace_batch((const Node*)nodes64, (const Tri*)tris48, rays, hits, count, mode, counters);
-}
-
 extern "C" void orc_trace_rays_on_bvh4(const void* nodes64, uint32_t, const void* tris48, uint32_t, const orc_ray* rays,
                                        orc_hit* hits, uint32_t count, int mode, uint64_t* counters) {
   const Node4* nodes = (const Node4*)nodes64;
@@ -511,74 +523,9 @@ extern "C" void orc_trace_rays_brute(const orc_scene* s, const orc_ray* rays, or
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// structural validation of a product-built BVH
+// structural validation of a product-built BVH (compressed 4-wide nodes): every child's DEQUANTISED box (evaluated in
+// double, i.e. exactly) must contain what hangs below it
 // ---------------------------------------------------------------------------------------------------------
-extern "C" int orc_validate_bvh(const void* nodes64, uint32_t node_count, const void* tris48, uint32_t tri_count,
-                                const float* ref9, uint32_t* max_depth) {
-  const Node* nodes = (const Node*)nodes64;
-  const Tri* tris = (const Tri*)tris48;
-  if (max_depth) *max_depth = 0;
-  if (node_count == 0) return 1;
-  std::vector<uint8_t> seen_tri(tri_count, 0), seen_node(node_count, 0), seen_slot(tri_count, 0);
-  struct Item { uint32_t node, depth; };
-  std::vector<Item> st{{0, 1}};
-  uint32_t md = 0;
-  while (!st.empty()) {
-    Item it = st.back(); st.pop_back();
-    if (it.node >= node_count) return 2;
-    if (seen_node[it.node]) return 3;  // cycle / shared node
-    seen_node[it.node] = 1;
-    md = std::max(md, it.depth);
-    const Node& n = nodes[it.node];
-    for (int ci = 0; ci < 2; ++ci) {
-      uint32_t child = ci ? n.child1 : n.child0, count = ci ? n.count1 : n.count0;
-      const float* mn = ci ? n.c1min : n.c0min; const float* mx = ci ? n.c1max : n.c0max;
-      if (count == 0 && child == kAbsent) continue;
-      if (count == 0) {
-        // child node's two boxes must lie inside this child box
-        if (child >= node_count) return 2;
-        const Node& cn = nodes[child];
-        for (int cj = 0; cj < 2; ++cj) {
-          uint32_t gc = cj ? cn.child1 : cn.child0, gcount = cj ? cn.count1 : cn.count0;
-          if (gcount == 0 && gc == kAbsent) continue;
-          const float* gmn = cj ? cn.c1min : cn.c0min; const float* gmx = cj ? cn.c1max : cn.c0max;
-          for (int k = 0; k < 3; ++k) if (gmn[k] < mn[k] || gmx[k] > mx[k]) return 4;
-        }
-        st.push_back({child, it.depth + 1});
-      } else {
-        if ((uint64_t)child + count > tri_count) return 5;
-        for (uint32_t i = 0; i < count; ++i) {
-          if (seen_slot[child + i]) return 6;
-          seen_slot[child + i] = 1;
-          const Tri& tr = tris[child + i];
-          if (tr.id >= tri_count || seen_tri[tr.id]) return 7;
-          seen_tri[tr.id] = 1;
-          float v[3][3];
-          for (int k = 0; k < 3; ++k) { v[0][k] = tr.v0[k]; v[1][k] = tr.v0[k] + tr.e1[k]; v[2][k] = tr.v0[k] + tr.e2[k]; }
-          if (ref9) {
-            const float* rv = ref9 + 9 * (size_t)tr.id;
-            // v0 and the edge vectors must be the bit-exact flattening of RENDER_SPEC §3
-            for (int k = 0; k < 3; ++k) {
-              if (tr.v0[k] != rv[k]) return 8;
-              if (tr.e1[k] != rv[3 + k] - rv[k]) return 8;
-              if (tr.e2[k] != rv[6 + k] - rv[k]) return 8;
-            }
-          }
-          for (int c = 0; c < 3; ++c) {
-            const float* pv = ref9 ? ref9 + 9 * (size_t)tr.id + 3 * c : v[c];
-            for (int k = 0; k < 3; ++k) if (pv[k] < mn[k] || pv[k] > mx[k]) return 9;
-          }
-        }
-      }
-    }
-  }
-  for (uint32_t i = 0; i < tri_count; ++i) if (!seen_tri[i]) return 10;
-  if (max_depth) *max_depth = md;
-  return 0;
-}
-
-// the same for compressed 4-wide nodes: every child's DEQUANTISED box (evaluated in double, i.e. exactly) must contain
-// what hangs below it — the triangles of a leaf, the dequantised child boxes of an inner node
 extern "C" int orc_validate_bvh4(const void* nodes64, uint32_t node_count, const void* tris48, uint32_t tri_count,
                                  const float* ref9, uint32_t* max_depth) {
   const Node4* nodes = (const Node4*)nodes64;

@@ -5,6 +5,7 @@ set -u
 CFG=${1:-2}; FRAMES=${2:-4}; OUT=${3:-pmc}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 export TMPDIR=/tmp
+mkdir -p $ROOT/gpurun_out/$OUT
 cd /tmp
 i=0
 for SET in \

@@ -226,21 +226,21 @@ class OracleScene:
         return images, st
 
 
-def trace_on_bvh(nodes_u32, tris_u32, rays, mode=0, width=2):
+def trace_on_bvh(nodes_u32, tris_u32, rays, mode=0):
     rays = np.ascontiguousarray(rays, dtype=A.RAY_DTYPE)
     hits = np.empty(rays.shape[0], dtype=A.HIT_DTYPE)
     ctr = (C.c_uint64 * 2)(0, 0)
-    fn = lib().orc_trace_rays_on_bvh4 if width == 4 else lib().orc_trace_rays_on_bvh
+    fn = lib().orc_trace_rays_on_bvh4
     fn(C.c_void_p(nodes_u32.ctypes.data), C.c_uint32(nodes_u32.size // 16), C.c_void_p(tris_u32.ctypes.data),
        C.c_uint32(tris_u32.size // 12), C.c_void_p(rays.ctypes.data), C.c_void_p(hits.ctypes.data),
        C.c_uint32(rays.shape[0]), C.c_int(mode), ctr)
     return hits, (ctr[0], ctr[1])
 
 
-def validate_bvh(nodes_u32, tris_u32, ref_triangles9, width=2):
+def validate_bvh(nodes_u32, tris_u32, ref_triangles9):
     md = C.c_uint32()
     ref = np.ascontiguousarray(ref_triangles9, dtype=np.float32)
-    fn = lib().orc_validate_bvh4 if width == 4 else lib().orc_validate_bvh
+    fn = lib().orc_validate_bvh4
     fn.restype = C.c_int
     rc = fn(C.c_void_p(nodes_u32.ctypes.data), C.c_uint32(nodes_u32.size // 16), C.c_void_p(tris_u32.ctypes.data),
             C.c_uint32(tris_u32.size // 12), fptr(ref), C.byref(md))

@@ -142,7 +142,7 @@ def test_bvh_structure_and_flattening(halart, oracle, name):
     assert list(info.scene_min) == list(omn) and list(info.scene_max) == list(omx)
     nodes, tris = r.download_bvh()
     assert info.node_width == 4  # compressed 4-wide nodes are the default format (RENDER_SPEC §4.1b)
-    rc, depth = oracle.validate_bvh(nodes, tris, osc.triangles(), width=4)  # also checks v0/e1/e2 bit-exact vs RENDER_SPEC §3
+    rc, depth = oracle.validate_bvh(nodes, tris, osc.triangles())  # also checks v0/e1/e2 bit-exact vs RENDER_SPEC §3
     assert rc == 0, f"validate_bvh code {rc}"
     assert depth == info.max_depth
     r.close()
@@ -179,7 +179,7 @@ def test_traversal_step_counts_match_oracle_on_same_bvh(halart, oracle):
     nodes, tris = r.download_bvh()
     for mode in (0, 1):
         hits, cnt = r.trace_rays_host(rays, mode, count_steps=True)
-        ohits, ocnt = oracle.trace_on_bvh(nodes, tris, rays, mode, width=r.bvh_info().node_width)
+        ohits, ocnt = oracle.trace_on_bvh(nodes, tris, rays, mode)
         assert cnt == ocnt
         assert np.array_equal(hits["t"], ohits["t"])
     r.close()
@@ -243,7 +243,7 @@ def test_refit_after_node_transform(halart, oracle):
     s.nodes[2].local_transform = m
     osc = oracle.OracleScene(s)
     nodes, tris = r.download_bvh()
-    rc, _ = oracle.validate_bvh(nodes, tris, osc.triangles(), width=r.bvh_info().node_width)
+    rc, _ = oracle.validate_bvh(nodes, tris, osc.triangles())
     assert rc == 0
     rays = osc.camera_rays(128, 128, 0)
     assert r.trace_rays_host(rays, 0).tobytes() == osc.trace(rays, 0).tobytes()
