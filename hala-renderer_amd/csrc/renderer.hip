@@ -23,7 +23,7 @@ using namespace rt;
 
 namespace {
 
-constexpr uint32_t kLeafMax = 4;
+constexpr uint32_t kLeafMax = 2;  // triangles per leaf: a triangle test costs ~2x a child box test, profiles/r01_h_leaf_max.txt
 constexpr size_t kLdsStageBudget = 40 * 1024;  // a BVH up to this size is staged whole in LDS (next to the 24-KB stack)
 constexpr uint32_t kRefillThreshold = 32;      // idle lanes that trigger a refill of the wave (persistent_trace)
 constexpr int kStatRing = 16;
@@ -400,7 +400,9 @@ int build_bvh(hala_rt_renderer* r) {
   r->bvh.primitives = r->d_instances.ptr; r->bvh.inst_first_tri = r->d_inst_first_tri.ptr;
   r->bvh.instance_count = (uint32_t)r->hs.instances.size(); r->bvh.tri_count = n;
   r->bvh.tris_by_id = r->d_tris_by_id.ptr; r->bvh.tris = r->d_tris.ptr; r->bvh.tri_instance = r->d_tri_instance.ptr; r->bvh.nodes = r->d_nodes.ptr;
-  const std::string e = bvh_build(r->bvh, kLeafMax, r->stream);
+  uint32_t leaf_max = kLeafMax;
+  if (const char* ev = getenv("HALART_LEAF_MAX")) leaf_max = std::min(8u, std::max(1u, (uint32_t)atoi(ev)));  // tuning knob
+  const std::string e = bvh_build(r->bvh, leaf_max, r->stream);
   if (!e.empty()) RT_FAIL(e);
   return configure_traversal(r);
 }

@@ -191,6 +191,28 @@ def bunny_class(subdivisions=6, seed=1234, aspect=16.0 / 9.0, disney=False) -> H
     return s
 
 
+def stacked_sheets(count=4096, seed=3, aspect=1.0) -> HalaScene:
+    """Traversal-stack stress case: `count` large, slightly jittered quads piled inside one small slab, all overlapping
+    in x/y.  Every node's child boxes overlap almost completely, so a ray through the pile hits every child of every node:
+    closest-hit rays visit most of the tree and the per-lane stack grows by up to three entries per level (past the
+    entries kept in LDS, into the global spill area)."""
+    rng = np.random.RandomState(seed)
+    quads = []
+    for i in range(count):
+        z = float(rng.uniform(-0.05, 0.05))
+        dx, dy = rng.uniform(-0.02, 0.02, 2)
+        tilt = float(rng.uniform(-0.01, 0.01))
+        quads.append(((-1 + dx, -1 + dy, z - tilt), (1 + dx, -1 + dy, z + tilt), (1 + dx, 1 + dy, z + tilt), (-1 + dx, 1 + dy, z - tilt)))
+    s = HalaScene()
+    s.materials = [HalaMaterial(type=HalaMaterialType.DIFFUSE, base_color=(0.7, 0.7, 0.7))]
+    prim = _merge_quads(quads); prim.material_index = 0
+    s.meshes = [HalaMesh([prim])]
+    s.nodes = [HalaNode(name="sheets", mesh_index=0),
+               HalaNode(name="camera", camera_index=0, local_transform=look_at_node_transform((0.3, 0.2, 3.0), (0.0, 0.0, 0.0)))]
+    s.cameras = [HalaPerspectiveCamera(aspect=aspect, yfov=math.radians(45.0), znear=0.1)]
+    return s
+
+
 def sky_sun_envmap(width=2048, height=1024, sun_dir=(0.4, 0.6, 0.35), sun_radius_deg=2.0, sun_gain=1.0e4):
     """Config 3 env map: analytic sky gradient + a sun disc 1e4x brighter (exercises the A1 table tails).
     Returns RGBA32F [H, W, 4] with row 0 = top (v = 0 <-> +Y), matching RENDER_SPEC §7.3's (u, v) mapping."""

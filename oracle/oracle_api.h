@@ -151,6 +151,12 @@ void orc_trace_rays_on_bvh4(const void* nodes64, uint32_t node_count, const void
 int orc_validate_bvh4(const void* nodes64, uint32_t node_count, const void* tris48, uint32_t tri_count,
                       const float* ref9, uint32_t* max_depth);
 
+// The oracle's own SAH tree in the product's 4-wide format (greedy surface-area collapse, conservative quantisation) and
+// its triangles in that tree's order: a CPU-built tree to pin the two functions above on, and a quality yardstick for
+// the product's builder.  Returns the node count (query with nodes64_out == NULL); 0 on failure.
+uint32_t orc_scene_export_bvh4(const orc_scene* s, void* nodes64_out, uint32_t capacity);
+void orc_scene_get_bvh_triangles(const orc_scene* s, void* tris48_out);
+
 // ---- the integrator (RENDER_SPEC §5-§8) ------------------------------------------------------------------------
 typedef struct {
   uint32_t width, height;

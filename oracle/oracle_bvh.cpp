@@ -3,6 +3,7 @@
 // product builds its BVH on the GPU and the two are compared through traversal RESULTS, never topology), the
 // traversal rule of RENDER_SPEC §4, a brute-force intersector and a structural validator for product BVHs.
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -601,4 +602,84 @@ extern "C" int orc_validate_bvh4(const void* nodes64, uint32_t node_count, const
   for (uint32_t i = 0; i < tri_count; ++i) if (!seen_tri[i]) return 10;
   if (max_depth) *max_depth = md;
   return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The oracle's own (binned SAH) tree re-expressed in the product's compressed 4-wide format: greedy top-down collapse
+// by surface area, breadth-first numbering, conservative 8-bit quantisation in double (RENDER_SPEC §4.1b).  This is NOT
+// a mirror of the product's builder (which is validated through results and structure only); it gives the CPU tier a
+// 4-wide tree to pin traverse4 / orc_validate_bvh4 on, and the quality probe a SAH tree in the same format.
+// Returns the number of nodes (nodes64_out may be NULL to query); 0 if a leaf holds more than 8 triangles.
+// ---------------------------------------------------------------------------------------------------------
+extern "C" uint32_t orc_scene_export_bvh4(const orc_scene* s, void* nodes64_out, uint32_t capacity) {
+  struct Child { Box box; uint32_t child, count; };  // count > 0: leaf [child, child + count); else binary node index
+  auto children_of = [&](uint32_t bi, Child* out) {
+    const Node& n = s->nodes[bi];
+    int k = 0;
+    if (!(n.count0 == 0 && n.child0 == kAbsent)) { memcpy(out[k].box.mn, n.c0min, 12); memcpy(out[k].box.mx, n.c0max, 12); out[k].child = n.child0; out[k].count = n.count0; ++k; }
+    if (!(n.count1 == 0 && n.child1 == kAbsent)) { memcpy(out[k].box.mn, n.c1min, 12); memcpy(out[k].box.mx, n.c1max, 12); out[k].child = n.child1; out[k].count = n.count1; ++k; }
+    return k;
+  };
+  std::vector<uint32_t> order{0};           // binary root of every 4-node, breadth-first
+  std::vector<std::array<Child, 4>> kids;   // its children
+  std::vector<int> nkids;
+  for (size_t head = 0; head < order.size(); ++head) {
+    std::array<Child, 4> c{};
+    int n = children_of(order[head], c.data());
+    while (n > 0 && n < 4) {
+      int pick = -1; float best = -1.0f;
+      for (int k = 0; k < n; ++k) if (c[k].count == 0 && c[k].box.half_area() > best) { best = c[k].box.half_area(); pick = k; }
+      if (pick < 0) break;
+      Child sub[2];
+      int m = children_of(c[pick].child, sub);
+      if (m == 2) { for (int k = n; k > pick + 1; --k) c[k] = c[k - 1]; c[pick] = sub[0]; c[pick + 1] = sub[1]; ++n; }
+      else if (m == 1) c[pick] = sub[0];
+      else break;
+    }
+    for (int k = 0; k < n; ++k) {
+      if (c[k].count > 8) return 0;
+      if (c[k].count == 0) { order.push_back(c[k].child); c[k].child = (uint32_t)order.size() - 1; }  // now a 4-node index
+    }
+    kids.push_back(c); nkids.push_back(n);
+  }
+  const uint32_t total = (uint32_t)order.size();
+  if (!nodes64_out) return total;
+  if (capacity < total) return 0;
+  Node4* out = (Node4*)nodes64_out;
+  for (uint32_t i = 0; i < total; ++i) {
+    Node4 nd{};
+    const int n = nkids[i];
+    Box all; all.reset();
+    for (int k = 0; k < n; ++k) all.grow(kids[i][k].box);
+    if (n == 0) { for (int a = 0; a < 3; ++a) { all.mn[a] = 0.0f; all.mx[a] = 0.0f; } }
+    int e[3];
+    for (int a = 0; a < 3; ++a) {
+      nd.pmin[a] = all.mn[a];
+      const double q = ((double)all.mx[a] - (double)all.mn[a]) / 255.0;
+      int ex = -100;
+      if (q > 0.0) { (void)std::frexp(q, &ex); ex = std::min(100, std::max(-100, ex)); }  // q = m * 2^ex, m in [0.5, 1)
+      e[a] = ex;
+      nd.exps |= (uint32_t)(ex + 127) << (8 * a);
+    }
+    for (int k = 0; k < 4; ++k) {
+      if (k >= n) { nd.ref[k] = kAbsent; continue; }
+      const Child& ch = kids[i][k];
+      nd.ref[k] = ch.count ? (0x80000000u | ((ch.count - 1u) << 28) | ch.child) : ch.child;
+      for (int a = 0; a < 3; ++a) {
+        const double sc = std::ldexp(1.0, e[a]), base = (double)all.mn[a];
+        double lo = std::floor(((double)ch.box.mn[a] - base) / sc), hi = std::ceil(((double)ch.box.mx[a] - base) / sc);
+        if (base + lo * sc > (double)ch.box.mn[a]) lo -= 1.0;
+        if (base + hi * sc < (double)ch.box.mx[a]) hi += 1.0;
+        lo = std::min(255.0, std::max(0.0, lo)); hi = std::min(255.0, std::max(0.0, hi));
+        nd.qlo[a] |= (uint32_t)lo << (8 * k);
+        nd.qhi[a] |= (uint32_t)hi << (8 * k);
+      }
+    }
+    out[i] = nd;
+  }
+  return total;
+}
+// the oracle's triangles in ITS BVH order (48-B records), i.e. what the leaves of orc_scene_export_bvh4 index
+extern "C" void orc_scene_get_bvh_triangles(const orc_scene* s, void* tris48_out) {
+  memcpy(tris48_out, s->tris.data(), s->tris.size() * sizeof(Tri));
 }

@@ -175,6 +175,18 @@ class OracleScene:
         lib().orc_scene_get_triangles(self._h, fptr(out))
         return out
 
+    def export_bvh4(self):
+        """the oracle's SAH tree in the product's compressed 4-wide format: (nodes [n,16] u32, triangles [m,12] u32)"""
+        fn = lib().orc_scene_export_bvh4
+        fn.restype = C.c_uint32
+        n = fn(self._h, C.c_void_p(0), C.c_uint32(0))
+        assert n > 0
+        nodes = np.zeros((n, 16), dtype=np.uint32)
+        assert fn(self._h, C.c_void_p(nodes.ctypes.data), C.c_uint32(n)) == n
+        tris = np.zeros((self.triangle_count, 12), dtype=np.uint32)
+        lib().orc_scene_get_bvh_triangles(self._h, C.c_void_p(tris.ctypes.data))
+        return nodes, tris
+
     def trace(self, rays, mode=0, count_steps=False, brute=False):
         rays = np.ascontiguousarray(rays, dtype=A.RAY_DTYPE)
         hits = np.empty(rays.shape[0], dtype=A.HIT_DTYPE)
@@ -239,11 +251,12 @@ def trace_on_bvh(nodes_u32, tris_u32, rays, mode=0):
 
 def validate_bvh(nodes_u32, tris_u32, ref_triangles9):
     md = C.c_uint32()
-    ref = np.ascontiguousarray(ref_triangles9, dtype=np.float32)
+    # ref_triangles9 None: containment is checked on v0, v0 + e1, v0 + e2 of the 48-B records instead of the exact vertices
+    ref = np.ascontiguousarray(ref_triangles9, dtype=np.float32) if ref_triangles9 is not None else None
     fn = lib().orc_validate_bvh4
     fn.restype = C.c_int
     rc = fn(C.c_void_p(nodes_u32.ctypes.data), C.c_uint32(nodes_u32.size // 16), C.c_void_p(tris_u32.ctypes.data),
-            C.c_uint32(tris_u32.size // 12), fptr(ref), C.byref(md))
+            C.c_uint32(tris_u32.size // 12), fptr(ref) if ref is not None else C.c_void_p(0), C.byref(md))
     return rc, md.value
 
 

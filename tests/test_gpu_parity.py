@@ -185,6 +185,27 @@ def test_traversal_step_counts_match_oracle_on_same_bvh(halart, oracle):
     r.close()
 
 
+def test_deep_stack_spills_to_global_scratch(halart, oracle):
+    """overlapping sheets: rays hit every child of every node, the traversal stack outgrows its LDS entries; results must
+    still equal brute force, and the step counts the oracle's on the same BVH"""
+    s = scenes.stacked_sheets(count=4096)
+    r = make_renderer(halart, s, 16, 16)
+    osc = oracle.OracleScene(s)
+    info = r.bvh_info()
+    assert 3 * info.max_depth > 12  # more than the LDS part of the stack can hold (traverse.h kStackLds)
+    rays = np.concatenate([osc.camera_rays(48, 48, 0), random_rays(2000, np.array([-1.5, -1.5, -2], dtype=f32), np.array([1.5, 1.5, 2], dtype=f32), 5)])
+    got = r.trace_rays_host(rays, 0)
+    want = osc.trace(rays, 0, brute=True)
+    assert got.tobytes() == want.tobytes()
+    nodes, tris = r.download_bvh()
+    for mode in (1, 0):
+        hits, cnt = r.trace_rays_host(rays, mode, count_steps=True)
+        ohits, ocnt = oracle.trace_on_bvh(nodes, tris, rays, mode)
+        assert cnt == ocnt and np.array_equal(hits["t"], ohits["t"])
+    assert cnt[0] > 20 * len(rays)  # closest-hit rays visit dozens of nodes each here
+    r.close()
+
+
 def test_empty_and_ragged_batches(halart, oracle):
     s = scenes.cornell_box()
     r = make_renderer(halart, s, 16, 16)
