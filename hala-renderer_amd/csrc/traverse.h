@@ -100,6 +100,7 @@ RT_DI void trav_begin(Trav& t, const RayPre& r, float tmax) {
   t.cur = 0; t.sp = 0;
 }
 
+typedef float v2f __attribute__((ext_vector_type(2)));  // operand pair of the packed FP32 instructions
 RT_DI float ubyte_f32(uint32_t w, int c) { return (float)((w >> (8 * c)) & 0xffu); }  // v_cvt_f32_ubyte{c}
 // (key, reference) compare-exchange of the 5-comparator sorting network
 RT_DI void sort2kv(uint32_t& ka, uint32_t& kb, uint32_t& ra, uint32_t& rb) {
@@ -155,16 +156,23 @@ RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, 
   const uint32_t lox = __float_as_uint(q1.x), loy = __float_as_uint(q1.y), loz = __float_as_uint(q1.z);
   const uint32_t hix = __float_as_uint(q1.w), hiy = __float_as_uint(q2.x), hiz = __float_as_uint(q2.y);
   uint32_t ref[4] = {__float_as_uint(q3.x), __float_as_uint(q3.y), __float_as_uint(q3.z), __float_as_uint(q3.w)};
+  // Slab test (§4.3b): tn = max(min(x0,x1), min(y0,y1), min(z0,z1), tmin), tf = min(max(x0,x1), ..., best.t) with
+  // x0/x1 = fma(qlo/qhi, k, a).  qlo <= qhi and fma rounding is monotonic, so min(x0,x1) is simply the plane picked by the
+  // sign of the direction: select the near / far byte words once per node (6 v_cndmask) instead of 6 min/max per child,
+  // and compute (near, far) of one axis with one packed v_pk_fma_f32.  Bit-identical to the min/max form.
+  const bool px = r.idir.x >= 0.0f, py = r.idir.y >= 0.0f, pz = r.idir.z >= 0.0f;
+  const uint32_t nx = px ? lox : hix, fx = px ? hix : lox, ny = py ? loy : hiy, fy = py ? hiy : loy, nz = pz ? loz : hiz, fz = pz ? hiz : loz;
+  const v2f kx2 = {kx, kx}, ky2 = {ky, ky}, kz2 = {kz, kz}, ax2 = {ax, ax}, ay2 = {ay, ay}, az2 = {az, az};
   // ordering key: entry distance (>= tmin >= 0) with the child slot in its two low mantissa bits (ties -> lower slot);
   // misses sort last.  hw_minf / hw_maxf are the one-instruction IEEE minNum / maxNum (v_min3 / v_max3 fuse them).
   uint32_t key[4];
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
-    const float x0 = __fmaf_rn(ubyte_f32(lox, c), kx, ax), x1 = __fmaf_rn(ubyte_f32(hix, c), kx, ax);
-    const float y0 = __fmaf_rn(ubyte_f32(loy, c), ky, ay), y1 = __fmaf_rn(ubyte_f32(hiy, c), ky, ay);
-    const float z0 = __fmaf_rn(ubyte_f32(loz, c), kz, az), z1 = __fmaf_rn(ubyte_f32(hiz, c), kz, az);
-    const float tn = hw_maxf(hw_maxf(hw_minf(x0, x1), hw_minf(y0, y1)), hw_maxf(hw_minf(z0, z1), r.tmin));
-    const float tf = hw_minf(hw_minf(hw_maxf(x0, x1), hw_maxf(y0, y1)), hw_minf(hw_maxf(z0, z1), best.t));
+    const v2f tx = __builtin_elementwise_fma(v2f{ubyte_f32(nx, c), ubyte_f32(fx, c)}, kx2, ax2);
+    const v2f ty = __builtin_elementwise_fma(v2f{ubyte_f32(ny, c), ubyte_f32(fy, c)}, ky2, ay2);
+    const v2f tz = __builtin_elementwise_fma(v2f{ubyte_f32(nz, c), ubyte_f32(fz, c)}, kz2, az2);
+    const float tn = hw_maxf(hw_maxf(tx.x, ty.x), hw_maxf(tz.x, r.tmin));
+    const float tf = hw_minf(hw_minf(tx.y, ty.y), hw_minf(tz.y, best.t));
     const bool hit = ref[c] != kAbsent && tn <= tf * 1.0000004f;
     key[c] = hit ? ((__float_as_uint(tn) & ~3u) | (uint32_t)c) : kMissKey;
   }
