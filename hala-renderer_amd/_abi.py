@@ -148,7 +148,9 @@ class RtStatistics(C.Structure):
                 ("rays_closest_total", C.c_uint64), ("rays_shadow_total", C.c_uint64),
                 ("nodes_closest_total", C.c_uint64), ("tris_closest_total", C.c_uint64),
                 ("nodes_shadow_total", C.c_uint64), ("tris_shadow_total", C.c_uint64),
-                ("rays_closest_counted", C.c_uint64), ("rays_shadow_counted", C.c_uint64)]
+                ("rays_closest_counted", C.c_uint64), ("rays_shadow_counted", C.c_uint64),
+                ("wave_steps_closest_total", C.c_uint64), ("leaf_passes_closest_total", C.c_uint64), ("leaf_lanes_closest_total", C.c_uint64),
+                ("wave_steps_shadow_total", C.c_uint64), ("leaf_passes_shadow_total", C.c_uint64), ("leaf_lanes_shadow_total", C.c_uint64)]
 
 
 class BvhInfo(C.Structure):

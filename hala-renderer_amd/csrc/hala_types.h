@@ -127,6 +127,9 @@ struct Control {
   // only filled by counting launches: steps[kind] = {nodes visited, triangles tested}; kind 0 closest-hit
   // kernel, kind 1 shadow / any-hit kernel
   unsigned long long steps[2][2];
+  // counting launches, wave level: probe[kind] = {wave steps (one node visit by every lane that holds a ray), leaf passes
+  // (executions of one leaf-test copy by a wave), lanes taking part in those passes}: SIMT utilisation of the two code paths
+  unsigned long long probe[2][3];
 };
 
 // wavefront path state, SoA, indexed by pixel slot

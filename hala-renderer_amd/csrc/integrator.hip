@@ -147,7 +147,7 @@ RT_DI uint32_t work_take(WorkCounters* wc, WorkCursor& c, uint32_t n, uint32_t w
 // Source: load(i, &o, &d, &tmin, &tmax) fetches queue entry i; done(i, trav, found) consumes the result.
 template <bool ANY, bool COUNT, bool STAGED, class Source>
 RT_DI void persistent_trace(const SceneView& sv, const TraverseLds& lds, uint2* spill, WorkCounters* work, uint32_t n, uint32_t refill,
-                            Source& src, uint32_t& cn, uint32_t& ct) {
+                            Source& src, StepCounters& sc) {
   WorkCursor cur = work_begin(n);
   bool more = n > 0u;  // wave-uniform: some shard may still hold rays
   bool has = false;
@@ -173,8 +173,9 @@ RT_DI void persistent_trace(const SceneView& sv, const TraverseLds& lds, uint2* 
     }
     if (__ballot(has) == 0ull) { if (!more) break; continue; }
     for (;;) {
+      if (COUNT && lane_id() == 0u) sc.wave_steps++;  // lane 0 runs every iteration of this wave-uniform loop
       if (has) {
-        if (trav_step<ANY, COUNT, STAGED>(sv, lds, spill, t, cn, ct)) { src.done(idx, t, pay); has = false; }
+        if (trav_step<ANY, COUNT, STAGED>(sv, lds, spill, t, sc)) { src.done(idx, t, pay); has = false; }
       }
       const uint32_t nidle = (uint32_t)__popcll(__ballot(!has));
       if (nidle == 64u || (more && nidle >= refill)) break;
@@ -224,6 +225,15 @@ struct ShadowSource {
 
 extern __shared__ __attribute__((aligned(16))) unsigned char g_smem[];
 
+// counting launches: one set of atomics per wave
+RT_DI void flush_counters(Control* ctl, int kind, const StepCounters& sc) {
+  const uint32_t v[5] = {wave_sum(sc.nodes), wave_sum(sc.tris), wave_sum(sc.wave_steps), wave_sum(sc.leaf_passes), wave_sum(sc.leaf_lanes)};
+  if (lane_id() != 0u) return;
+  atomicAdd(&ctl->steps[kind][0], (unsigned long long)v[0]); atomicAdd(&ctl->steps[kind][1], (unsigned long long)v[1]);
+  atomicAdd(&ctl->probe[kind][0], (unsigned long long)v[2]); atomicAdd(&ctl->probe[kind][1], (unsigned long long)v[3]);
+  atomicAdd(&ctl->probe[kind][2], (unsigned long long)v[4]);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // K5a: persistent closest-hit traversal over a compact ray queue (coalesced 32-B ray reads, 16-B hit writes)
 // ---------------------------------------------------------------------------------------------------------
@@ -235,16 +245,13 @@ k_trace_batch(SceneView sv, const hala_ray* __restrict__ rays, hala_hit* __restr
   const TraverseLds lds = stage_bvh<STAGED>(sv, g_smem);
   const uint32_t n = n_ptr ? *n_ptr : n_imm;
   uint2* spill = spill_base ? spill_base + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * kStackSpill : nullptr;
-  uint32_t cn = 0, ct = 0;
+  StepCounters sc;
   if (account && blockIdx.x == 0 && threadIdx.x == 0) {
     if (ANY) ctl->rays_shadow += n; else ctl->rays_closest += n;
   }
   BatchSource src{rays, hits, ANY};
-  persistent_trace<ANY, COUNT, STAGED>(sv, lds, spill, work, n, refill, src, cn, ct);
-  if (COUNT) {
-    cn = wave_sum(cn); ct = wave_sum(ct);
-    if (lane_id() == 0u) { atomicAdd(&ctl->steps[ANY ? 1 : 0][0], (unsigned long long)cn); atomicAdd(&ctl->steps[ANY ? 1 : 0][1], (unsigned long long)ct); }
-  }
+  persistent_trace<ANY, COUNT, STAGED>(sv, lds, spill, work, n, refill, src, sc);
+  if (COUNT) flush_counters(ctl, ANY ? 1 : 0, sc);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -258,13 +265,10 @@ k_trace_shadow(SceneView sv, Queues q, PathState ps, Control* __restrict__ ctl, 
   const TraverseLds lds = stage_bvh<STAGED>(sv, g_smem);
   const uint32_t n = ctl->n_shadow[kind][depth];
   uint2* spill = spill_base ? spill_base + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * kStackSpill : nullptr;
-  uint32_t cn = 0, ct = 0;
+  StepCounters sc;
   ShadowSource src{q.shadow[kind], ps.radiance_rng};
-  persistent_trace<true, COUNT, STAGED>(sv, lds, spill, &ctl->work_shadow[kind], n, refill, src, cn, ct);
-  if (COUNT) {
-    cn = wave_sum(cn); ct = wave_sum(ct);
-    if (lane_id() == 0u) { atomicAdd(&ctl->steps[1][0], (unsigned long long)cn); atomicAdd(&ctl->steps[1][1], (unsigned long long)ct); }
-  }
+  persistent_trace<true, COUNT, STAGED>(sv, lds, spill, &ctl->work_shadow[kind], n, refill, src, sc);
+  if (COUNT) flush_counters(ctl, 1, sc);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -82,7 +82,7 @@ struct TraceEvents {
   hipEvent_t frame_begin = nullptr, frame_end = nullptr;
   bool pending = false, counted = false;
   uint32_t samples = 1;  // frames rendered by this wavefront pass
-  unsigned long long* host_counts = nullptr;  // pinned: rays_closest, rays_shadow, steps[2][2]
+  unsigned long long* host_counts = nullptr;  // pinned: rays_closest, rays_shadow, steps[2][2], probe[2][3]
 };
 
 }  // namespace
@@ -240,6 +240,8 @@ struct hala_rt_renderer {
       stats.nodes_closest_total += t.host_counts[2]; stats.tris_closest_total += t.host_counts[3];
       stats.nodes_shadow_total += t.host_counts[4]; stats.tris_shadow_total += t.host_counts[5];
       stats.rays_closest_counted += rc; stats.rays_shadow_counted += rs;
+      stats.wave_steps_closest_total += t.host_counts[6]; stats.leaf_passes_closest_total += t.host_counts[7]; stats.leaf_lanes_closest_total += t.host_counts[8];
+      stats.wave_steps_shadow_total += t.host_counts[9]; stats.leaf_passes_shadow_total += t.host_counts[10]; stats.leaf_lanes_shadow_total += t.host_counts[11];
     }
     t.pending = false;
   }
@@ -619,7 +621,7 @@ static int update_impl(hala_rt_renderer* r, uint32_t frames) {
   TraceEvents& te = r->ring[r->ring_pos];
   r->ring_pos = (r->ring_pos + 1) % kStatRing;
   r->resolve_slot(te);
-  if (!te.frame_begin) { RT_HIP(hipEventCreate(&te.frame_begin)); RT_HIP(hipEventCreate(&te.frame_end)); RT_HIP(hipHostMalloc(reinterpret_cast<void**>(&te.host_counts), 6 * sizeof(unsigned long long), hipHostMallocDefault)); }
+  if (!te.frame_begin) { RT_HIP(hipEventCreate(&te.frame_begin)); RT_HIP(hipEventCreate(&te.frame_end)); RT_HIP(hipHostMalloc(reinterpret_cast<void**>(&te.host_counts), 12 * sizeof(unsigned long long), hipHostMallocDefault)); }
   te.used = 0; te.counted = r->counting;
 
   te.samples = samples;
@@ -646,7 +648,7 @@ static int update_impl(hala_rt_renderer* r, uint32_t frames) {
     RT_HIP(hipEventRecord(d, s));
   }
   launch_resolve(fc, ps, r->img_local[0].ptr, r->img_local[1].ptr, r->img_local[2].ptr, r->img_local[3].ptr, s);
-  RT_HIP(hipMemcpyAsync(te.host_counts, &ctl->rays_closest, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  RT_HIP(hipMemcpyAsync(te.host_counts, &ctl->rays_closest, 12 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
   RT_HIP(hipEventRecord(te.frame_end, s));
   RT_HIP(hipGetLastError());
   te.pending = true;

@@ -109,7 +109,8 @@ RT_DI void sort2kv(uint32_t& ka, uint32_t& kb, uint32_t& ra, uint32_t& rb) {
   ka = k0; kb = k1; ra = r0; rb = r1;
 }
 constexpr uint32_t kMissKey = 0xffffffffu;
-RT_DI float key_tn(uint32_t key) { return __uint_as_float(key & ~3u); }
+constexpr uint32_t kInnerKey = 0x80000000u;  // key bit of an inner child: inner children sort after all leaf children
+RT_DI float key_tn(uint32_t key) { return __uint_as_float(key & 0x7ffffffcu); }
 
 // closest-hit / any-hit test of one leaf (count <= 8 triangles from `first`, storage order; fetched two at a time so that
 // a leaf costs ceil(count/2) memory round trips)
@@ -138,16 +139,21 @@ RT_DI bool leaf_test(const SceneView& sv, const TraverseLds& lds, const RayPre& 
   return false;
 }
 
+// per-lane tallies of counting launches (summed over the wave at kernel end)
+struct StepCounters {
+  uint32_t nodes = 0, tris = 0, leaf_lanes = 0, leaf_passes = 0, wave_steps = 0;
+};
+
 // returns true when the ray is finished (ANY: also on the first hit inside (tmin, tmax))
 template <bool ANY, bool COUNT, bool STAGED>
-RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, Trav& t, uint32_t& n_nodes, uint32_t& n_tris) {
+RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, Trav& t, StepCounters& sc) {
   uint2* stack = lds.stack + threadIdx.x;
   const RayPre& r = t.r;
   HitRec& best = t.best;
   int sp = t.sp;
   const float4* p = (STAGED ? lds.nodes : reinterpret_cast<const float4*>(sv.nodes)) + (size_t)t.cur * 4;
   const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
-  if (COUNT) n_nodes++;
+  if (COUNT) sc.nodes++;
   // plane distances without materialising the planes: t = q * (2^e * idir) + (pmin * idir - o * idir)
   const uint32_t ex = __float_as_uint(q0.w);
   const float kx = __uint_as_float((ex & 0xffu) << 23) * r.idir.x, ky = __uint_as_float(((ex >> 8) & 0xffu) << 23) * r.idir.y,
@@ -163,8 +169,11 @@ RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, 
   const bool px = r.idir.x >= 0.0f, py = r.idir.y >= 0.0f, pz = r.idir.z >= 0.0f;
   const uint32_t nx = px ? lox : hix, fx = px ? hix : lox, ny = py ? loy : hiy, fy = py ? hiy : loy, nz = pz ? loz : hiz, fz = pz ? hiz : loz;
   const v2f kx2 = {kx, kx}, ky2 = {ky, ky}, kz2 = {kz, kz}, ax2 = {ax, ax}, ay2 = {ay, ay}, az2 = {az, az};
-  // ordering key: entry distance (>= tmin >= 0) with the child slot in its two low mantissa bits (ties -> lower slot);
-  // misses sort last.  hw_minf / hw_maxf are the one-instruction IEEE minNum / maxNum (v_min3 / v_max3 fuse them).
+  // ordering key: entry distance (>= tmin >= +0, so its sign bit is free) with the child slot in its two low mantissa
+  // bits (ties -> lower slot) and the sign bit set for inner children: one sort puts the leaves first, nearest first,
+  // then the inner children, nearest first, then the misses.  Lane by lane that is the order they are processed in anyway;
+  // wave-wide it lines the lanes' k-th leaves up at position k, so the k-th copy of the triangle test runs for every lane
+  // that has a k-th leaf instead of one copy per sorted position at a few percent lane utilisation (profiles/r01_h_pmc_*).  hw_minf / hw_maxf are the one-instruction IEEE minNum / maxNum (v_min3 / v_max3 fuse them).
   uint32_t key[4];
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
@@ -174,7 +183,7 @@ RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, 
     const float tn = hw_maxf(hw_maxf(tx.x, ty.x), hw_maxf(tz.x, r.tmin));
     const float tf = hw_minf(hw_minf(tx.y, ty.y), hw_minf(tz.y, best.t));
     const bool hit = ref[c] != kAbsent && tn <= tf * 1.0000004f;
-    key[c] = hit ? ((__float_as_uint(tn) & ~3u) | (uint32_t)c) : kMissKey;
+    key[c] = hit ? ((__float_as_uint(tn) & ~3u) | (uint32_t)c | (~ref[c] & kInnerKey)) : kMissKey;
   }
   sort2kv(key[0], key[1], ref[0], ref[1]); sort2kv(key[2], key[3], ref[2], ref[3]); sort2kv(key[0], key[2], ref[0], ref[2]);
   sort2kv(key[1], key[3], ref[1], ref[3]); sort2kv(key[1], key[2], ref[1], ref[2]);
@@ -183,21 +192,25 @@ RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, 
   uint32_t next = kAbsent, next_key = 0;
 #pragma unroll
   for (int k = 3; k >= 0; --k) {
-    if (key[k] == kMissKey || (ref[k] & kLeafRef)) continue;
+    if (key[k] == kMissKey || !(key[k] & kInnerKey)) continue;
     if (next != kAbsent) {
       if (sp < kStackLds) stack[sp * kTraverseThreads] = make_uint2(next_key, next); else spill[sp - kStackLds] = make_uint2(next_key, next);
       ++sp;
     }
     next = ref[k]; next_key = key[k];
   }
-  // leaves, nearest first (each one can shrink best.t for the ones after it).  A flattened loop over triangle pairs with a
-  // per-lane cursor keeps lanes in lock step but its cursor selects cost more VALU than they save (profiles/r01_h_*).
+  // leaves, nearest first (each one can shrink best.t for the ones after it)
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    if (key[k] == kMissKey) break;
-    if (!(ref[k] & kLeafRef) || !(key_tn(key[k]) <= best.t)) continue;
+    if (key[k] & kInnerKey) break;  // inner child or miss: no more leaves
+    if (!(key_tn(key[k]) <= best.t)) break;  // sorted: the leaves after it are out of reach too
     const uint32_t count = ((ref[k] >> 28) & 7u) + 1u;
-    if (COUNT) n_tris += count;
+    if (COUNT) {
+      sc.tris += count;
+      const unsigned long long m = __ballot(1);  // the lanes inside this copy of the leaf test
+      sc.leaf_lanes++;
+      if ((uint32_t)__ffsll((long long)m) - 1u == (threadIdx.x & 63u)) sc.leaf_passes++;
+    }
     if (leaf_test<ANY, STAGED>(sv, lds, r, t.tmax, best, ref[k] & 0x0fffffffu, count)) return true;
   }
   // go on with the nearest inner child if it is still in reach, else with the first stack entry that is

@@ -362,6 +362,11 @@ typedef struct hala_rt_statistics {
    * rays those counts belong to */
   uint64_t nodes_closest_total, tris_closest_total, nodes_shadow_total, tris_shadow_total;
   uint64_t rays_closest_counted, rays_shadow_counted;
+  /* counting launches, wave level (SIMT utilisation): wave steps = node visits issued by a 64-lane wave (lane
+   * utilisation of the node path = nodes / (64 * wave_steps)); leaf passes = executions of a leaf-test copy by a
+   * wave, leaf lanes = lanes taking part in them (utilisation of the leaf path = leaf_lanes / (64 * leaf_passes)) */
+  uint64_t wave_steps_closest_total, leaf_passes_closest_total, leaf_lanes_closest_total;
+  uint64_t wave_steps_shadow_total, leaf_passes_shadow_total, leaf_lanes_shadow_total;
 } hala_rt_statistics;
 int hala_rt_get_info(hala_rt_renderer* r, hala_rt_info* out);
 int hala_rt_get_statistics(hala_rt_renderer* r, hala_rt_statistics* out);

@@ -65,6 +65,13 @@ def run(name, scene, w, h, spp, env=None, max_depth=5, rr_depth=3, steps=3):
         "shadow_nodes_per_ray": round((c1.nodes_shadow_total - c0.nodes_shadow_total) / ns, 2),
         "shadow_tris_per_ray": round((c1.tris_shadow_total - c0.tris_shadow_total) / ns, 2),
     }
+    for kind in ("closest", "shadow"):  # SIMT utilisation of the two code paths of the traversal kernels (counting pass)
+        ws = getattr(c1, f"wave_steps_{kind}_total") - getattr(c0, f"wave_steps_{kind}_total")
+        lp = getattr(c1, f"leaf_passes_{kind}_total") - getattr(c0, f"leaf_passes_{kind}_total")
+        ll = getattr(c1, f"leaf_lanes_{kind}_total") - getattr(c0, f"leaf_lanes_{kind}_total")
+        nn = getattr(c1, f"nodes_{kind}_total") - getattr(c0, f"nodes_{kind}_total")
+        out[f"{kind}_simt"] = {"node_path_lanes": round(nn / max(ws, 1), 1), "leaf_passes_per_wave_step": round(lp / max(ws, 1), 2),
+                               "leaf_path_lanes": round(ll / max(lp, 1), 1)}
     out["closest_alg_GBps"] = round((48 + 64 * out["closest_nodes_per_ray"] + 48 * out["closest_tris_per_ray"]) * out["closest_grays_in_kernel"], 1)
     img = r.read_image(0)
     out["mean_radiance"] = round(float(img[..., :3].mean()), 4)
