@@ -238,7 +238,7 @@ RT_DI void flush_counters(Control* ctl, int kind, const StepCounters& sc) {
 // K5a: persistent closest-hit traversal over a compact ray queue (coalesced 32-B ray reads, 16-B hit writes)
 // ---------------------------------------------------------------------------------------------------------
 template <bool ANY, bool COUNT, bool STAGED>
-__global__ void __launch_bounds__(kTraverseThreads, kTraverseWavesPerSimd)
+__global__ void __launch_bounds__(kTraverseThreads, STAGED ? kTraverseWavesPerSimdStaged : kTraverseWavesPerSimd)
 k_trace_batch(SceneView sv, const hala_ray* __restrict__ rays, hala_hit* __restrict__ hits, const uint32_t* __restrict__ n_ptr,
               uint32_t n_imm, WorkCounters* __restrict__ work, uint2* __restrict__ spill_base, Control* __restrict__ ctl, int account,
               uint32_t refill) {
@@ -259,7 +259,7 @@ k_trace_batch(SceneView sv, const hala_ray* __restrict__ rays, hala_hit* __restr
 // path's radiance in the fixed order light, environment (RENDER_SPEC §6)
 // ---------------------------------------------------------------------------------------------------------
 template <bool COUNT, bool STAGED>
-__global__ void __launch_bounds__(kTraverseThreads, kTraverseWavesPerSimd)
+__global__ void __launch_bounds__(kTraverseThreads, STAGED ? kTraverseWavesPerSimdStaged : kTraverseWavesPerSimd)
 k_trace_shadow(SceneView sv, Queues q, PathState ps, Control* __restrict__ ctl, uint32_t depth, uint32_t kind, uint2* __restrict__ spill_base,
                uint32_t refill) {
   const TraverseLds lds = stage_bvh<STAGED>(sv, g_smem);

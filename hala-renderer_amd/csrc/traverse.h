@@ -24,6 +24,10 @@ constexpr int kTraverseThreads = 256;
 #define RT_WAVES_PER_SIMD 6  // profiles/r01_e_variant_sweep.txt, re-checked for BVH4 in profiles/r01_h_variant_sweep.txt
 #endif
 constexpr int kTraverseWavesPerSimd = RT_WAVES_PER_SIMD;
+#ifndef RT_WAVES_PER_SIMD_STAGED
+#define RT_WAVES_PER_SIMD_STAGED 4
+#endif
+constexpr int kTraverseWavesPerSimdStaged = RT_WAVES_PER_SIMD_STAGED;
 // Per-lane traversal stack: 8-B entries (ordering key = entry distance | slot, child reference).  96 B of LDS per lane
 // = 24 KB per workgroup: six workgroups plus their staged BVH fill the 160 KB of a CU at 6 waves/SIMD.
 constexpr int kStackLds = 12;    // entries kept in LDS per lane
@@ -112,27 +116,76 @@ constexpr uint32_t kMissKey = 0xffffffffu;
 constexpr uint32_t kInnerKey = 0x80000000u;  // key bit of an inner child: inner children sort after all leaf children
 RT_DI float key_tn(uint32_t key) { return __uint_as_float(key & 0x7ffffffcu); }
 
-// closest-hit / any-hit test of one leaf (count <= 8 triangles from `first`, storage order; fetched two at a time so that
-// a leaf costs ceil(count/2) memory round trips)
+// §4.2 for TWO triangles at once: the same operation sequence as tri_test, component 0 = first triangle, component 1 =
+// second, on the packed FP32 pipe (v_pk_mul / v_pk_fma / v_pk_add: two IEEE binary32 results per instruction, each
+// rounded exactly like the scalar instruction).  A triangle pair costs about what one scalar test does; the kernels
+// are VALU-issue bound and leaves hold up to two triangles.
+RT_DI v2f pk2(float a, float b) { return v2f{a, b}; }
+RT_DI v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+RT_DI v2f pk_dot3(v2f ax, v2f ay, v2f az, v2f bx, v2f by, v2f bz) { return pk_fma(az, bz, pk_fma(ay, by, ax * bx)); }
+RT_DI void tri_test2(const RayPre& r, float4 a0, float4 b0, float4 c0, float4 a1, float4 b1, float4 c1, bool ok[2], float t[2], float u[2],
+                     float v[2]) {
+  const v2f dx = pk2(r.d.x, r.d.x), dy = pk2(r.d.y, r.d.y), dz = pk2(r.d.z, r.d.z);
+  const v2f e1x = pk2(b0.x, b1.x), e1y = pk2(b0.y, b1.y), e1z = pk2(b0.z, b1.z);
+  const v2f e2x = pk2(c0.x, c1.x), e2y = pk2(c0.y, c1.y), e2z = pk2(c0.z, c1.z);
+  // p = cross3(d, e2)
+  const v2f px = pk_fma(dy, e2z, -(dz * e2y)), py = pk_fma(dz, e2x, -(dx * e2z)), pz = pk_fma(dx, e2y, -(dy * e2x));
+  const v2f det = pk_dot3(e1x, e1y, e1z, px, py, pz);
+  const v2f inv = pk2(1.0f / det.x, 1.0f / det.y);
+  const v2f tvx = pk2(r.o.x, r.o.x) - pk2(a0.x, a1.x), tvy = pk2(r.o.y, r.o.y) - pk2(a0.y, a1.y), tvz = pk2(r.o.z, r.o.z) - pk2(a0.z, a1.z);
+  const v2f uu = pk_dot3(tvx, tvy, tvz, px, py, pz) * inv;
+  // q = cross3(tv, e1)
+  const v2f qx = pk_fma(tvy, e1z, -(tvz * e1y)), qy = pk_fma(tvz, e1x, -(tvx * e1z)), qz = pk_fma(tvx, e1y, -(tvy * e1x));
+  const v2f vv = pk_dot3(dx, dy, dz, qx, qy, qz) * inv;
+  const v2f tt = pk_dot3(e2x, e2y, e2z, qx, qy, qz) * inv;
+  const v2f uv = uu + vv;
+  ok[0] = det.x != 0.0f && uu.x >= 0.0f && uu.x <= 1.0f && vv.x >= 0.0f && uv.x <= 1.0f;
+  ok[1] = det.y != 0.0f && uu.y >= 0.0f && uu.y <= 1.0f && vv.y >= 0.0f && uv.y <= 1.0f;
+  t[0] = tt.x; t[1] = tt.y; u[0] = uu.x; u[1] = uu.y; v[0] = vv.x; v[1] = vv.y;
+}
+
+// closest-hit / any-hit test of one leaf (count <= 8 triangles from `first`, storage order; fetched and tested two at a
+// time: a leaf costs ceil(count/2) memory round trips and ceil(count/2) packed triangle tests)
 template <bool ANY, bool STAGED>
 RT_DI bool leaf_test(const SceneView& sv, const TraverseLds& lds, const RayPre& r, float tmax, HitRec& best, uint32_t first, uint32_t count) {
   const float4* base = STAGED ? lds.tris : reinterpret_cast<const float4*>(sv.tris);
   for (uint32_t i = 0; i < count; i += 2u) {
     const bool two = i + 1u < count;
     const float4* p = base + (size_t)(first + i) * 3;
-    float4 a0 = p[0], b0 = p[1], c0 = p[2], a1, b1, c1;
-    if (two) { a1 = p[3]; b1 = p[4]; c1 = p[5]; }
+    if (STAGED) {
+      // LDS-resident scenes (4 waves/SIMD, 128 VGPRs): the pair is tested on the packed pipe
+      const float4 a0 = p[0], b0 = p[1], c0 = p[2];
+      float4 a1 = a0, b1 = b0, c1 = c0;  // a single triangle is tested against itself in the second component (result unused)
+      if (two) { a1 = p[3]; b1 = p[4]; c1 = p[5]; }
+      bool ok[2]; float tt[2], uu[2], vv[2];
+      tri_test2(r, a0, b0, c0, a1, b1, c1, ok, tt, uu, vv);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      if (j == 1 && !two) break;
-      const float4 a = j ? a1 : a0, b = j ? b1 : b0, c = j ? c1 : c0;
-      float t, u, v;
-      if (!tri_test(r, a, b, c, &t, &u, &v)) continue;
-      const uint32_t id = __float_as_uint(a.w);
-      if (ANY) {
-        if (t > r.tmin && t < tmax) { best.t = t; best.u = u; best.v = v; best.prim = id; return true; }
-      } else if (t > r.tmin && (t < best.t || (t == best.t && id < best.prim))) {
-        best.t = t; best.u = u; best.v = v; best.prim = id;
+      for (int j = 0; j < 2; ++j) {
+        if (!ok[j] || (j == 1 && !two)) continue;
+        const uint32_t id = __float_as_uint(j ? a1.w : a0.w);
+        if (ANY) {
+          if (tt[j] > r.tmin && tt[j] < tmax) { best.t = tt[j]; best.u = uu[j]; best.v = vv[j]; best.prim = id; return true; }
+        } else if (tt[j] > r.tmin && (tt[j] < best.t || (tt[j] == best.t && id < best.prim))) {
+          best.t = tt[j]; best.u = uu[j]; best.v = vv[j]; best.prim = id;
+        }
+      }
+    } else {
+      // large scenes keep 6 waves/SIMD to hide L2 / Infinity Cache latency; the register pairs of the packed form would
+      // spill there (profiles/r01_h_packed_tri.txt), so the two triangles are tested one after the other
+      float4 a0 = p[0], b0 = p[1], c0 = p[2], a1, b1, c1;
+      if (two) { a1 = p[3]; b1 = p[4]; c1 = p[5]; }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (j == 1 && !two) break;
+        const float4 a = j ? a1 : a0, b = j ? b1 : b0, c = j ? c1 : c0;
+        float t, u, v;
+        if (!tri_test(r, a, b, c, &t, &u, &v)) continue;
+        const uint32_t id = __float_as_uint(a.w);
+        if (ANY) {
+          if (t > r.tmin && t < tmax) { best.t = t; best.u = u; best.v = v; best.prim = id; return true; }
+        } else if (t > r.tmin && (t < best.t || (t == best.t && id < best.prim))) {
+          best.t = t; best.u = u; best.v = v; best.prim = id;
+        }
       }
     }
   }

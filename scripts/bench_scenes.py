@@ -16,7 +16,7 @@ import hala_renderer_amd as H  # noqa: E402
 from hala_renderer_amd import scenes  # noqa: E402
 
 
-def run(name, scene, w, h, spp, env=None, max_depth=5, rr_depth=3, steps=3):
+def run(name, scene, w, h, spp, env=None, max_depth=5, rr_depth=3, steps=8):
     t0 = time.perf_counter()
     r = H.HalaRenderer(name, w, h, max_depth, rr_depth, False, False, False, 0)
     if env is not None:
