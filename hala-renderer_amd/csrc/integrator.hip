@@ -2,7 +2,8 @@
 // `trace_rays(width, height, 1)` (src/rt_renderer.rs:458-464), as HIP kernels for gfx950.
 //
 // One update() = one sample per pixel =
-//   raygen -> for each bounce { traverse_closest -> shade (+ballot compaction) -> traverse_shadow } -> resolve
+//   for each bounce { traverse_closest (depth 0: camera rays generated in place) -> shade (+ballot compaction) ->
+//   traverse_shadow } -> resolve
 // All queue sizes live in a device control block; nothing returns to the host inside a frame.
 #include <hip/hip_runtime.h>
 
@@ -144,7 +145,7 @@ RT_DI uint32_t work_take(WorkCounters* wc, WorkCursor& c, uint32_t n, uint32_t w
 // The persistent wavefront loop: every lane owns at most one ray in flight; whenever `refill` or more lanes are idle
 // (and the queue is not dry) the wave dequeues exactly that many rays and hands them to its idle lanes by ballot rank
 // — consecutive queue entries go to consecutive idle lanes, so refill loads stay as coalesced as the holes allow.
-// Source: load(i, &o, &d, &tmin, &tmax) fetches queue entry i; done(i, trav, found) consumes the result.
+// Source: load(i, &o, &d, &tmin, &tmax) fetches queue entry i (false: no ray there); done(i, trav, payload) consumes the result.
 template <bool ANY, bool COUNT, bool STAGED, class Source>
 RT_DI void persistent_trace(const SceneView& sv, const TraverseLds& lds, uint2* spill, WorkCounters* work, uint32_t n, uint32_t refill,
                             Source& src, StepCounters& sc) {
@@ -165,9 +166,10 @@ RT_DI void persistent_trace(const SceneView& sv, const TraverseLds& lds, uint2* 
         if (rank < got) {
           idx = base + rank;
           f3 o, d; float tmin, tmax;
-          src.load(idx, &o, &d, &tmin, &tmax, &pay);
-          trav_begin(t, make_ray(o, d, tmin), tmax);
-          has = true;
+          if (src.load(idx, &o, &d, &tmin, &tmax, &pay)) {  // false: the source had no ray for this entry and has dealt with it
+            trav_begin(t, make_ray(o, d, tmin), tmax);
+            has = true;
+          }
         }
       }
     }
@@ -188,10 +190,11 @@ struct BatchSource {
   const hala_ray* rays;
   hala_hit* hits;
   bool any;
-  RT_DI void load(uint32_t i, f3* o, f3* d, float* tmin, float* tmax, Payload*) const {
+  RT_DI bool load(uint32_t i, f3* o, f3* d, float* tmin, float* tmax, Payload*) const {
     const float4* rp = reinterpret_cast<const float4*>(rays + i);
     const float4 ro = rp[0], rd = rp[1];
     *o = mk3(ro.x, ro.y, ro.z); *d = mk3(rd.x, rd.y, rd.z); *tmin = ro.w; *tmax = rd.w;
+    return true;
   }
   RT_DI void done(uint32_t i, const Trav& t, const Payload&) const {
     const bool found = t.best.prim != kAbsent;
@@ -201,15 +204,46 @@ struct BatchSource {
     reinterpret_cast<float4*>(hits)[i] = out;
   }
 };
+// The camera ray of path slot `slot` (RENDER_SPEC §5) and the RNG state after it; false for the padding slots of a
+// sharded frame.  Primary rays are never stored: the depth-0 traversal and the depth-0 shading both evaluate this.
+RT_DI bool primary_ray(const FrameConst& fc, const SceneView& sv, uint32_t slot, f3* o, f3* d, uint32_t* rng) {
+  const uint32_t sample = slot / fc.pixel_slots, pslot = slot - sample * fc.pixel_slots;
+  uint32_t px = 0, py = 0;
+  *o = splat3(0.0f); *d = mk3(0.0f, 0.0f, 1.0f); *rng = 0u;
+  if (!slot_to_pixel(fc, pslot, &px, &py)) return false;
+  uint32_t state = rng_init(py * fc.width + px, fc.u.frame_index + sample);
+  camera_ray(fc, sv.cameras[fc.u.camera_index], px, py, state, o, d);
+  *rng = state;
+  return true;
+}
+struct CameraSource {
+  struct Payload {};
+  const FrameConst& fc;
+  const SceneView& sv;
+  hala_hit* hits;
+  RT_DI bool load(uint32_t i, f3* o, f3* d, float* tmin, float* tmax, Payload*) const {
+    uint32_t rng;
+    *tmin = 0.0f; *tmax = kTMax;
+    if (primary_ray(fc, sv, i, o, d, &rng)) return true;
+    reinterpret_cast<float4*>(hits)[i] = make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(kAbsent));  // padding slot: no ray
+    return false;
+  }
+  RT_DI void done(uint32_t i, const Trav& t, const Payload&) const {
+    const bool found = t.best.prim != kAbsent;
+    reinterpret_cast<float4*>(hits)[i] = found ? make_float4(t.best.t, t.best.u, t.best.v, __uint_as_float(t.best.prim))
+                                               : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(kAbsent));
+  }
+};
 struct ShadowSource {
   struct Payload { float4 cs; };  // contribution.xyz | pixel slot, fetched with the ray (one coalesced 48-B record)
   const ShadowEntry* entries;
   float4* radiance_rng;
-  RT_DI void load(uint32_t i, f3* o, f3* d, float* tmin, float* tmax, Payload* p) const {
+  RT_DI bool load(uint32_t i, f3* o, f3* d, float* tmin, float* tmax, Payload* p) const {
     const float4* e = reinterpret_cast<const float4*>(entries + i);
     const float4 ro = e[0], rd = e[1];
     p->cs = e[2];
     *o = mk3(ro.x, ro.y, ro.z); *d = mk3(rd.x, rd.y, rd.z); *tmin = ro.w; *tmax = rd.w;
+    return true;
   }
   // A path owns at most one connection per queue and the two queues are traced by separate launches, so each radiance
   // word receives at most ONE add per launch: a fire-and-forget float atomic is then exactly `L = L + c` (one IEEE add,
@@ -254,6 +288,21 @@ k_trace_batch(SceneView sv, const hala_ray* __restrict__ rays, hala_hit* __restr
   if (COUNT) flush_counters(ctl, ANY ? 1 : 0, sc);
 }
 
+// K5a at depth 0: the camera rays are generated in the lanes that trace them (RENDER_SPEC §5) — no ray-generation kernel,
+// no primary-ray queue in HBM; entry i of the hit queue belongs to path slot i.  `n_account` = real (non-padding) paths.
+template <bool COUNT, bool STAGED>
+__global__ void __launch_bounds__(kTraverseThreads, STAGED ? kTraverseWavesPerSimdStaged : kTraverseWavesPerSimd)
+k_trace_primary(SceneView sv, FrameConst fc, hala_hit* __restrict__ hits, WorkCounters* __restrict__ work, uint2* __restrict__ spill_base,
+                Control* __restrict__ ctl, uint32_t n_account, uint32_t refill) {
+  const TraverseLds lds = stage_bvh<STAGED>(sv, g_smem);
+  uint2* spill = spill_base ? spill_base + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * kStackSpill : nullptr;
+  StepCounters sc;
+  if (blockIdx.x == 0 && threadIdx.x == 0) ctl->rays_closest += n_account;
+  CameraSource src{fc, sv, hits};
+  persistent_trace<false, COUNT, STAGED>(sv, lds, spill, work, fc.slot_count, refill, src, sc);
+  if (COUNT) flush_counters(ctl, 0, sc);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // K5c: shadow traversal of the NEE connections of one bounce; unoccluded contributions are added to the
 // path's radiance in the fixed order light, environment (RENDER_SPEC §6)
@@ -272,48 +321,15 @@ k_trace_shadow(SceneView sv, Queues q, PathState ps, Control* __restrict__ ctl, 
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// raygen: one camera ray per pixel slot (RENDER_SPEC §5)
-// ---------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_raygen(FrameConst fc, SceneView sv, Queues q, PathState ps, Control* __restrict__ ctl) {
-  const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t sample = slot / fc.pixel_slots, pslot = slot - sample * fc.pixel_slots;
-  uint32_t px = 0, py = 0;
-  const bool valid = slot < fc.slot_count && slot_to_pixel(fc, pslot, &px, &py);
-  f3 o = splat3(0.0f), d = mk3(0.0f, 0.0f, 1.0f);
-  uint32_t rng = 0;
-  if (valid) {
-    rng = rng_init(py * fc.width + px, fc.u.frame_index + sample);
-    camera_ray(fc, sv.cameras[fc.u.camera_index], px, py, rng, &o, &d);
-  }
-  if (slot < fc.slot_count) {
-    ps.throughput_pdf[slot] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-    ps.radiance_rng[slot] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(rng));
-    ps.albedo[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    ps.normal[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-  }
-  // unsharded frames have no invalid slots: the queue index is the slot and the queue size is known up front;
-  // sharded frames compact away padding tiles / out-of-frame pixels (one atomic per wave: the first queue only)
-  uint32_t qi = slot;
-  if (fc.world <= 1u) {
-    if (slot == 0u) ctl->n_active[0] = fc.slot_count;
-  } else {
-    qi = wave_compact(valid, &ctl->n_active[0]);
-  }
-  if (valid) {
-    float4* rp = reinterpret_cast<float4*>(q.rays[0] + qi);
-    rp[0] = make_float4(o.x, o.y, o.z, 0.0f);
-    rp[1] = make_float4(d.x, d.y, d.z, kTMax);
-    q.slots[0][qi] = slot;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------
 // shade: closest-hit + miss + light/env NEE + BSDF sampling + Russian roulette for one bounce (RENDER_SPEC §6)
 // ---------------------------------------------------------------------------------------------------------
+// PRIMARY (depth 0): queue entry i IS path slot i, its ray is re-evaluated from the camera instead of being read, and
+// the path state starts from its constants (throughput 1, radiance 0) — this kernel initialises every per-path record.
+template <bool PRIMARY>
 __global__ void __launch_bounds__(kShadeThreads) k_shade(FrameConst fc, SceneView sv, Queues q, PathState ps, Control* __restrict__ ctl, uint32_t depth) {
   __shared__ BlockCompact s_compact;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t n = ctl->n_active[depth];
+  const uint32_t n = PRIMARY ? fc.slot_count : ctl->n_active[depth];
   // the traversal of this bounce is over and the next users (shadow pass of this bounce, closest-hit pass of the next)
   // have not started: re-arm their work counters here
   if (blockIdx.x == 0u && threadIdx.x < kWorkShards) {
@@ -329,17 +345,33 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(FrameConst fc, SceneVie
   f3 no = splat3(0.0f), nd = splat3(0.0f);
   float4 conn[2][3];  // the two NEE connections of this path, written to the compact queues after the block scan
   uint32_t slot = 0;
-  if (active) {
-    slot = q.slots[in][i];
-    const float4* rp = reinterpret_cast<const float4*>(q.rays[in] + i);
-    const float4 ro = rp[0], rd = rp[1];
+  f3 o, d;
+  uint32_t rng = 0;
+  bool real = active;  // false: padding slot of a sharded frame (depth 0 only; later queues hold real paths only)
+  if (PRIMARY && active) {
+    slot = i;
+    real = primary_ray(fc, sv, slot, &o, &d, &rng);
+    if (!real) {  // resolve reads every slot of the rank's tile buffer
+      ps.radiance_rng[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      ps.albedo[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      ps.normal[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+  }
+  if (real) {
+    f3 T = splat3(1.0f), L = splat3(0.0f);
+    float prev_pdf = 0.0f;
+    if (!PRIMARY) {
+      slot = q.slots[in][i];
+      const float4* rp = reinterpret_cast<const float4*>(q.rays[in] + i);
+      const float4 ro = rp[0], rd = rp[1];
+      o = mk3(ro.x, ro.y, ro.z); d = mk3(rd.x, rd.y, rd.z);
+      const float4 tp = ps.throughput_pdf[slot];
+      const float4 lr = ps.radiance_rng[slot];
+      T = mk3(tp.x, tp.y, tp.z); L = mk3(lr.x, lr.y, lr.z);
+      prev_pdf = tp.w;
+      rng = __float_as_uint(lr.w);
+    }
     const float4 hv = reinterpret_cast<const float4*>(q.hits)[i];
-    const f3 o = mk3(ro.x, ro.y, ro.z), d = mk3(rd.x, rd.y, rd.z);
-    const float4 tp = ps.throughput_pdf[slot];
-    float4 lr = ps.radiance_rng[slot];
-    f3 T = mk3(tp.x, tp.y, tp.z), L = mk3(lr.x, lr.y, lr.z);
-    float prev_pdf = tp.w;
-    uint32_t rng = __float_as_uint(lr.w);
     const uint32_t hit_prim = __float_as_uint(hv.w);
     const uint32_t nl = fc.u.num_of_lights;
     const float t_surf = hit_prim != kAbsent ? hv.x : kTMax;
@@ -354,21 +386,27 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(FrameConst fc, SceneVie
     if (hit_light >= 0) {
       const f3 le = ld3(sv.lights[hit_light].intensity);
       float w = 1.0f;
-      if (depth > 0u) w = power_heuristic(prev_pdf, light_pdf * (1.0f / (float)nl));
+      if (!PRIMARY) w = power_heuristic(prev_pdf, light_pdf * (1.0f / (float)nl));
       L = L + T * le * w;
-      if (depth == 0u) ps.albedo[slot] = make_float4(minf(le.x, 1.0f), minf(le.y, 1.0f), minf(le.z, 1.0f), 1.0f);
+      if (PRIMARY) {
+        ps.albedo[slot] = make_float4(minf(le.x, 1.0f), minf(le.y, 1.0f), minf(le.z, 1.0f), 1.0f);
+        ps.normal[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      }
     } else if (hit_prim == kAbsent) {
       f3 env;
       float w = 1.0f;
       if (fc.u.env_type == 1u) {
         env = env_map_eval(fc, sv, d);
-        if (depth > 0u) w = power_heuristic(prev_pdf, env_map_pdf(fc, sv, d));
+        if (!PRIMARY) w = power_heuristic(prev_pdf, env_map_pdf(fc, sv, d));
       } else env = sky_eval(fc, d);
       L = L + T * env * w;
-      if (depth == 0u) ps.albedo[slot] = make_float4(minf(env.x, 1.0f), minf(env.y, 1.0f), minf(env.z, 1.0f), 1.0f);
+      if (PRIMARY) {
+        ps.albedo[slot] = make_float4(minf(env.x, 1.0f), minf(env.y, 1.0f), minf(env.z, 1.0f), 1.0f);
+        ps.normal[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      }
     } else {
       const Surface sf = make_surface(sv, fc.pixel_spread, o, d, hv.x, hv.y, hv.z, hit_prim);
-      if (depth == 0u) {
+      if (PRIMARY) {
         ps.albedo[slot] = make_float4(sf.mat.base.x, sf.mat.base.y, sf.mat.base.z, 1.0f);
         ps.normal[slot] = make_float4(sf.ns.x, sf.ns.y, sf.ns.z, 1.0f);
       }
@@ -561,11 +599,22 @@ void launch_trace_shadow(const LaunchCfg& lc, const SceneView& sv, const Queues&
   }
 }
 
-void launch_raygen(const FrameConst& fc, const SceneView& sv, const Queues& q, const PathState& ps, Control* ctl, hipStream_t s) {
-  hipLaunchKernelGGL(k_raygen, dim3(blocks_for(fc.slot_count, 256)), dim3(256), 0, s, fc, sv, q, ps, ctl);
+void launch_trace_primary(const LaunchCfg& lc, const SceneView& sv, const FrameConst& fc, hala_hit* hits, WorkCounters* work, Control* ctl,
+                          uint32_t n_account, bool count, hipStream_t s) {
+  const size_t smem = traverse_smem(sv);
+  dim3 grid(lc.persistent_blocks), block(kTraverseThreads);
+  if (sv.staged) {
+    if (count) hipLaunchKernelGGL((k_trace_primary<true, true>), grid, block, smem, s, sv, fc, hits, work, lc.spill, ctl, n_account, lc.refill);
+    else hipLaunchKernelGGL((k_trace_primary<false, true>), grid, block, smem, s, sv, fc, hits, work, lc.spill, ctl, n_account, lc.refill);
+  } else {
+    if (count) hipLaunchKernelGGL((k_trace_primary<true, false>), grid, block, smem, s, sv, fc, hits, work, lc.spill, ctl, n_account, lc.refill);
+    else hipLaunchKernelGGL((k_trace_primary<false, false>), grid, block, smem, s, sv, fc, hits, work, lc.spill, ctl, n_account, lc.refill);
+  }
 }
 void launch_shade(const FrameConst& fc, const SceneView& sv, const Queues& q, const PathState& ps, Control* ctl, uint32_t depth, hipStream_t s) {
-  hipLaunchKernelGGL(k_shade, dim3(blocks_for(fc.slot_count, kShadeThreads)), dim3(kShadeThreads), 0, s, fc, sv, q, ps, ctl, depth);
+  const dim3 grid(blocks_for(fc.slot_count, kShadeThreads)), block(kShadeThreads);
+  if (depth == 0u) hipLaunchKernelGGL(k_shade<true>, grid, block, 0, s, fc, sv, q, ps, ctl, depth);
+  else hipLaunchKernelGGL(k_shade<false>, grid, block, 0, s, fc, sv, q, ps, ctl, depth);
 }
 void launch_resolve(const FrameConst& fc, const PathState& ps, float4* accum, float4* albedo, float4* normal, float4* final_img, hipStream_t s) {
   hipLaunchKernelGGL(k_resolve, dim3(blocks_for(fc.pixel_slots, 256)), dim3(256), 0, s, fc, ps, accum, albedo, normal, final_img);

@@ -23,7 +23,8 @@ void launch_trace_batch(const LaunchCfg& lc, const SceneView& sv, const hala_ray
                         uint32_t n_imm, WorkCounters* work, Control* ctl, bool any, bool count, bool account, hipStream_t s);
 void launch_trace_shadow(const LaunchCfg& lc, const SceneView& sv, const Queues& q, const PathState& ps, Control* ctl, uint32_t depth,
                          uint32_t kind /* 0 light, 1 environment */, bool count, hipStream_t s);
-void launch_raygen(const FrameConst& fc, const SceneView& sv, const Queues& q, const PathState& ps, Control* ctl, hipStream_t s);
+void launch_trace_primary(const LaunchCfg& lc, const SceneView& sv, const FrameConst& fc, hala_hit* hits, WorkCounters* work, Control* ctl,
+                          uint32_t n_account /* real paths among fc.slot_count */, bool count, hipStream_t s);
 void launch_shade(const FrameConst& fc, const SceneView& sv, const Queues& q, const PathState& ps, Control* ctl, uint32_t depth, hipStream_t s);
 void launch_resolve(const FrameConst& fc, const PathState& ps, float4* accum, float4* albedo, float4* normal, float4* final_img, hipStream_t s);
 void launch_scatter_tiles(const FrameConst& fc, const float4* gathered, float4* full, hipStream_t s);

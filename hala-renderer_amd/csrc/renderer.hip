@@ -136,6 +136,7 @@ struct hala_rt_renderer {
   float env_total_sum = 0.0f;
 
   // tile shard (RENDER_SPEC §9)
+  uint32_t real_pixels = 0;  // pixels among the rank's slot_count slots that exist in the frame
   uint32_t rank = 0, world = 1, tile_size = 32, tiles_x = 0, tiles_y = 0, tiles_per_rank = 0, perm_a_inv = 0, perm_b = 7;
   uint32_t slot_count = 0;      // pixel slots of this rank
   uint32_t batch_capacity = 1;  // samples the wavefront buffers can hold in flight (hala_rt_update_batch)
@@ -262,6 +263,7 @@ int ensure_device(hala_rt_renderer* r) {
 void compute_tiling(hala_rt_renderer* r) {
   if (r->world <= 1) {
     r->slot_count = r->width * r->height;
+    r->real_pixels = r->slot_count;
     r->tiles_x = r->tiles_y = r->tiles_per_rank = 0;
     return;
   }
@@ -275,6 +277,16 @@ void compute_tiling(hala_rt_renderer* r) {
   r->perm_a_inv = mod_inverse(A, n);
   r->perm_b = 7;
   r->slot_count = r->tiles_per_rank * r->tile_size * r->tile_size;
+  // pixels this rank really owns (its padding tiles and the out-of-frame part of border tiles hold no paths)
+  uint64_t real = 0;
+  for (uint32_t t = 0; t < n; ++t) {
+    const uint32_t k = (uint32_t)(((uint64_t)t * A + r->perm_b) % n);
+    if (k % r->world != r->rank) continue;
+    const uint32_t tx = t % r->tiles_x, ty = t / r->tiles_x;
+    const uint32_t w = std::min(r->tile_size, r->width - tx * r->tile_size), h = std::min(r->tile_size, r->height - ty * r->tile_size);
+    real += (uint64_t)w * h;
+  }
+  r->real_pixels = (uint32_t)real;
 }
 
 // wavefront state for `samples` frames in flight (hala_rt_update_batch): everything indexed by path slot
@@ -633,11 +645,12 @@ static int update_impl(hala_rt_renderer* r, uint32_t frames) {
   hipStream_t s = r->stream;
   RT_HIP(hipEventRecord(te.frame_begin, s));
   RT_HIP(hipMemsetAsync(ctl, 0, sizeof(Control), s));
-  launch_raygen(fc, sv, q, ps, ctl, s);
   for (uint32_t depth = 0; depth < r->max_depth; ++depth) {
     hipEvent_t a = r->next_event(te), b = r->next_event(te);
     RT_HIP(hipEventRecord(a, s));
-    launch_trace_batch(r->lcfg, sv, q.rays[depth & 1u], q.hits, &ctl->n_active[depth], 0, &ctl->work_closest, ctl, false, r->counting, true, s);
+    // depth 0: the camera rays are generated inside the traversal kernel, there is no ray-generation pass
+    if (depth == 0) launch_trace_primary(r->lcfg, sv, fc, q.hits, &ctl->work_closest, ctl, r->real_pixels * samples, r->counting, s);
+    else launch_trace_batch(r->lcfg, sv, q.rays[depth & 1u], q.hits, &ctl->n_active[depth], 0, &ctl->work_closest, ctl, false, r->counting, true, s);
     RT_HIP(hipEventRecord(b, s));
     launch_shade(fc, sv, q, ps, ctl, depth, s);
     hipEvent_t c = r->next_event(te), d = r->next_event(te);
