@@ -3,10 +3,11 @@
 
   metric   : Mrays/s (+ ms/frame) — rays = every BVH traversal: primary + bounce + shadow
   workload : configs[1] — Cornell box (32 triangles), 1920x1080, 4 spp, diffuse-only closest hit, max_depth 5, rr_depth 3
-  step     : one frame = 4 x update() (the reference renders 1 spp per update, src/rt_renderer.rs:458-464)
+  step     : one frame = update_batch(4) == 4 x update() (the reference renders 1 spp per update,
+             src/rt_renderer.rs:458-464; the four samples travel through the wavefront kernels together) + render()
   N > 1    : weak scaling — every rank renders one 1920x1080-pixel share of a (1920*kx) x (1080*ky) frame (kx*ky = N),
-             cut into 32x32 tiles dealt to the ranks by a fixed permutation; after the 4 spp the three AOVs
-             (accum, albedo, normal) are all-gathered over RCCL and de-interleaved on every rank.
+             cut into 32x32 tiles dealt to the ranks by a fixed permutation; after the 4 spp the accumulated image is
+             all-gathered over RCCL (one collective per frame) and de-interleaved on every rank.
 
 Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (closest-hit traversal) with the
 algorithmic-bytes figure of DESIGN.md; `cpu_baseline` times the CPU oracle on the host cores (N = 1 only).
@@ -151,14 +152,21 @@ def main():
     else:
         dt_all, rays_all = dt, float(rays_local)
 
-    # ---- roofline of the dominant kernel: closest-hit traversal (rank 0's launches) ---------------------------
-    # algorithmic bytes per ray (DESIGN.md §"Kernels"): 32 B ray read + 16 B hit write + 64 B per BVH node visited
-    # + 48 B per triangle tested; node/triangle counts come from one extra frame with the counting kernels
-    # (identical traversal order; tests/test_gpu_parity.py pins those counts to the oracle's).
+    # ---- roofline of the dominant kernel (rank 0's launches) ---------------------------------------------------
+    # Closest-hit traversal runs as two kernel symbols: k_trace_primary (depth 0: camera rays generated in place, one
+    # launch per frame) and k_trace_batch<false,false,STAGED> (depth >= 1: bounce rays from the compact queues, four
+    # launches per frame).  The dominant one by time is k_trace_batch; it is what `roofline` prices.
+    # algorithmic bytes per ray (DESIGN.md "Kernels"): 32 B ray read + 16 B hit write + 64 B per (4-wide) BVH node
+    # visited + 48 B per triangle tested; node/triangle counts come from one extra frame with the counting kernels
+    # (identical traversal; tests/test_gpu_parity.py pins those counts to the oracle's on the same BVH).
     closest_ms = s1.traverse_closest_ms_total - s0.traverse_closest_ms_total
     closest_launches = s1.traverse_closest_launches - s0.traverse_closest_launches
+    primary_ms = s1.traverse_primary_ms_total - s0.traverse_primary_ms_total
+    primary_launches = s1.traverse_primary_launches - s0.traverse_primary_launches
     shadow_ms = s1.traverse_shadow_ms_total - s0.traverse_shadow_ms_total
+    shadow_launches = s1.traverse_shadow_launches - s0.traverse_shadow_launches
     rays_closest = s1.rays_closest_total - s0.rays_closest_total
+    rays_primary = s1.rays_primary_total - s0.rays_primary_total
     rays_shadow = s1.rays_shadow_total - s0.rays_shadow_total
     r.set_counting(True)
     c0 = r.statistics()
@@ -166,16 +174,26 @@ def main():
     fence()
     c1 = r.statistics()
     r.set_counting(False)
-    nc = c1.rays_closest_counted - c0.rays_closest_counted
-    nodes_per_ray = (c1.nodes_closest_total - c0.nodes_closest_total) / max(nc, 1)
-    tris_per_ray = (c1.tris_closest_total - c0.tris_closest_total) / max(nc, 1)
-    ns = c1.rays_shadow_counted - c0.rays_shadow_counted
-    s_nodes_per_ray = (c1.nodes_shadow_total - c0.nodes_shadow_total) / max(ns, 1)
-    s_tris_per_ray = (c1.tris_shadow_total - c0.tris_shadow_total) / max(ns, 1)
+    d = lambda name: getattr(c1, name) - getattr(c0, name)
+    n_bounce = max(d("rays_closest_counted") - d("rays_primary_counted"), 1)
+    nodes_per_ray = (d("nodes_closest_total") - d("nodes_primary_total")) / n_bounce
+    tris_per_ray = (d("tris_closest_total") - d("tris_primary_total")) / n_bounce
+    p_nodes_per_ray = d("nodes_primary_total") / max(d("rays_primary_counted"), 1)
+    p_tris_per_ray = d("tris_primary_total") / max(d("rays_primary_counted"), 1)
+    ns = d("rays_shadow_counted")
+    s_nodes_per_ray = d("nodes_shadow_total") / max(ns, 1)
+    s_tris_per_ray = d("tris_shadow_total") / max(ns, 1)
     bytes_per_ray = 32.0 + 16.0 + 64.0 * nodes_per_ray + 48.0 * tris_per_ray
-    avg_launch_ms = closest_ms / max(closest_launches, 1)
-    rays_per_launch = rays_closest / max(closest_launches, 1)
+    batch_ms, batch_launches, rays_bounce = closest_ms - primary_ms, closest_launches - primary_launches, rays_closest - rays_primary
+    avg_launch_ms = batch_ms / max(batch_launches, 1)
+    rays_per_launch = rays_bounce / max(batch_launches, 1)
     achieved = bytes_per_ray * rays_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+    simt = {}
+    for kind in ("closest", "shadow"):
+        ws = max(d(f"wave_steps_{kind}_total"), 1)
+        lp = max(d(f"leaf_passes_{kind}_total"), 1)
+        simt[kind] = {"node_path_lanes_of_64": round(d(f"nodes_{kind}_total") / ws, 1), "leaf_passes_per_wave_step": round(d(f"leaf_passes_{kind}_total") / ws, 2),
+                      "leaf_path_lanes_of_64": round(d(f"leaf_lanes_{kind}_total") / lp, 1)}
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic_closest.json")
     if os.path.exists(tpath):
@@ -195,19 +213,30 @@ def main():
                        "resolution": [W, Hh], "spp": SPP, "max_depth": MAX_DEPTH, "rr_depth": RR_DEPTH,
                        "parallelism": f"pixel-tile shard {TILE}x{TILE} over {world} rank(s)" + (", one RCCL all-gather of the accumulated image per frame" if world > 1 else ""),
                        "rays_per_frame": int(rays_all / args.steps), "ms_per_frame": round(dt_all / args.steps * 1e3, 4)},
-            "roofline": {"bound": "hbm", "kernel": "rt::k_trace_batch<false,false> (closest-hit traversal)",
+            "roofline": {"bound": "hbm", "kernel": "rt::k_trace_batch<false, false, true> (closest-hit traversal of the bounce-ray queues, depth >= 1)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_GBps": (round(traffic / (avg_launch_ms * 1e-3) / 1e9, 1) if traffic and avg_launch_ms > 0 else None),
-                         "note": "achieved = ALGORITHMIC bytes (SURVEY §8d formula) / launch time. For this 32-triangle scene the whole BVH "
-                                 "(12 nodes + 32 triangles = 2.3 KB) is staged in LDS, so node/triangle bytes never reach HBM: `traffic` (PMC "
-                                 "FETCH_SIZE*2 + WRITE_SIZE per launch, profiles/traffic_closest.json) is just the ray-queue read + hit write, "
-                                 "and frac can exceed 1. scripts/bench_scenes.py reports the same figure for the 82 k and 1 M triangle scenes.",
+                         "note": "achieved = ALGORITHMIC bytes (SURVEY 8d formula, 64 B per 4-wide node) / launch time, both per launch of this "
+                                 "kernel symbol; avg_launch_ms is measured with HIP events on the renderer's stream and agrees with the "
+                                 "rocprofv3 --kernel-trace --stats average in profiles/. For this 32-triangle scene the whole BVH (6 nodes + "
+                                 "32 triangles = 1.9 KB) is staged in LDS, so node/triangle bytes never reach HBM: `traffic` (PMC FETCH_SIZE*2 "
+                                 "+ WRITE_SIZE per launch, profiles/traffic_closest.json) is just the ray-queue read + hit write, and frac can "
+                                 "exceed 1. The kernel is VALU-issue bound (profiles/r01_h_pmc_config2.txt: ~0.8 of the issue slots; `simt` "
+                                 "gives the active lanes per wave on its two code paths). scripts/bench_scenes.py reports the same figures "
+                                 "for the 82 k and 1 M triangle scenes, where the nodes do come from L2 / Infinity Cache / HBM.",
                          "bytes_per_ray": round(bytes_per_ray, 1), "nodes_per_ray": round(nodes_per_ray, 3),
                          "tris_per_ray": round(tris_per_ray, 3), "avg_launch_ms": round(avg_launch_ms, 5),
-                         "launches": int(closest_launches), "rays_per_launch": round(rays_per_launch, 1),
-                         "grays_per_s_in_kernel": round(rays_closest / max(closest_ms, 1e-9) / 1e6, 3),
-                         "shadow_kernel": {"ms_total": round(shadow_ms, 3), "rays": int(rays_shadow),
+                         "launches": int(batch_launches), "rays_per_launch": round(rays_per_launch, 1),
+                         "grays_per_s_in_kernel": round(rays_bounce / max(batch_ms, 1e-9) / 1e6, 3),
+                         "simt": simt,
+                         "primary_kernel": {"kernel": "rt::k_trace_primary<false, true> (depth 0: camera rays generated in the lanes that trace them, 16 B hit write per ray)",
+                                            "avg_launch_ms": round(primary_ms / max(primary_launches, 1), 5), "launches": int(primary_launches),
+                                            "rays_per_launch": round(rays_primary / max(primary_launches, 1), 1),
+                                            "nodes_per_ray": round(p_nodes_per_ray, 3), "tris_per_ray": round(p_tris_per_ray, 3),
+                                            "grays_per_s_in_kernel": round(rays_primary / max(primary_ms, 1e-9) / 1e6, 3)},
+                         "shadow_kernel": {"kernel": "rt::k_trace_shadow<false, true>", "avg_launch_ms": round(shadow_ms / max(shadow_launches, 1), 5),
+                                           "launches": int(shadow_launches), "rays": int(rays_shadow),
                                            "nodes_per_ray": round(s_nodes_per_ray, 3), "tris_per_ray": round(s_tris_per_ray, 3),
                                            "grays_per_s_in_kernel": round(rays_shadow / max(shadow_ms, 1e-9) / 1e6, 3)}},
         }

@@ -150,7 +150,10 @@ class RtStatistics(C.Structure):
                 ("nodes_shadow_total", C.c_uint64), ("tris_shadow_total", C.c_uint64),
                 ("rays_closest_counted", C.c_uint64), ("rays_shadow_counted", C.c_uint64),
                 ("wave_steps_closest_total", C.c_uint64), ("leaf_passes_closest_total", C.c_uint64), ("leaf_lanes_closest_total", C.c_uint64),
-                ("wave_steps_shadow_total", C.c_uint64), ("leaf_passes_shadow_total", C.c_uint64), ("leaf_lanes_shadow_total", C.c_uint64)]
+                ("wave_steps_shadow_total", C.c_uint64), ("leaf_passes_shadow_total", C.c_uint64), ("leaf_lanes_shadow_total", C.c_uint64),
+                ("traverse_primary_ms_total", C.c_double), ("traverse_primary_launches", C.c_uint64),
+                ("nodes_primary_total", C.c_uint64), ("tris_primary_total", C.c_uint64), ("rays_primary_counted", C.c_uint64),
+                ("rays_primary_total", C.c_uint64)]
 
 
 class BvhInfo(C.Structure):

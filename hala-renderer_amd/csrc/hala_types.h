@@ -130,6 +130,7 @@ struct Control {
   // counting launches, wave level: probe[kind] = {wave steps (one node visit by every lane that holds a ray), leaf passes
   // (executions of one leaf-test copy by a wave), lanes taking part in those passes}: SIMT utilisation of the two code paths
   unsigned long long probe[2][3];
+  unsigned long long primary_steps[2];  // counting launches: steps[0] as it stood after the depth-0 launch (camera rays only)
 };
 
 // wavefront path state, SoA, indexed by pixel slot

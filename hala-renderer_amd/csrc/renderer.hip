@@ -224,7 +224,10 @@ struct hala_rt_renderer {
     double tr[2] = {0.0, 0.0};  // event pairs alternate: closest-hit launch, shadow launch
     for (size_t k = 0; k + 1 < t.used; k += 2) {
       float m = 0.0f;
-      if (hipEventElapsedTime(&m, t.ev[k], t.ev[k + 1]) == hipSuccess) tr[(k / 2) & 1] += m;
+      if (hipEventElapsedTime(&m, t.ev[k], t.ev[k + 1]) == hipSuccess) {
+        tr[(k / 2) & 1] += m;
+        if (k == 0) { stats.traverse_primary_ms_total += m; stats.traverse_primary_launches += 1; }  // depth 0: k_trace_primary
+      }
     }
     stats.traverse_ms_last_update = tr[0] + tr[1];
     stats.traverse_closest_ms_total += tr[0];
@@ -236,12 +239,15 @@ struct hala_rt_renderer {
     stats.rays_last_update = rc + rs;
     stats.rays_total += rc + rs;
     stats.rays_closest_total += rc;
+    stats.rays_primary_total += (unsigned long long)real_pixels * t.samples;
     stats.rays_shadow_total += rs;
     if (t.counted) {
       stats.nodes_closest_total += t.host_counts[2]; stats.tris_closest_total += t.host_counts[3];
       stats.nodes_shadow_total += t.host_counts[4]; stats.tris_shadow_total += t.host_counts[5];
       stats.rays_closest_counted += rc; stats.rays_shadow_counted += rs;
       stats.wave_steps_closest_total += t.host_counts[6]; stats.leaf_passes_closest_total += t.host_counts[7]; stats.leaf_lanes_closest_total += t.host_counts[8];
+      stats.nodes_primary_total += t.host_counts[12]; stats.tris_primary_total += t.host_counts[13];
+      stats.rays_primary_counted += (unsigned long long)real_pixels * t.samples;
       stats.wave_steps_shadow_total += t.host_counts[9]; stats.leaf_passes_shadow_total += t.host_counts[10]; stats.leaf_lanes_shadow_total += t.host_counts[11];
     }
     t.pending = false;
@@ -633,7 +639,7 @@ static int update_impl(hala_rt_renderer* r, uint32_t frames) {
   TraceEvents& te = r->ring[r->ring_pos];
   r->ring_pos = (r->ring_pos + 1) % kStatRing;
   r->resolve_slot(te);
-  if (!te.frame_begin) { RT_HIP(hipEventCreate(&te.frame_begin)); RT_HIP(hipEventCreate(&te.frame_end)); RT_HIP(hipHostMalloc(reinterpret_cast<void**>(&te.host_counts), 12 * sizeof(unsigned long long), hipHostMallocDefault)); }
+  if (!te.frame_begin) { RT_HIP(hipEventCreate(&te.frame_begin)); RT_HIP(hipEventCreate(&te.frame_end)); RT_HIP(hipHostMalloc(reinterpret_cast<void**>(&te.host_counts), 14 * sizeof(unsigned long long), hipHostMallocDefault)); }
   te.used = 0; te.counted = r->counting;
 
   te.samples = samples;
@@ -649,7 +655,10 @@ static int update_impl(hala_rt_renderer* r, uint32_t frames) {
     hipEvent_t a = r->next_event(te), b = r->next_event(te);
     RT_HIP(hipEventRecord(a, s));
     // depth 0: the camera rays are generated inside the traversal kernel, there is no ray-generation pass
-    if (depth == 0) launch_trace_primary(r->lcfg, sv, fc, q.hits, &ctl->work_closest, ctl, r->real_pixels * samples, r->counting, s);
+    if (depth == 0) {
+      launch_trace_primary(r->lcfg, sv, fc, q.hits, &ctl->work_closest, ctl, r->real_pixels * samples, r->counting, s);
+      if (r->counting) RT_HIP(hipMemcpyAsync(ctl->primary_steps, ctl->steps[0], 16, hipMemcpyDeviceToDevice, s));
+    }
     else launch_trace_batch(r->lcfg, sv, q.rays[depth & 1u], q.hits, &ctl->n_active[depth], 0, &ctl->work_closest, ctl, false, r->counting, true, s);
     RT_HIP(hipEventRecord(b, s));
     launch_shade(fc, sv, q, ps, ctl, depth, s);
@@ -661,7 +670,7 @@ static int update_impl(hala_rt_renderer* r, uint32_t frames) {
     RT_HIP(hipEventRecord(d, s));
   }
   launch_resolve(fc, ps, r->img_local[0].ptr, r->img_local[1].ptr, r->img_local[2].ptr, r->img_local[3].ptr, s);
-  RT_HIP(hipMemcpyAsync(te.host_counts, &ctl->rays_closest, 12 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  RT_HIP(hipMemcpyAsync(te.host_counts, &ctl->rays_closest, 14 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
   RT_HIP(hipEventRecord(te.frame_end, s));
   RT_HIP(hipGetLastError());
   te.pending = true;

@@ -367,6 +367,12 @@ typedef struct hala_rt_statistics {
    * wave, leaf lanes = lanes taking part in them (utilisation of the leaf path = leaf_lanes / (64 * leaf_passes)) */
   uint64_t wave_steps_closest_total, leaf_passes_closest_total, leaf_lanes_closest_total;
   uint64_t wave_steps_shadow_total, leaf_passes_shadow_total, leaf_lanes_shadow_total;
+  /* the depth-0 share of traverse_closest_*: launches of the kernel that generates the camera rays it traces
+   * (k_trace_primary); the rest are k_trace_batch launches over the bounce-ray queues */
+  double traverse_primary_ms_total;
+  uint64_t traverse_primary_launches;
+  uint64_t nodes_primary_total, tris_primary_total, rays_primary_counted; /* counting launches, camera rays only */
+  uint64_t rays_primary_total; /* camera rays of all updates (part of rays_closest_total) */
 } hala_rt_statistics;
 int hala_rt_get_info(hala_rt_renderer* r, hala_rt_info* out);
 int hala_rt_get_statistics(hala_rt_renderer* r, hala_rt_statistics* out);
