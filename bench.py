@@ -109,6 +109,7 @@ def main():
     r.commit()
 
     gather = None
+    sync_gather = bool(os.environ.get("BENCH_SYNC_GATHER"))
     if world > 1:
         from hala_renderer_amd.dist import TileGather
         # one all-gather per finished frame: the accumulated colour image; albedo/normal are gathered the
@@ -120,10 +121,17 @@ def main():
         r.reset_accumulation()
         r.update_batch(SPP)  # == SPP x update(): the SPP samples travel through the wavefront kernels together
         if gather is not None:
-            gather.gather()  # one RCCL all-gather per AOV + de-interleave kernel
+            # one RCCL all-gather of the finished frame + de-interleave kernel; pipelined: it runs while the next frame is
+            # rendered and is waited for by the next begin() / the closing fence (BENCH_SYNC_GATHER=1: wait right here)
+            if sync_gather:
+                gather.gather()
+            else:
+                gather.begin()
         r.render()
 
     def fence():
+        if gather is not None:
+            gather.finish()  # the last frame's all-gather and de-interleave are part of the timed region
         r.wait_idle()
         torch.cuda.synchronize()
         if dist is not None:

@@ -99,7 +99,44 @@ class TileGather:
             dst = torch.empty(self.world * (nbytes // 4), dtype=torch.float32, device=f"cuda:{device_index}")
             self.bufs.append((which, src, dst, nbytes))
 
+    # ---- pipelined form: the all-gather of frame k runs while frame k + 1 is rendered -------------------------------
+    # xGMI is point-to-point: a ring all-gather of N x 33 MB (1080p RGBA32F per rank) is bound by ONE link per hop, i.e.
+    # it can take as long as rendering the frame.  begin() snapshots the rank's tile buffer (the next frame overwrites
+    # it) and starts the collective on a side stream; finish() — called by the next begin(), or explicitly — waits for it
+    # and de-interleaves.  Every frame is still gathered and de-interleaved in full; only the waiting is overlapped.
+    def begin(self):
+        torch = self.torch
+        self.r.wait_idle()  # frame k is complete in the rank's tile buffer (the renderer works on its own HIP stream)
+        self.finish()       # frame k - 1 must have left the staging / receive buffers
+        if not hasattr(self, "_side"):
+            self._side = torch.cuda.Stream()
+            self._stage = [torch.empty_like(src) for _, src, _, _ in self.bufs]
+        self._works = []
+        with torch.cuda.stream(self._side):
+            for (_, src, dst, _), stage in zip(self.bufs, self._stage):
+                stage.copy_(src, non_blocking=True)
+                if self.dist.get_backend(self.group) == "gloo":  # rehearsal on a 1-GPU box; same buffer layout
+                    self._side.synchronize()
+                    self._works.append(self.dist.all_gather(list(dst.view(self.world, -1).unbind(0)), stage, group=self.group, async_op=True))
+                else:
+                    self._works.append(self.dist.all_gather_into_tensor(dst, stage, group=self.group, async_op=True))
+        self._pending = True
+
+    def finish(self):
+        if not getattr(self, "_pending", False):
+            return
+        with self.torch.cuda.stream(self._side):
+            for w in self._works:
+                w.wait()
+        self._side.synchronize()
+        self._pending = False
+        if self.world == 1:
+            return
+        for which, _, dst, nbytes in self.bufs:
+            self.r.scatter_gathered_tiles(which, dst.data_ptr(), nbytes * self.world)
+
     def gather(self):
+        self.finish()
         self.r.wait_idle()  # the renderer works on its own HIP stream
         for _, src, dst, _ in self.bufs:
             if self.dist.get_backend(self.group) == "gloo":  # rehearsal on a 1-GPU box; same buffer layout

@@ -99,6 +99,57 @@ def test_rccl_all_gather_aliases_library_memory(halart):
         dist.destroy_process_group()
 
 
+def _pipelined_worker(rank, world, port, q):
+    """two real processes (gloo: RCCL refuses two ranks on one device) sharing cuda:0: sharded renders of three different
+    frames through the pipelined begin()/finish() gather; every frame's gathered image must equal the unsharded render"""
+    import torch
+    import torch.distributed as dist
+    import hala_renderer_amd as H
+    from hala_renderer_amd.dist import TileGather
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        w, h = 160, 96
+        scene = scenes.cornell_box(aspect=w / h)
+        ref = H.HalaRenderer("ref", w, h, 4, 2, False, False, False, 0)
+        ref.set_scene(scene); ref.commit()
+        r = H.HalaRenderer("shard", w, h, 4, 2, False, False, False, 0)
+        r.set_tile_shard(rank, world, 32)
+        r.set_scene(scene); r.commit()
+        g = TileGather(r, 0, aovs=(r.ACCUM,))
+        ok = True
+        want_prev = None
+        for frame, spp in enumerate((1, 2, 3)):  # three different frames: a stale buffer would show
+            r.reset_accumulation(); r.update_batch(spp)
+            g.begin()                        # finishes the previous frame's gather first
+            if want_prev is not None:
+                ok = ok and np.array_equal(r.read_image(r.ACCUM), want_prev)
+            ref.reset_accumulation(); ref.update_batch(spp)
+            want_prev = ref.read_image(ref.ACCUM)
+        g.finish()
+        ok = ok and np.array_equal(r.read_image(r.ACCUM), want_prev)
+        q.put((rank, bool(ok)))
+        r.close(); ref.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_pipelined_gather_two_processes(halart):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipelined_worker, args=(rk, 2, port, q)) for rk in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(results) == [(0, True), (1, True)]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("world", [2, 8])
 def test_sharded_render_equals_unsharded(halart, world):
