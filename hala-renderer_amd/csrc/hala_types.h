@@ -33,7 +33,7 @@ constexpr float kTMax = 3.402823466e+38f;
 // 64-B compressed BVH4 node (RENDER_SPEC §4.1b): up to four children in the bytes a plain BVH2 node would take.  Child boxes are
 // 8-bit quantised against the node's own box: lo = pmin + qlo * 2^e, hi = pmin + qhi * 2^e per axis (lo rounded down,
 // hi rounded up, so the quantised box always contains the true one).  Halves the dependent fetches per ray and the
-// node bytes per ray of a BVH2 — measured +25-34 % rays/s on the 82 k and 1 M triangle scenes (profiles/r01_h_bvh_width.txt).
+// node bytes per ray of a BVH2 — measured +25-34 % rays/s on the 82 k and 1 M triangle scenes (profiles/r01_h_experiments.txt).
 struct alignas(16) BvhNode4 {
   float pmin[3];
   uint32_t exps;     // byte a = biased float exponent of the quantum of axis a: quantum = uint_as_float(byte << 23)

@@ -23,7 +23,7 @@ using namespace rt;
 
 namespace {
 
-constexpr uint32_t kLeafMax = 2;  // triangles per leaf: a triangle test costs ~2x a child box test, profiles/r01_h_leaf_max.txt
+constexpr uint32_t kLeafMax = 2;  // triangles per leaf: a triangle test costs ~2x a child box test, profiles/r01_h_experiments.txt
 constexpr size_t kLdsStageBudget = 40 * 1024;  // a BVH up to this size is staged whole in LDS (next to the 24-KB stack)
 constexpr uint32_t kRefillThreshold = 32;      // idle lanes that trigger a refill of the wave (persistent_trace)
 constexpr int kStatRing = 16;
@@ -386,7 +386,7 @@ int upload_textures(hala_rt_renderer* r) {
 int configure_traversal(hala_rt_renderer* r) {
   const size_t nb = (size_t)r->bvh.node_count * 64, tb = (size_t)r->bvh.tri_count * 48;
   // Whole BVH in LDS when it fits the budget (the STAGED kernel variants read it with ds_read only); otherwise nothing
-  // is staged: a top-of-tree slice measured no gain (profiles/r01_h_stage_sweep.txt), the caches already hold it.
+  // is staged: a top-of-tree slice measured no gain (profiles/r01_h_experiments.txt), the caches already hold it.
   size_t budget = kLdsStageBudget;
   if (const char* e = getenv("HALART_LDS_STAGE_BYTES")) budget = (size_t)strtoul(e, nullptr, 10);  // tuning knob
   r->staged = nb + tb <= budget;

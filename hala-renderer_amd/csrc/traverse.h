@@ -6,7 +6,7 @@
 // Scenes whose whole BVH fits the LDS budget are STAGED: every workgroup copies nodes and triangles into LDS once and
 // the kernel variant compiled for that case reads them with ds_read_b128 only; all other scenes read nodes and
 // triangles straight from L2 / Infinity Cache / HBM (a partially staged top-of-tree slice measured no gain:
-// profiles/r01_h_stage_sweep.txt, and mixing both sources in one variant turns every fetch into a flat_load).
+// profiles/r01_h_experiments.txt, and mixing both sources in one variant turns every fetch into a flat_load).
 // The per-lane traversal stack lives in LDS as [entry][thread] (8-B entries, conflict-free), deeper entries spill to a
 // global scratch area.  No MFMA: this is branchy scalar-per-ray work, and it is VALU-issue bound (profiles/r01_h_pmc_*):
 // what counts is the number of vector instructions per node visit and per triangle test.
@@ -21,7 +21,7 @@ namespace rt {
 constexpr int kTraverseThreads = 256;
 // second launch-bound argument = waves per SIMD; it caps the register allocation (512 / waves)
 #ifndef RT_WAVES_PER_SIMD
-#define RT_WAVES_PER_SIMD 6  // profiles/r01_e_variant_sweep.txt, re-checked for BVH4 in profiles/r01_h_variant_sweep.txt
+#define RT_WAVES_PER_SIMD 6  // profiles/r01_e_variant_sweep.txt, re-checked for BVH4 in profiles/r01_h_experiments.txt
 #endif
 constexpr int kTraverseWavesPerSimd = RT_WAVES_PER_SIMD;
 #ifndef RT_WAVES_PER_SIMD_STAGED
@@ -171,7 +171,7 @@ RT_DI bool leaf_test(const SceneView& sv, const TraverseLds& lds, const RayPre& 
       }
     } else {
       // large scenes keep 6 waves/SIMD to hide L2 / Infinity Cache latency; the register pairs of the packed form would
-      // spill there (profiles/r01_h_packed_tri.txt), so the two triangles are tested one after the other
+      // spill there (profiles/r01_h_experiments.txt), so the two triangles are tested one after the other
       float4 a0 = p[0], b0 = p[1], c0 = p[2], a1, b1, c1;
       if (two) { a1 = p[3]; b1 = p[4]; c1 = p[5]; }
 #pragma unroll
