@@ -155,20 +155,39 @@ RT_DI void persistent_trace(const SceneView& sv, const TraverseLds& lds, uint2* 
   uint32_t idx = 0;
   Trav t;
   typename Source::Payload pay;
+  // Whole-wave batches (refill == 64: the LDS-staged scenes, whose rays are short) ask for their NEXT batch while the
+  // current one is traced: the returning atomic's round trip (1-2 us, about as long as tracing 64 such rays) is off the
+  // critical path.  A speculative request on a shard that has run dry just overshoots its counter; it is resolved —
+  // taken if it lies inside the shard, else replaced by the searching dequeue — before anything else is asked for.
+  bool pre_out = false;  // wave-uniform: a request is outstanding
+  uint32_t pre_raw = 0, pre_shard = 0;
   for (;;) {
     const unsigned long long idle = __ballot(!has);
     if (more && idle) {
-      uint32_t got = 0;
-      const uint32_t base = work_take(work, cur, n, (uint32_t)__popcll(idle), &got);
+      uint32_t got = 0, base = kAbsent;
+      if (pre_out) {
+        const uint32_t v = (uint32_t)__shfl((int)pre_raw, 0);
+        const unsigned long long lo = (unsigned long long)pre_shard * cur.per + v;
+        const unsigned long long hi = min((unsigned long long)(pre_shard + 1u) * cur.per, (unsigned long long)n);
+        if (v < cur.per && lo < hi) { base = (uint32_t)lo; got = (uint32_t)min(64ull, hi - lo); }
+        pre_out = false;
+      }
+      if (base == kAbsent) base = work_take(work, cur, n, (uint32_t)__popcll(idle), &got);
       if (base == kAbsent) more = false;
-      else if (!has) {
-        const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane_id()) - 1ull));
-        if (rank < got) {
-          idx = base + rank;
-          f3 o, d; float tmin, tmax;
-          if (src.load(idx, &o, &d, &tmin, &tmax, &pay)) {  // false: the source had no ray for this entry and has dealt with it
-            trav_begin(t, make_ray(o, d, tmin), tmax);
-            has = true;
+      else {
+        if (STAGED && refill == 64u) {
+          if (lane_id() == 0u) pre_raw = atomicAdd(&work->c[cur.shard * kWorkStride], 64u);
+          pre_shard = cur.shard; pre_out = true;
+        }
+        if (!has) {
+          const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane_id()) - 1ull));
+          if (rank < got) {
+            idx = base + rank;
+            f3 o, d; float tmin, tmax;
+            if (src.load(idx, &o, &d, &tmin, &tmax, &pay)) {  // false: the source had no ray for this entry and has dealt with it
+              trav_begin(t, make_ray(o, d, tmin), tmax);
+              has = true;
+            }
           }
         }
       }
