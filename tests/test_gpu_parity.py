@@ -206,6 +206,29 @@ def test_deep_stack_spills_to_global_scratch(halart, oracle):
     r.close()
 
 
+@pytest.mark.parametrize("ntri", [1, 2, 3, 5])
+def test_tiny_scenes_build_and_trace(halart, oracle, ntri):
+    """fewer triangles than one leaf / one node holds: single-leaf root, one real node, and the first scene with two"""
+    s = scenes.stacked_sheets(count=3)
+    prim = s.meshes[0].primitives[0]
+    prim.indices = prim.indices[: 3 * ntri].copy()
+    r = make_renderer(halart, s, 16, 16)
+    osc = oracle.OracleScene(s)
+    info = r.bvh_info()
+    assert info.triangle_count == ntri and info.node_count >= 1
+    nodes, tris = r.download_bvh()
+    assert oracle.validate_bvh(nodes, tris, osc.triangles())[0] == 0
+    rays = np.concatenate([osc.camera_rays(32, 32, 0), random_rays(500, np.array([-1.5, -1.5, -2], dtype=f32), np.array([1.5, 1.5, 2], dtype=f32), 9)])
+    for mode in (0, 1):
+        hits, cnt = r.trace_rays_host(rays, mode, count_steps=True)
+        assert hits.tobytes() == osc.trace(rays, mode, brute=True).tobytes()
+        assert cnt == oracle.trace_on_bvh(nodes, tris, rays, mode)[1]
+    r.update(); r.render()
+    img, _ = osc.render(16, 16, frames=1)
+    assert r.read_image(0).tobytes() == img[0].tobytes()
+    r.close()
+
+
 def test_empty_and_ragged_batches(halart, oracle):
     s = scenes.cornell_box()
     r = make_renderer(halart, s, 16, 16)
