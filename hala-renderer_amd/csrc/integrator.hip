@@ -443,7 +443,7 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(FrameConst fc, SceneVie
             const float side = dot3(ls.wi, sf.ng) >= 0.0f ? sv.ray_eps : -sv.ray_eps;
             const f3 so = madd3(sf.ng, side, sf.P);
             const float tmax = ls.dist >= kTMax ? kTMax : maxf(ls.dist - 2.0f * sv.ray_eps, 0.0f);
-            const float cosl = dot3(sf.ns, ls.wi);
+            const float cosl = fabsf(dot3(sf.ns, ls.wi));  // |cos|: a connection may leave through the surface (§7.1c)
             f3 contrib;
             if (ls.delta) contrib = fb * ls.le * (cosl * (float)nl);
             else {
@@ -468,7 +468,7 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(FrameConst fc, SceneVie
           if (pdf_b > 0.0f) {
             const float side = dot3(wi, sf.ng) >= 0.0f ? sv.ray_eps : -sv.ray_eps;
             const f3 so = madd3(sf.ng, side, sf.P);
-            const float cosl = dot3(sf.ns, wi);
+            const float cosl = fabsf(dot3(sf.ns, wi));
             const float w = power_heuristic(pdf_e, pdf_b);
             const f3 col = env_map_eval(fc, sv, wi);
             const f3 tc = T * (fb * col * (cosl * w / pdf_e));

@@ -145,6 +145,8 @@ struct MatView {
   uint32_t type;
   // DISNEY (type 1) only
   float metallic, roughness, specular_tint, sheen, sheen_tint, clearcoat, clearcoat_roughness, ior;
+  float trans;  // §7.1c: specular_transmission * (1 - metallic)
+  float eta;    // §7.1c: index of the far side relative to the side the path arrives from (ior entering, 1/ior leaving)
 };
 
 // ---- §7.1b DISNEY ----------------------------------------------------------------------------------------------
@@ -182,10 +184,19 @@ RT_DI f3 ggx_sample_vndf(f3 v, float ax, float ay, float r1, float r2) {
   return normalize3(mk3(ax * nh.x, ay * nh.y, maxf(0.0f, nh.z)));
 }
 struct DisneyLobes {
-  float pd, ps, pc;
+  float pd, ps, pc, pt;
   f3 cspec0, csheen;
   float cc_alpha;
 };
+// §7.1c exact unpolarised Fresnel reflectance of a dielectric interface; c = |cos| on the arriving side
+RT_DI float fresnel_dielectric(float c, float eta) {
+  float g2 = eta * eta - 1.0f + c * c;
+  if (!(g2 > 0.0f)) return 1.0f;  // total internal reflection
+  float g = sqrtf(g2);
+  float a = (g - c) / (g + c);
+  float b = (c * (g + c) - 1.0f) / (c * (g - c) + 1.0f);
+  return 0.5f * a * a * (1.0f + b * b);
+}
 RT_DI DisneyLobes disney_lobes(const MatView& m, float nv) {
   DisneyLobes d;
   float lb = luminance(m.base);
@@ -196,28 +207,51 @@ RT_DI DisneyLobes disney_lobes(const MatView& m, float nv) {
   d.csheen = mix3(splat3(1.0f), tint, m.sheen_tint);
   d.cc_alpha = maxf(0.001f, m.clearcoat_roughness * m.clearcoat_roughness);
   float fv = schlick5(nv);
-  float wd = (1.0f - m.metallic) * lb;
+  float wd = (1.0f - m.metallic) * lb * (1.0f - m.trans);
   float ws = luminance(mix3(d.cspec0, splat3(1.0f), fv));
   float wc = 0.25f * m.clearcoat * mixf(0.04f, 1.0f, fv);
-  float sum = wd + ws + wc;
-  if (!(sum > 0.0f)) { d.pd = d.ps = d.pc = 0.0f; return d; }
+  float wt = m.trans * (1.0f - mixf(f0, 1.0f, fv));
+  float sum = wd + ws + wc + wt;
+  if (!(sum > 0.0f)) { d.pd = d.ps = d.pc = d.pt = 0.0f; return d; }
   float inv = 1.0f / sum;
-  d.pd = wd * inv; d.ps = ws * inv; d.pc = wc * inv;
+  d.pd = wd * inv; d.ps = ws * inv; d.pc = wc * inv; d.pt = wt * inv;
   return d;
 }
 RT_DI void disney_eval(const MatView& m, f3 wo, f3 wi, f3 n, f3* f, float* pdf) {
   float nl = dot3(n, wi), nv = dot3(n, wo);
-  if (!(nl > 0.0f && nv > 0.0f)) { *f = splat3(0.0f); *pdf = 0.0f; return; }
+  *f = splat3(0.0f); *pdf = 0.0f;
+  if (!(nv > 0.0f)) return;
   f3 t, b;
   onb(n, &t, &b);
   f3 lo = mk3(dot3(wo, t), dot3(wo, b), nv), li = mk3(dot3(wi, t), dot3(wi, b), nl);
+  if (nl < 0.0f) {  // §7.1c: refraction through the microfacet with half vector h = -(lo + eta*li), flipped to the upper side
+    if (!(m.trans > 0.0f)) return;
+    f3 h = lo + li * m.eta;
+    float h2 = dot3(h, h);
+    if (!(h2 > 0.0f)) return;
+    h = h * (1.0f / sqrtf(h2));
+    if (h.z < 0.0f) h = -h;
+    float odh = dot3(lo, h), idh = dot3(li, h);
+    if (!(odh > 0.0f && idh < 0.0f)) return;  // both directions must see the front / the back of the same facet
+    DisneyLobes d = disney_lobes(m, nv);
+    float fr = fresnel_dielectric(odh, m.eta);
+    float ds = ggx_d(h, m.ax, m.ay);
+    float g1o = ggx_g1(lo, m.ax, m.ay), g1i = ggx_g1(li, m.ax, m.ay);
+    float den = odh + m.eta * idh;
+    float jac = m.eta * m.eta * (-idh) / (den * den);  // |dh/dwi|
+    float w = m.trans * (1.0f - fr) * ds * g1o * g1i * odh * jac / (-nl * nv);
+    *f = mk3(sqrtf(m.base.x), sqrtf(m.base.y), sqrtf(m.base.z)) * w;
+    *pdf = d.pt * (g1o * odh * ds / nv) * jac;
+    return;
+  }
+  if (!(nl > 0.0f)) return;
   f3 h = normalize3(lo + li);
   float ldh = dot3(li, h);
   DisneyLobes d = disney_lobes(m, nv);
   float fl = schlick5(nl), fv = schlick5(nv), fh = schlick5(ldh);
   float fd90 = 0.5f + 2.0f * sqrtf(m.roughness) * ldh * ldh;
   float fd = mixf(1.0f, fd90, fl) * mixf(1.0f, fd90, fv);
-  float dw = 1.0f - m.metallic;
+  float dw = (1.0f - m.metallic) * (1.0f - m.trans);
   f3 fs = mix3(d.cspec0, splat3(1.0f), fh);
   f3 fr = m.base * (splat3(1.0f) - fs) * (kInvPi * fd * dw) + d.csheen * (m.sheen * fh * dw);
   float ds = ggx_d(h, m.ax, m.ay);
@@ -252,6 +286,15 @@ RT_DI bool bsdf_sample(const MatView& m, f3 wo, f3 n, float r1, float r2, float 
     DisneyLobes d = disney_lobes(m, nv);
     if (r3 < d.pd) {
       *wi = to_world(cosine_hemisphere(r1, r2), t, b, n);
+    } else if (r3 >= d.pd + d.ps + d.pc) {  // §7.1c: refract through a VNDF-sampled facet (nothing when totally reflected)
+      f3 lo = mk3(dot3(wo, t), dot3(wo, b), nv);
+      f3 h = ggx_sample_vndf(lo, m.ax, m.ay, r1, r2);
+      float c = dot3(lo, h);
+      float ie = 1.0f / m.eta;
+      float k = 1.0f - (1.0f - c * c) * (ie * ie);
+      if (!(k > 0.0f)) { *f = splat3(0.0f); *pdf = 0.0f; return false; }
+      f3 li = h * (c * ie - sqrtf(k)) - lo * ie;
+      *wi = to_world(li, t, b, n);
     } else {
       bool spec = r3 < d.pd + d.ps;
       float ax = spec ? m.ax : d.cc_alpha, ay = spec ? m.ay : d.cc_alpha;
@@ -469,6 +512,7 @@ RT_DI Surface make_surface(const SceneView& sv, float pixel_spread, f3 o, f3 d, 
   sf.mat.metallic = m.metallic; sf.mat.roughness = m.roughness; sf.mat.specular_tint = m.specular_tint;
   sf.mat.sheen = m.sheen; sf.mat.sheen_tint = m.sheen_tint; sf.mat.clearcoat = m.clearcoat;
   sf.mat.clearcoat_roughness = m.clearcoat_roughness; sf.mat.ior = m.ior;
+  sf.mat.trans = 0.0f; sf.mat.eta = m.ior;
   // texture maps (set 2; u32::MAX = none, gltf_loader.rs:346-353)
   const uint32_t nt = sv.texture_count;
   const bool has_base = m.base_color_map_index < nt, has_nrm = m.normal_map_index < nt;
@@ -521,8 +565,12 @@ RT_DI Surface make_surface(const SceneView& sv, float pixel_spread, f3 o, f3 d, 
       }
     }
   }
+  if (m.type == 1u) sf.mat.trans = m.specular_transmission * (1.0f - sf.mat.metallic);  // after the metallic map
   if (dot3(sf.ns, sf.ng) < 0.0f) sf.ng = -sf.ng;
-  if (dot3(sf.ng, d) > 0.0f) { sf.ns = -sf.ns; sf.ng = -sf.ng; }
+  if (dot3(sf.ng, d) > 0.0f) {  // the path arrives from behind the surface: it is leaving the object
+    sf.ns = -sf.ns; sf.ng = -sf.ng;
+    sf.mat.eta = 1.0f / sf.mat.ior;
+  }
   return sf;
 }
 

@@ -352,7 +352,7 @@ def sponza_class(target_triangles=1_000_000, aspect=16.0 / 9.0, seed=7, disney=T
             s.materials.append(HalaMaterial(type=T, base_color=base, roughness=0.15 + 0.035 * (i % 12),
                                             metallic=1.0 if i % 6 == 1 else 0.0,
                                             clearcoat=1.0 if i % 8 == 3 else 0.0, clearcoat_roughness=0.1,
-                                            specular_transmission=0.0, ior=1.5))
+                                            specular_transmission=0.9 if i % 8 == 5 else 0.0, ior=1.5))  # 5: the second column mesh and one drape are glass
     n_col, n_arch, n_drape = 28, 14, 10
     # budget: columns 55 %, drapes 25 %, arches 8 %, floor+walls 12 %
     k = math.sqrt(max(target_triangles, 2000) / 1_000_000.0)

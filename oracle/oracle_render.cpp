@@ -175,8 +175,20 @@ static inline V3 ggx_sample_vndf(V3 v, float ax, float ay, float r1, float r2) {
   V3 nh = t1 * a + t2 * b + vh * cz;
   return normalize3(v3(ax * nh.x, ay * nh.y, maxf(0.0f, nh.z)));
 }
-struct DisneyLobes { float pd, ps, pc; V3 cspec0, csheen; float cc_alpha; };
-static inline DisneyLobes disney_lobes(const orc_gpu_material& m, V3 base, float nv) {
+struct DisneyLobes { float pd, ps, pc, pt; V3 cspec0, csheen; float cc_alpha; };
+// RENDER_SPEC §7.1c: what the refraction lobe needs beyond the packed material: trans = specular_transmission * (1 - metallic)
+// (after the metallic map), eta = index of the far side relative to the side the path arrives from
+struct Trans { float trans, eta; };
+// exact unpolarised Fresnel reflectance of a dielectric interface; c = |cos| on the arriving side
+static inline float fresnel_dielectric(float c, float eta) {
+  float g2 = eta * eta - 1.0f + c * c;
+  if (!(g2 > 0.0f)) return 1.0f;
+  float g = sqrtf(g2);
+  float a = (g - c) / (g + c);
+  float b = (c * (g + c) - 1.0f) / (c * (g - c) + 1.0f);
+  return 0.5f * a * a * (1.0f + b * b);
+}
+static inline DisneyLobes disney_lobes(const orc_gpu_material& m, V3 base, Trans tr, float nv) {
   DisneyLobes d;
   float lb = luminance(base);
   V3 tint = lb > 0.0f ? base * (1.0f / lb) : v3s(1.0f);
@@ -186,29 +198,52 @@ static inline DisneyLobes disney_lobes(const orc_gpu_material& m, V3 base, float
   d.csheen = mix3(v3s(1.0f), tint, m.sheen_tint);
   d.cc_alpha = maxf(0.001f, m.clearcoat_roughness * m.clearcoat_roughness);
   float fv = schlick5(nv);
-  float wd = (1.0f - m.metallic) * lb;
+  float wd = (1.0f - m.metallic) * lb * (1.0f - tr.trans);
   float ws = luminance(mix3(d.cspec0, v3s(1.0f), fv));
   float wc = 0.25f * m.clearcoat * mixf(0.04f, 1.0f, fv);
-  float sum = wd + ws + wc;
-  if (!(sum > 0.0f)) { d.pd = d.ps = d.pc = 0.0f; return d; }
+  float wt = tr.trans * (1.0f - mixf(f0, 1.0f, fv));
+  float sum = wd + ws + wc + wt;
+  if (!(sum > 0.0f)) { d.pd = d.ps = d.pc = d.pt = 0.0f; return d; }
   float inv = 1.0f / sum;
-  d.pd = wd * inv; d.ps = ws * inv; d.pc = wc * inv;
+  d.pd = wd * inv; d.ps = ws * inv; d.pc = wc * inv; d.pt = wt * inv;
   return d;
 }
-static inline void disney_eval(const orc_gpu_material& m, V3 base, V3 wo, V3 wi, V3 n, V3* f, float* pdf) {
+static inline void disney_eval(const orc_gpu_material& m, V3 base, Trans tr, V3 wo, V3 wi, V3 n, V3* f, float* pdf) {
   float nl = dot3(n, wi), nv = dot3(n, wo);
-  if (!(nl > 0.0f && nv > 0.0f)) { *f = v3s(0.0f); *pdf = 0.0f; return; }
+  *f = v3s(0.0f); *pdf = 0.0f;
+  if (!(nv > 0.0f)) return;
   V3 t, b;
   onb(n, &t, &b);
   V3 lo = v3(dot3(wo, t), dot3(wo, b), nv), li = v3(dot3(wi, t), dot3(wi, b), nl);
+  if (nl < 0.0f) {  // §7.1c refraction
+    if (!(tr.trans > 0.0f)) return;
+    V3 h = lo + li * tr.eta;
+    float h2 = dot3(h, h);
+    if (!(h2 > 0.0f)) return;
+    h = h * (1.0f / sqrtf(h2));
+    if (h.z < 0.0f) h = -h;
+    float odh = dot3(lo, h), idh = dot3(li, h);
+    if (!(odh > 0.0f && idh < 0.0f)) return;
+    DisneyLobes d = disney_lobes(m, base, tr, nv);
+    float fr = fresnel_dielectric(odh, tr.eta);
+    float ds = ggx_d(h, m.ax, m.ay);
+    float g1o = ggx_g1(lo, m.ax, m.ay), g1i = ggx_g1(li, m.ax, m.ay);
+    float den = odh + tr.eta * idh;
+    float jac = tr.eta * tr.eta * (-idh) / (den * den);
+    float w = tr.trans * (1.0f - fr) * ds * g1o * g1i * odh * jac / (-nl * nv);
+    *f = v3(sqrtf(base.x), sqrtf(base.y), sqrtf(base.z)) * w;
+    *pdf = d.pt * (g1o * odh * ds / nv) * jac;
+    return;
+  }
+  if (!(nl > 0.0f)) return;
   V3 h = normalize3(lo + li);
   float ldh = dot3(li, h);
-  DisneyLobes d = disney_lobes(m, base, nv);
+  DisneyLobes d = disney_lobes(m, base, tr, nv);
   float fl = schlick5(nl), fv = schlick5(nv), fh = schlick5(ldh);
   // diffuse + sheen
   float fd90 = 0.5f + 2.0f * sqrtf(m.roughness) * ldh * ldh;
   float fd = mixf(1.0f, fd90, fl) * mixf(1.0f, fd90, fv);
-  float dw = 1.0f - m.metallic;
+  float dw = (1.0f - m.metallic) * (1.0f - tr.trans);
   V3 fs = mix3(d.cspec0, v3s(1.0f), fh);  // specular Fresnel; the diffuse lobe only gets what it lets through
   V3 fr = base * (v3s(1.0f) - fs) * (kInvPi * fd * dw) + d.csheen * (m.sheen * fh * dw);
   // specular
@@ -226,8 +261,8 @@ static inline void disney_eval(const orc_gpu_material& m, V3 base, V3 wo, V3 wi,
   *pdf = d.pd * (nl * kInvPi) + d.ps * (g1o * ds * inv4nv) + d.pc * (c1o * dc * inv4nv);
 }
 
-static inline void bsdf_eval(const orc_gpu_material& m, V3 base, V3 wo, V3 wi, V3 n, V3* f, float* pdf) {
-  if (m.type == 1u) { disney_eval(m, base, wo, wi, n, f, pdf); return; }
+static inline void bsdf_eval(const orc_gpu_material& m, V3 base, Trans tr, V3 wo, V3 wi, V3 n, V3* f, float* pdf) {
+  if (m.type == 1u) { disney_eval(m, base, tr, wo, wi, n, f, pdf); return; }
   float nl = dot3(n, wi), nv = dot3(n, wo);
   if (!(nl > 0.0f && nv > 0.0f)) { *f = v3s(0.0f); *pdf = 0.0f; return; }
   float s = dot3(wi, wo) - nl * nv;
@@ -236,15 +271,24 @@ static inline void bsdf_eval(const orc_gpu_material& m, V3 base, V3 wo, V3 wi, V
   *f = base * k;
   *pdf = nl * kInvPi;
 }
-static inline bool bsdf_sample(const orc_gpu_material& m, V3 base, V3 wo, V3 n, float r1, float r2, float r3, V3* wi, V3* f, float* pdf) {
+static inline bool bsdf_sample(const orc_gpu_material& m, V3 base, Trans tr, V3 wo, V3 n, float r1, float r2, float r3, V3* wi, V3* f, float* pdf) {
   V3 t, b;
   onb(n, &t, &b);
   if (m.type == 1u) {
     float nv = dot3(n, wo);
     if (!(nv > 0.0f)) { *f = v3s(0.0f); *pdf = 0.0f; return false; }
-    DisneyLobes d = disney_lobes(m, base, nv);
+    DisneyLobes d = disney_lobes(m, base, tr, nv);
     if (r3 < d.pd) {
       *wi = to_world(cosine_hemisphere(r1, r2), t, b, n);
+    } else if (r3 >= d.pd + d.ps + d.pc) {  // §7.1c: refract through a VNDF-sampled facet
+      V3 lo = v3(dot3(wo, t), dot3(wo, b), nv);
+      V3 h = ggx_sample_vndf(lo, m.ax, m.ay, r1, r2);
+      float c = dot3(lo, h);
+      float ie = 1.0f / tr.eta;
+      float k = 1.0f - (1.0f - c * c) * (ie * ie);
+      if (!(k > 0.0f)) { *f = v3s(0.0f); *pdf = 0.0f; return false; }
+      V3 li = h * (c * ie - sqrtf(k)) - lo * ie;
+      *wi = to_world(li, t, b, n);
     } else {
       bool spec = r3 < d.pd + d.ps;
       float ax = spec ? m.ax : d.cc_alpha, ay = spec ? m.ay : d.cc_alpha;
@@ -254,12 +298,12 @@ static inline bool bsdf_sample(const orc_gpu_material& m, V3 base, V3 wo, V3 n, 
       V3 li = h * k - lo;
       *wi = to_world(li, t, b, n);
     }
-    disney_eval(m, base, wo, *wi, n, f, pdf);
+    disney_eval(m, base, tr, wo, *wi, n, f, pdf);
     return *pdf > 0.0f;
   }
   V3 l = cosine_hemisphere(r1, r2);
   *wi = to_world(l, t, b, n);
-  bsdf_eval(m, base, wo, *wi, n, f, pdf);
+  bsdf_eval(m, base, tr, wo, *wi, n, f, pdf);
   return *pdf > 0.0f;
 }
 
@@ -377,7 +421,7 @@ static float intersect_light(const orc_gpu_light& l, V3 o, V3 d, float* pdf) {
 }
 
 // ---- RENDER_SPEC §6 surface reconstruction ----------------------------------------------------------------------
-struct Surface { V3 P, ns, ng; orc_gpu_material m; V3 base; };  // m: the packed material after texture modulation
+struct Surface { V3 P, ns, ng; orc_gpu_material m; V3 base; Trans tr; };  // m: the packed material after texture modulation
 
 static inline V3 transform_normal(const float* m, V3 n) {
   // inverse-transpose of the upper 3x3 = cofactor matrix / det; columns c0,c1,c2 of M
@@ -507,8 +551,13 @@ static Surface make_surface(const orc_scene* s, float pixel_spread, V3 o, V3 d, 
       }
     }
   }
+  sf.tr.trans = 0.0f; sf.tr.eta = sf.m.ior;
+  if (sf.m.type == 1u) sf.tr.trans = sf.m.specular_transmission * (1.0f - sf.m.metallic);  // after the metallic map
   if (dot3(sf.ns, sf.ng) < 0.0f) sf.ng = -sf.ng;
-  if (dot3(sf.ng, d) > 0.0f) { sf.ns = -sf.ns; sf.ng = -sf.ng; }
+  if (dot3(sf.ng, d) > 0.0f) {  // the path arrives from behind the surface: it is leaving the object
+    sf.ns = -sf.ns; sf.ng = -sf.ng;
+    sf.tr.eta = 1.0f / sf.m.ior;
+  }
   return sf;
 }
 
@@ -567,7 +616,7 @@ static PixelOut trace_path(const Frame& f, uint32_t px, uint32_t py, uint32_t fr
       LightSample ls = sample_light(s->lights[idx], sf.P, r1, r2);
       if (ls.valid) {
         V3 fb; float pdf_b;
-        bsdf_eval(sf.m, sf.base, wo, ls.wi, sf.ns, &fb, &pdf_b);
+        bsdf_eval(sf.m, sf.base, sf.tr, wo, ls.wi, sf.ns, &fb, &pdf_b);
         if (pdf_b > 0.0f) {
           float side = dot3(ls.wi, sf.ng) >= 0.0f ? s->ray_eps : -s->ray_eps;
           V3 so = madd3(sf.ng, side, sf.P);
@@ -575,7 +624,7 @@ static PixelOut trace_path(const Frame& f, uint32_t px, uint32_t py, uint32_t fr
           st->rays_shadow++;
           bool occ = trace_any(nodes, tris, so, ls.wi, 0.0f, tmax, ctr);
           if (!occ) {
-            float cosl = dot3(sf.ns, ls.wi);
+            float cosl = fabsf(dot3(sf.ns, ls.wi));
             V3 contrib;
             if (ls.delta) contrib = fb * ls.le * (cosl * (float)nl);
             else {
@@ -594,14 +643,14 @@ static PixelOut trace_path(const Frame& f, uint32_t px, uint32_t py, uint32_t fr
       V3 wi; float pdf_e;
       if (env_map_sample(f, r1, r2, &wi, &pdf_e)) {
         V3 fb; float pdf_b;
-        bsdf_eval(sf.m, sf.base, wo, wi, sf.ns, &fb, &pdf_b);
+        bsdf_eval(sf.m, sf.base, sf.tr, wo, wi, sf.ns, &fb, &pdf_b);
         if (pdf_b > 0.0f) {
           float side = dot3(wi, sf.ng) >= 0.0f ? s->ray_eps : -s->ray_eps;
           V3 so = madd3(sf.ng, side, sf.P);
           st->rays_shadow++;
           bool occ = trace_any(nodes, tris, so, wi, 0.0f, kTMax, ctr);
           if (!occ) {
-            float cosl = dot3(sf.ns, wi);
+            float cosl = fabsf(dot3(sf.ns, wi));
             float w = power_heuristic(pdf_e, pdf_b);
             V3 col = env_map_eval(f, wi);
             L = L + T * (fb * col * (cosl * w / pdf_e));
@@ -612,7 +661,7 @@ static PixelOut trace_path(const Frame& f, uint32_t px, uint32_t py, uint32_t fr
     // continue the path
     float r1 = rng_next(&rng), r2 = rng_next(&rng), r3 = rng_next(&rng);
     V3 wi, fb; float pdf_b;
-    if (!bsdf_sample(sf.m, sf.base, wo, sf.ns, r1, r2, r3, &wi, &fb, &pdf_b)) break;
+    if (!bsdf_sample(sf.m, sf.base, sf.tr, wo, sf.ns, r1, r2, r3, &wi, &fb, &pdf_b)) break;
     T = T * fb * (fabsf(dot3(sf.ns, wi)) / pdf_b);
     prev_pdf = pdf_b;
     if (depth >= f.p.rr_depth) {

@@ -146,6 +146,9 @@ DISNEY_VARIANTS = {
     "plastic": dict(metallic=0.0, roughness=0.5),
     "metal_aniso": dict(metallic=1.0, roughness=0.4, anisotropic=0.8, base_color=(0.9, 0.7, 0.4)),
     "clearcoat_sheen": dict(metallic=0.0, roughness=0.7, clearcoat=1.0, clearcoat_roughness=0.2, sheen=0.8, sheen_tint=0.5, specular_tint=0.6),
+    # §7.1c: the refraction lobe (entering, leaving, total internal reflection); the env-map pass also connects THROUGH the surface
+    "glass_rough": dict(metallic=0.0, roughness=0.4, specular_transmission=1.0, ior=1.5),
+    "glass_tinted_partial": dict(metallic=0.0, roughness=0.25, specular_transmission=0.6, ior=1.33, base_color=(0.9, 0.6, 0.5)),
 }
 
 
