@@ -429,6 +429,20 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(FrameConst fc, SceneVie
         ps.albedo[slot] = make_float4(sf.mat.base.x, sf.mat.base.y, sf.mat.base.z, 1.0f);
         ps.normal[slot] = make_float4(sf.ns.x, sf.ns.y, sf.ns.z, 1.0f);
       }
+      bool through = false;
+      if (sf.mat.opacity < 1.0f) {  // §7.1d: the surface is skipped with probability 1 - opacity (one extra random number)
+        const float ro = rng_next(rng);
+        through = !(ro < sf.mat.opacity);
+      }
+      if (through) {
+        const bool alive = depth + 1u < fc.u.max_depth;
+        keep[0] = alive;
+        if (alive) {
+          no = madd3(sf.ng, -sv.ray_eps, sf.P);
+          nd = d;
+          ps.throughput_pdf[slot] = make_float4(T.x, T.y, T.z, prev_pdf);
+        }
+      } else {
       const f3 em = sf.mat.emission;
       if (em.x > 0.0f || em.y > 0.0f || em.z > 0.0f) L = L + T * em;
       const f3 wo = -d;
@@ -500,6 +514,7 @@ __global__ void __launch_bounds__(kShadeThreads) k_shade(FrameConst fc, SceneVie
           ps.throughput_pdf[slot] = make_float4(T.x, T.y, T.z, prev_pdf);
         }
       }
+      }  // !through
     }
     ps.radiance_rng[slot] = make_float4(L.x, L.y, L.z, __uint_as_float(rng));
   }

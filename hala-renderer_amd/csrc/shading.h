@@ -145,6 +145,7 @@ struct MatView {
   uint32_t type;
   // DISNEY (type 1) only
   float metallic, roughness, specular_tint, sheen, sheen_tint, clearcoat, clearcoat_roughness, ior;
+  float opacity;  // §7.1d: material opacity x base-colour-map alpha
   float trans;  // §7.1c: specular_transmission * (1 - metallic)
   float eta;    // §7.1c: index of the far side relative to the side the path arrives from (ior entering, 1/ior leaving)
 };
@@ -512,7 +513,7 @@ RT_DI Surface make_surface(const SceneView& sv, float pixel_spread, f3 o, f3 d, 
   sf.mat.metallic = m.metallic; sf.mat.roughness = m.roughness; sf.mat.specular_tint = m.specular_tint;
   sf.mat.sheen = m.sheen; sf.mat.sheen_tint = m.sheen_tint; sf.mat.clearcoat = m.clearcoat;
   sf.mat.clearcoat_roughness = m.clearcoat_roughness; sf.mat.ior = m.ior;
-  sf.mat.trans = 0.0f; sf.mat.eta = m.ior;
+  sf.mat.trans = 0.0f; sf.mat.eta = m.ior; sf.mat.opacity = m.opacity;
   // texture maps (set 2; u32::MAX = none, gltf_loader.rs:346-353)
   const uint32_t nt = sv.texture_count;
   const bool has_base = m.base_color_map_index < nt, has_nrm = m.normal_map_index < nt;
@@ -532,6 +533,7 @@ RT_DI Surface make_surface(const SceneView& sv, float pixel_spread, f3 o, f3 d, 
     if (has_base) {
       const float4 s = tex_sample(sv, m.base_color_map_index, tu, tv, tex_lod(sv, m.base_color_map_index, lod_base));
       sf.mat.base = sf.mat.base * mk3(s.x, s.y, s.z);
+      sf.mat.opacity = sf.mat.opacity * s.w;
     }
     if (has_em) {
       const float4 s = tex_sample(sv, m.emission_map_index, tu, tv, tex_lod(sv, m.emission_map_index, lod_base));

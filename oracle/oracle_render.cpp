@@ -421,7 +421,7 @@ static float intersect_light(const orc_gpu_light& l, V3 o, V3 d, float* pdf) {
 }
 
 // ---- RENDER_SPEC §6 surface reconstruction ----------------------------------------------------------------------
-struct Surface { V3 P, ns, ng; orc_gpu_material m; V3 base; Trans tr; };  // m: the packed material after texture modulation
+struct Surface { V3 P, ns, ng; orc_gpu_material m; V3 base; Trans tr; float opacity; };  // opacity: §7.1d, material x base-colour-map alpha  // m: the packed material after texture modulation
 
 static inline V3 transform_normal(const float* m, V3 n) {
   // inverse-transpose of the upper 3x3 = cofactor matrix / det; columns c0,c1,c2 of M
@@ -497,6 +497,7 @@ static Surface make_surface(const orc_scene* s, float pixel_spread, V3 o, V3 d, 
   sf.ng = normalize3(gcross);
   sf.P = madd3(d, h.t, o);
   sf.m = s->materials[inst.material_index];
+  sf.opacity = sf.m.opacity;
   orc_gpu_material& m = sf.m;
   sf.base = ld3(m.base_color);
   const orc_gpu_material& pm = s->materials[inst.material_index];  // as packed (the maps modulate a copy)
@@ -517,6 +518,7 @@ static Surface make_surface(const orc_scene* s, float pixel_spread, V3 o, V3 d, 
     if (has_base) {
       C4 t = tex_sample(s, pm.base_color_map_index, tu, tv, tex_lod(s, pm.base_color_map_index, lod_base));
       sf.base = sf.base * v3(t.x, t.y, t.z);
+      sf.opacity = sf.opacity * t.w;
     }
     if (has_em) {
       C4 t = tex_sample(s, pm.emission_map_index, tu, tv, tex_lod(s, pm.emission_map_index, lod_base));
@@ -606,6 +608,10 @@ static PixelOut trace_path(const Frame& f, uint32_t px, uint32_t py, uint32_t fr
     }
     Surface sf = make_surface(s, f.pixel_spread, o, d, h);
     if (depth == 0) { out.albedo = sf.base; out.normal = sf.ns; }
+    if (sf.opacity < 1.0f) {  // §7.1d: the surface is skipped with probability 1 - opacity (one extra random number, drawn only here)
+      float ro = rng_next(&rng);
+      if (!(ro < sf.opacity)) { o = madd3(sf.ng, -s->ray_eps, sf.P); continue; }
+    }
     V3 em = ld3(sf.m.emission);
     if (em.x > 0.0f || em.y > 0.0f || em.z > 0.0f) L = L + T * em;
     V3 wo = -d;

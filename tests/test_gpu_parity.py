@@ -620,3 +620,21 @@ def test_full_size_render_properties(halart):
     r2.render()
     assert np.array_equal(r2.read_image(0)[..., :3], a[..., :3] * f32(2.0))
     r.close(); r2.close()
+
+
+def test_render_opacity_bit_exact(halart, oracle):
+    """RENDER_SPEC §7.1d: stochastic pass-through of partly transparent surfaces (material opacity; the texture-alpha factor
+    is covered by the BGRA-tagged texture of test_textures_*), same random number budget on both sides"""
+    s = scenes.cornell_box()
+    s.materials[0].opacity = 0.35   # white: floor, ceiling, back wall, blocks -> paths leak out of the box into the sky
+    s.materials[2].opacity = 0.0    # one side wall: never shaded
+    r = make_renderer(halart, s, 64, 64, max_depth=6, rr_depth=2)
+    for _ in range(3):
+        r.update(); r.render()
+    imgs, st = oracle.OracleScene(s).render(64, 64, frames=3, max_depth=6, rr_depth=2)
+    assert_images_equal(r, imgs)
+    stg = r.statistics()
+    assert (stg.rays_closest_total, stg.rays_shadow_total) == (st.rays_closest, st.rays_shadow)
+    opaque, _ = oracle.OracleScene(scenes.cornell_box()).render(64, 64, frames=3, max_depth=6, rr_depth=2)
+    assert np.abs(opaque[0][..., :3] - imgs[0][..., :3]).mean() > 0.02
+    r.close()
