@@ -17,18 +17,6 @@ namespace rt {
 
 // wave64 helpers ------------------------------------------------------------------------------------------
 RT_DI uint32_t lane_id() { return threadIdx.x & 63u; }
-// Ordered compaction inside one wave: returns this lane's output index (base comes from one atomic per wave).
-RT_DI uint32_t wave_compact(bool keep, uint32_t* counter) {
-  const unsigned long long mask = __ballot(keep);
-  const uint32_t total = (uint32_t)__popcll(mask);
-  uint32_t base = 0;
-  if (total) {
-    if (lane_id() == 0u) base = atomicAdd(counter, total);
-    base = (uint32_t)__shfl((int)base, 0);
-  }
-  const uint32_t before = (uint32_t)__popcll(mask & ((1ull << lane_id()) - 1ull));
-  return base + before;
-}
 RT_DI uint32_t wave_sum(uint32_t v) {
   for (int off = 32; off > 0; off >>= 1) v += (uint32_t)__shfl_down((int)v, off);
   return v;  // valid in lane 0
@@ -74,8 +62,8 @@ RT_DI void block_compact3(BlockCompact& sm, const bool keep[3], uint32_t* const 
   }
 }
 
-// Sharded dequeue of ray batches for the persistent kernels (see WorkCounters).  Returns the first ray of a batch of
-// up to kWorkBatch rays inside [0, n), or kAbsent when every shard is dry.  Wave-uniform.
+// Sharded dequeue of rays for the persistent kernels (see WorkCounters): the queue [0, n) is cut into kWorkShards
+// contiguous shards, each with its own counter; a wave works on one shard until it is dry.  Wave-uniform.
 struct WorkCursor {
   uint32_t shard, per;
 };
@@ -86,35 +74,6 @@ RT_DI WorkCursor work_begin(uint32_t n) {
   c.per = ((batches + kWorkShards - 1u) / kWorkShards) * kWorkBatch;  // rays per shard, a multiple of the batch
   return c;
 }
-RT_DI uint32_t work_next(WorkCounters* wc, WorkCursor& c, uint32_t n, uint32_t* end) {
-  constexpr uint32_t kAll = (1u << kWorkShards) - 1u;
-  for (;;) {
-    uint32_t v = 0;
-    if (lane_id() == 0u) v = atomicAdd(&wc->c[c.shard * kWorkStride], kWorkBatch);
-    v = (uint32_t)__shfl((int)v, 0);
-    const unsigned long long lo = (unsigned long long)c.shard * c.per + v;
-    const unsigned long long hi = min((unsigned long long)(c.shard + 1u) * c.per, (unsigned long long)n);
-    if (v < c.per && lo < hi) {
-      *end = (uint32_t)min(lo + kWorkBatch, hi);
-      return (uint32_t)lo;
-    }
-    // this shard is dry: publish that (once) and move to a shard nobody has reported dry yet.  The mask only ever
-    // gains bits and a bit is set only after the shard's last batch was handed out, so a stale read costs at most an
-    // extra probe and "all dry" is never reported early.
-    uint32_t m = 0;
-    if (lane_id() == 0u) {
-      m = __hip_atomic_load(&wc->dry[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (!(m & (1u << c.shard))) { atomicOr(&wc->dry[0], 1u << c.shard); m |= 1u << c.shard; }
-    }
-    m = (uint32_t)__shfl((int)m, 0);
-    if ((m & kAll) == kAll) return kAbsent;
-    const uint32_t avail = ~m & kAll;
-    const uint32_t rot = (c.shard + 1u) & (kWorkShards - 1u);
-    const uint32_t r = ((avail >> rot) | (avail << (kWorkShards - rot))) & kAll;  // bit k <-> shard rot + k
-    c.shard = (rot + (uint32_t)__ffs((int)r) - 1u) & (kWorkShards - 1u);
-  }
-}
-
 // Variable-size dequeue for the refill loop: asks for `want` rays, is granted 1..want of them from one shard.
 RT_DI uint32_t work_take(WorkCounters* wc, WorkCursor& c, uint32_t n, uint32_t want, uint32_t* got) {
   constexpr uint32_t kAll = (1u << kWorkShards) - 1u;
@@ -128,6 +87,9 @@ RT_DI uint32_t work_take(WorkCounters* wc, WorkCursor& c, uint32_t n, uint32_t w
       *got = (uint32_t)min((unsigned long long)want, hi - lo);
       return (uint32_t)lo;
     }
+    // this shard is dry: publish that (once) and move to a shard nobody has reported dry yet.  The mask only ever
+    // gains bits and a bit is set only after the shard's last ray was handed out, so a stale read costs at most an
+    // extra probe and "all dry" is never reported early.
     uint32_t m = 0;
     if (lane_id() == 0u) {
       m = __hip_atomic_load(&wc->dry[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
