@@ -350,6 +350,107 @@ __global__ void k_emit_single4(const Box6* __restrict__ leaf_box, uint32_t n, Bv
   nodes[0] = pack_node4(ch, 1);
 }
 
+// ---- PLOC (parallel locally-ordered clustering, Meister & Bittner 2018) ----------------------------------------------
+// An alternative to the Karras hierarchy over the same Morton-sorted triangles: clusters (initially the triangles, in
+// Morton order) repeatedly merge with their nearest neighbour — nearest = smallest surface area of the union, searched
+// kPlocRadius positions to either side — whenever the choice is mutual.  Same arrays out as k_hierarchy (left, right,
+// parents, per-node triangle ranges), so fit / collapse / pack / refit are shared; because merged clusters need not be
+// adjacent, the triangles are re-ordered once at the end so that every subtree is a contiguous range again.
+constexpr int kPlocRadius = 16;
+RT_DI uint32_t ploc_size(uint32_t ref, const uint32_t* __restrict__ subtree) { return (ref & kLeafBit) ? 1u : subtree[ref]; }
+
+__global__ void __launch_bounds__(256) k_ploc_init(const Box6* __restrict__ tri_box, const uint32_t* __restrict__ sorted_ids, uint32_t n,
+                                                    uint32_t* __restrict__ cl_ref, Box6* __restrict__ cl_box) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  cl_ref[k] = kLeafBit | k;
+  cl_box[k] = tri_box[sorted_ids[k]];
+}
+__global__ void __launch_bounds__(256) k_ploc_nearest(const Box6* __restrict__ cl_box, uint32_t m, uint32_t radius, uint32_t* __restrict__ nn) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const Box6 bi = cl_box[i];
+  const uint32_t lo = i > radius ? i - radius : 0u, hi = min(m - 1u, i + radius);
+  float best = 3.402823466e+38f;
+  uint32_t bj = i;
+  for (uint32_t j = lo; j <= hi; ++j) {  // ascending j + strict '<': ties go to the lower index (guarantees a mutual pair)
+    if (j == i) continue;
+    const float a = half_area(box_union(bi, cl_box[j]));
+    if (a < best || bj == i) { best = a; bj = j; }
+  }
+  nn[i] = bj;
+}
+__global__ void __launch_bounds__(256) k_ploc_flags(const uint32_t* __restrict__ nn, uint32_t m, uint32_t* __restrict__ merge,
+                                                     uint32_t* __restrict__ keepc) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const uint32_t j = nn[i];
+  const bool mutual = j != i && nn[j] == i;
+  merge[i] = (mutual && i < j) ? 1u : 0u;
+  keepc[i] = (mutual && i > j) ? 0u : 1u;
+}
+__global__ void __launch_bounds__(256) k_ploc_apply(const uint32_t* __restrict__ nn, const uint32_t* __restrict__ merge,
+                                                     const uint32_t* __restrict__ keepc, const uint32_t* __restrict__ merge_scan,
+                                                     const uint32_t* __restrict__ keep_scan, uint32_t m, uint32_t next_id,
+                                                     const uint32_t* __restrict__ cl_ref, const Box6* __restrict__ cl_box,
+                                                     uint32_t* __restrict__ cl_ref_out, Box6* __restrict__ cl_box_out,
+                                                     uint32_t* __restrict__ left, uint32_t* __restrict__ right, uint32_t* __restrict__ node_parent,
+                                                     uint32_t* __restrict__ leaf_parent, uint32_t* __restrict__ subtree) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m || !keepc[i]) return;
+  const uint32_t pos = keep_scan[i];
+  if (!merge[i]) { cl_ref_out[pos] = cl_ref[i]; cl_box_out[pos] = cl_box[i]; return; }
+  const uint32_t j = nn[i], id = next_id - merge_scan[i];  // ids count down: the last merge of all creates node 0, the root
+  const uint32_t ra = cl_ref[i], rb = cl_ref[j];
+  left[id] = ra; right[id] = rb;
+  if (ra & kLeafBit) leaf_parent[ra & ~kLeafBit] = id; else node_parent[ra] = id;
+  if (rb & kLeafBit) leaf_parent[rb & ~kLeafBit] = id; else node_parent[rb] = id;
+  subtree[id] = ploc_size(ra, subtree) + ploc_size(rb, subtree);
+  cl_ref_out[pos] = id;
+  cl_box_out[pos] = box_union(cl_box[i], cl_box[j]);
+}
+// position of leaf k / first position of node i in the depth-first order of the finished tree: the sizes of all left
+// siblings passed on the way up
+RT_DI uint32_t ploc_offset(uint32_t ref, uint32_t p, const uint32_t* __restrict__ left, const uint32_t* __restrict__ right,
+                           const uint32_t* __restrict__ node_parent, const uint32_t* __restrict__ subtree) {
+  uint32_t pos = 0;
+  while (p != kAbsent) {
+    if (right[p] == ref) pos += ploc_size(left[p], subtree);
+    ref = p;
+    p = node_parent[p];
+  }
+  return pos;
+}
+__global__ void __launch_bounds__(256) k_ploc_leaf_order(const uint32_t* __restrict__ left, const uint32_t* __restrict__ right,
+                                                          const uint32_t* __restrict__ node_parent, const uint32_t* __restrict__ leaf_parent,
+                                                          const uint32_t* __restrict__ subtree, const uint32_t* __restrict__ sorted_ids, uint32_t n,
+                                                          uint32_t* __restrict__ new_pos, uint32_t* __restrict__ sorted_ids_out,
+                                                          uint32_t* __restrict__ leaf_parent_out) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const uint32_t pos = ploc_offset(kLeafBit | k, leaf_parent[k], left, right, node_parent, subtree);
+  new_pos[k] = pos;
+  sorted_ids_out[pos] = sorted_ids[k];
+  leaf_parent_out[pos] = leaf_parent[k];
+}
+__global__ void __launch_bounds__(256) k_ploc_node_ranges(const uint32_t* __restrict__ left, const uint32_t* __restrict__ right,
+                                                           const uint32_t* __restrict__ node_parent, const uint32_t* __restrict__ subtree,
+                                                           uint32_t n_internal, uint32_t* __restrict__ first, uint32_t* __restrict__ last) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_internal) return;
+  const uint32_t off = ploc_offset(i, node_parent[i], left, right, node_parent, subtree);
+  first[i] = off;
+  last[i] = off + subtree[i] - 1u;
+}
+__global__ void __launch_bounds__(256) k_ploc_renumber(uint32_t* __restrict__ left, uint32_t* __restrict__ right, const uint32_t* __restrict__ new_pos,
+                                                        uint32_t n_internal) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_internal) return;
+  const uint32_t l = left[i], r = right[i];
+  if (l & kLeafBit) left[i] = kLeafBit | new_pos[l & ~kLeafBit];
+  if (r & kLeafBit) right[i] = kLeafBit | new_pos[r & ~kLeafBit];
+}
+
 struct DevBuf {
   void* p = nullptr;
   ~DevBuf() { if (p) (void)hipFree(p); }
@@ -441,6 +542,63 @@ static std::string fit_and_emit(BvhBuffers& b, BvhTopology& t, hipStream_t s) {
   return "";
 }
 
+// Builds left/right/parents/first/last with PLOC instead of k_hierarchy (same contract; t.sorted_ids is re-ordered).
+static std::string ploc_hierarchy(BvhBuffers& b, BvhTopology& t, hipStream_t s) {
+  const uint32_t n = b.tri_count, ni = n - 1;
+  DevBuf ref[2], box[2], nn, merge, keepc, merge_scan, keep_scan, subtree, new_pos, ids2, lp2, tmp;
+  std::string e;
+  for (int k = 0; k < 2; ++k) {
+    if (!(e = ref[k].alloc((size_t)n * 4)).empty()) return e;
+    if (!(e = box[k].alloc((size_t)n * sizeof(Box6))).empty()) return e;
+  }
+  for (DevBuf* d : {&nn, &merge, &keepc, &merge_scan, &keep_scan, &new_pos, &ids2, &lp2})
+    if (!(e = d->alloc((size_t)n * 4)).empty()) return e;
+  if (!(e = subtree.alloc((size_t)ni * 4)).empty()) return e;
+  size_t tmp_bytes = 0;
+  HIP_TRY(rocprim::exclusive_scan(nullptr, tmp_bytes, merge.as<uint32_t>(), merge_scan.as<uint32_t>(), 0u, n, rocprim::plus<uint32_t>(), s));
+  if (!(e = tmp.alloc(tmp_bytes)).empty()) return e;
+  hipLaunchKernelGGL(k_ploc_init, dim3(nblk(n)), dim3(256), 0, s, t.tri_box.as<Box6>(), t.sorted_ids.as<uint32_t>(), n, ref[0].as<uint32_t>(),
+                     box[0].as<Box6>());
+  uint32_t m = n, created = 0;
+  int cur = 0;
+  uint32_t radius = kPlocRadius;
+  if (const char* ev = getenv("HALART_PLOC_RADIUS")) radius = (uint32_t)std::max(1, atoi(ev));  // tuning knob
+  while (m > 1) {
+    hipLaunchKernelGGL(k_ploc_nearest, dim3(nblk(m)), dim3(256), 0, s, box[cur].as<Box6>(), m, radius, nn.as<uint32_t>());
+    hipLaunchKernelGGL(k_ploc_flags, dim3(nblk(m)), dim3(256), 0, s, nn.as<uint32_t>(), m, merge.as<uint32_t>(), keepc.as<uint32_t>());
+    size_t tb = tmp_bytes;
+    HIP_TRY(rocprim::exclusive_scan(tmp.p, tb, merge.as<uint32_t>(), merge_scan.as<uint32_t>(), 0u, m, rocprim::plus<uint32_t>(), s));
+    tb = tmp_bytes;
+    HIP_TRY(rocprim::exclusive_scan(tmp.p, tb, keepc.as<uint32_t>(), keep_scan.as<uint32_t>(), 0u, m, rocprim::plus<uint32_t>(), s));
+    hipLaunchKernelGGL(k_ploc_apply, dim3(nblk(m)), dim3(256), 0, s, nn.as<uint32_t>(), merge.as<uint32_t>(), keepc.as<uint32_t>(),
+                       merge_scan.as<uint32_t>(), keep_scan.as<uint32_t>(), m, (ni - 1u) - created, ref[cur].as<uint32_t>(), box[cur].as<Box6>(),
+                       ref[cur ^ 1].as<uint32_t>(), box[cur ^ 1].as<Box6>(), t.left.as<uint32_t>(), t.right.as<uint32_t>(),
+                       t.node_parent.as<uint32_t>(), t.leaf_parent.as<uint32_t>(), subtree.as<uint32_t>());
+    uint32_t last_scan = 0, last_flag = 0;
+    HIP_TRY(hipMemcpyAsync(&last_scan, merge_scan.as<uint32_t>() + (m - 1), 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&last_flag, merge.as<uint32_t>() + (m - 1), 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const uint32_t merged = last_scan + last_flag;
+    if (merged == 0) return "bvh_build: PLOC made no progress";  // cannot happen: the closest pair is always mutual
+    created += merged;
+    m -= merged;
+    cur ^= 1;
+  }
+  static const uint32_t absent = kAbsent;
+  HIP_TRY(hipMemcpyAsync(t.node_parent.p, &absent, 4, hipMemcpyHostToDevice, s));  // node 0 is the root
+  hipLaunchKernelGGL(k_ploc_leaf_order, dim3(nblk(n)), dim3(256), 0, s, t.left.as<uint32_t>(), t.right.as<uint32_t>(), t.node_parent.as<uint32_t>(),
+                     t.leaf_parent.as<uint32_t>(), subtree.as<uint32_t>(), t.sorted_ids.as<uint32_t>(), n, new_pos.as<uint32_t>(),
+                     ids2.as<uint32_t>(), lp2.as<uint32_t>());
+  hipLaunchKernelGGL(k_ploc_node_ranges, dim3(nblk(ni)), dim3(256), 0, s, t.left.as<uint32_t>(), t.right.as<uint32_t>(), t.node_parent.as<uint32_t>(),
+                     subtree.as<uint32_t>(), ni, t.first.as<uint32_t>(), t.last.as<uint32_t>());
+  hipLaunchKernelGGL(k_ploc_renumber, dim3(nblk(ni)), dim3(256), 0, s, t.left.as<uint32_t>(), t.right.as<uint32_t>(), new_pos.as<uint32_t>(), ni);
+  HIP_TRY(hipMemcpyAsync(t.sorted_ids.p, ids2.p, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+  HIP_TRY(hipMemcpyAsync(t.leaf_parent.p, lp2.p, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  HIP_TRY(hipGetLastError());
+  return "";
+}
+
 void bvh_free_topology(void* topo) { delete static_cast<BvhTopology*>(topo); }
 
 std::string bvh_build(BvhBuffers& b, uint32_t leaf_max, hipStream_t s) {
@@ -476,9 +634,16 @@ std::string bvh_build(BvhBuffers& b, uint32_t leaf_max, hipStream_t s) {
     if (!(e = tmp.alloc(tmp_bytes)).empty()) return e;
     HIP_TRY(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, keys_in.as<unsigned long long>(), keys_out.as<unsigned long long>(),
                                       ids_in.as<uint32_t>(), t.sorted_ids.as<uint32_t>(), n, 0, 64, s));
-    hipLaunchKernelGGL(k_hierarchy, dim3(nblk(n - 1)), dim3(256), 0, s, keys_out.as<unsigned long long>(), (int)n, t.left.as<uint32_t>(),
-                       t.right.as<uint32_t>(), t.first.as<uint32_t>(), t.last.as<uint32_t>(), t.node_parent.as<uint32_t>(),
-                       t.leaf_parent.as<uint32_t>());
+    // hierarchy over the sorted triangles: PLOC for scenes large enough to repay its ~40 rounds of launches (+4-5 % rays/s on
+    // the 82 k and 1 M triangle scenes for +6 ms of build, profiles/r01_h_experiments.txt), Karras' LBVH otherwise
+    const char* builder = getenv("HALART_BUILDER");  // "ploc" | "lbvh": A/B knob
+    const bool ploc = builder ? !strcmp(builder, "ploc") : n >= 4096u;
+    if (ploc) {
+      if (!(e = ploc_hierarchy(b, t, s)).empty()) return e;
+    } else
+      hipLaunchKernelGGL(k_hierarchy, dim3(nblk(n - 1)), dim3(256), 0, s, keys_out.as<unsigned long long>(), (int)n, t.left.as<uint32_t>(),
+                         t.right.as<uint32_t>(), t.first.as<uint32_t>(), t.last.as<uint32_t>(), t.node_parent.as<uint32_t>(),
+                         t.leaf_parent.as<uint32_t>());
     hipLaunchKernelGGL(k_keep_flags, dim3(nblk(n - 1)), dim3(256), 0, s, t.first.as<uint32_t>(), t.last.as<uint32_t>(), n - 1, leaf_max,
                        t.keep.as<uint32_t>());
   } else if (n == 1) {

@@ -307,7 +307,10 @@ k_trace_shadow(SceneView sv, Queues q, PathState ps, Control* __restrict__ ctl, 
 // PRIMARY (depth 0): queue entry i IS path slot i, its ray is re-evaluated from the camera instead of being read, and
 // the path state starts from its constants (throughput 1, radiance 0) — this kernel initialises every per-path record.
 template <bool PRIMARY>
-__global__ void __launch_bounds__(kShadeThreads) k_shade(FrameConst fc, SceneView sv, Queues q, PathState ps, Control* __restrict__ ctl, uint32_t depth) {
+#ifndef RT_SHADE_WAVES
+#define RT_SHADE_WAVES 4
+#endif
+__global__ void __launch_bounds__(kShadeThreads, RT_SHADE_WAVES) k_shade(FrameConst fc, SceneView sv, Queues q, PathState ps, Control* __restrict__ ctl, uint32_t depth) {
   __shared__ BlockCompact s_compact;
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t n = PRIMARY ? fc.slot_count : ctl->n_active[depth];

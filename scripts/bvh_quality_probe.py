@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""LBVH (GPU builder) vs binned-SAH (oracle's CPU builder), both as compressed 4-wide trees: traversal steps per ray on
+"""GPU builder (PLOC or LBVH, see HALART_BUILDER) vs binned-SAH (oracle's CPU builder), both as compressed 4-wide trees: traversal steps per ray on
 the same rays, and an instruction-weighted cost (a node visit ~ 170 VALU, a triangle test ~ 60)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -28,6 +28,6 @@ for name, s in [("blob82k", scenes.bunny_class(subdivisions=6)), ("atrium250k", 
         _, c_lbvh = O.trace_on_bvh(nodes, tris, rr, 0)
         n = len(rr)
         cost = lambda c: (170 * c[0] + 60 * c[1]) / n
-        print(f"{name} {label}: cost SAH {cost(c_sah):.0f} LBVH {cost(c_lbvh):.0f} ratio {cost(c_lbvh) / cost(c_sah):.2f}")
-        print(f"{name} {label}: SAH nodes/ray {c_sah[0]/n:.2f} tris/ray {c_sah[1]/n:.2f} | LBVH nodes/ray {c_lbvh[0]/n:.2f} tris/ray {c_lbvh[1]/n:.2f} | oracle nodes {len(snodes)} gpu nodes {len(nodes)}")
+        print(f"{name} {label}: cost SAH {cost(c_sah):.0f} GPU {cost(c_lbvh):.0f} ratio {cost(c_lbvh) / cost(c_sah):.2f}")
+        print(f"{name} {label}: SAH nodes/ray {c_sah[0]/n:.2f} tris/ray {c_sah[1]/n:.2f} | GPU-built nodes/ray {c_lbvh[0]/n:.2f} tris/ray {c_lbvh[1]/n:.2f} | oracle nodes {len(snodes)} gpu nodes {len(nodes)}")
     r.close()
