@@ -54,7 +54,7 @@ RT_DI f3 transform_point(const float* m, f3 p) {
 
 // one thread per global triangle id
 __global__ void __launch_bounds__(256) k_flatten(const hala_gpu_mesh_data* __restrict__ prims, const uint32_t* __restrict__ first_tri,
-                                                  uint32_t inst_count, uint32_t n, Tri* __restrict__ tris_by_id,
+                                                  uint32_t inst_count, uint32_t n, Tri* __restrict__ tris_by_id, ShadeTri* __restrict__ shade_tris,
                                                   uint32_t* __restrict__ tri_instance, Box6* __restrict__ tri_box,
                                                   uint32_t* __restrict__ scene_ord /* [6] min xyz, max xyz */) {
   const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -77,6 +77,15 @@ __global__ void __launch_bounds__(256) k_flatten(const hala_gpu_mesh_data* __res
   out[1] = make_float4(e1.x, e1.y, e1.z, 0.0f);
   out[2] = make_float4(e2.x, e2.y, e2.z, 0.0f);
   tri_instance[g] = lo;
+  ShadeTri st{};
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const hala_vertex& vx = vb[idx[c]];
+    for (int k = 0; k < 3; ++k) { st.n[c][k] = vx.normal[k]; st.tg[c][k] = vx.tangent[k]; }
+    st.uv[c][0] = vx.tex_coord[0]; st.uv[c][1] = vx.tex_coord[1];
+  }
+  st.inst = lo; st.material = md.material_index;
+  shade_tris[g] = st;
   Box6 b;
   b.mn[0] = fminf(v[0].x, fminf(v[1].x, v[2].x)); b.mx[0] = fmaxf(v[0].x, fmaxf(v[1].x, v[2].x));
   b.mn[1] = fminf(v[0].y, fminf(v[1].y, v[2].y)); b.mx[1] = fmaxf(v[0].y, fmaxf(v[1].y, v[2].y));
@@ -476,7 +485,7 @@ static std::string flatten_and_bounds(BvhBuffers& b, BvhTopology& t, hipStream_t
   const uint32_t n = b.tri_count;
   static const uint32_t init_ord[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
   HIP_TRY(hipMemcpyAsync(t.scene_ord.p, init_ord, sizeof(init_ord), hipMemcpyHostToDevice, s));
-  if (n) hipLaunchKernelGGL(k_flatten, dim3(nblk(n)), dim3(256), 0, s, b.primitives, b.inst_first_tri, b.instance_count, n, b.tris_by_id,
+  if (n) hipLaunchKernelGGL(k_flatten, dim3(nblk(n)), dim3(256), 0, s, b.primitives, b.inst_first_tri, b.instance_count, n, b.tris_by_id, b.shade_tris,
                             b.tri_instance, t.tri_box.as<Box6>(), t.scene_ord.as<uint32_t>());
   uint32_t ord[6];
   HIP_TRY(hipMemcpyAsync(ord, t.scene_ord.p, sizeof(ord), hipMemcpyDeviceToHost, s));

@@ -53,6 +53,20 @@ struct alignas(16) Tri {
 };
 static_assert(sizeof(Tri) == 48, "triangle is 48 B");
 
+// 112-B shading record of one triangle (global-id order): what the closest-hit stage interpolates, gathered once at
+// build time from the vertex / index arenas so that shading a hit costs one dependent fetch (this record) instead of a
+// chain triangle -> instance -> indices -> three 44-B vertices.  Values are the LOCAL vertex attributes, untouched: the
+// instance transform is applied to the interpolated normal exactly as RENDER_SPEC §6 says (288 GB of HBM pay for this).
+struct alignas(16) ShadeTri {
+  float n[3][3];    // vertex normals
+  float uv[3][2];   // texture coordinates
+  float tg[3][3];   // tangents (normal mapping)
+  uint32_t inst;    // instance (node x primitive) -> transform, material
+  uint32_t material;
+  uint32_t pad[2];
+};
+static_assert(sizeof(ShadeTri) == 112, "shading record is 112 B");
+
 // One texture of set 2 binding 0 (src/rt_renderer.rs:197-226): a full mip chain of linear RGBA32F texels in the
 // texture arena (8-bit sources are decoded once at upload; gen_mipmaps of gpu_uploader.rs:366-400 is a 2x2 box filter
 // kernel).  mip_offset[l] = first texel of level l, in float4 units from the arena base.
@@ -73,6 +87,7 @@ struct SceneView {
   const BvhNode4* nodes;
   const Tri* tris;             // BVH order
   const Tri* tris_by_id;       // global-id order (for shading)
+  const ShadeTri* shade_tris;  // global-id order: per-vertex attributes of the hit triangle in one record
   const uint32_t* tri_instance;  // global id -> instance
   const uint32_t* inst_first_tri;
   const hala_gpu_mesh_data* primitives;  // set 1 binding 4

@@ -43,6 +43,7 @@ struct BvhBuffers {
   // outputs (device, allocated by the caller)
   Tri* tris_by_id;         // [tri_count]
   Tri* tris;               // [tri_count] BVH order
+  ShadeTri* shade_tris;    // [tri_count] global-id order
   uint32_t* tri_instance;  // [tri_count]
   BvhNode4* nodes;         // capacity >= max(tri_count - 1, 1)
   void* topology = nullptr;  // builder state kept for refit (freed with bvh_free_topology)

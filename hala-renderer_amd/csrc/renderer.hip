@@ -121,6 +121,7 @@ struct hala_rt_renderer {
 
   BvhBuffers bvh{};
   DeviceArray<Tri> d_tris_by_id, d_tris;
+  DeviceArray<ShadeTri> d_shade_tris;
   DeviceArray<uint32_t> d_tri_instance;
   DeviceArray<BvhNode4> d_nodes;
   uint32_t lds_nodes = 0, lds_tris = 0;
@@ -177,7 +178,7 @@ struct hala_rt_renderer {
 
   SceneView view() const {
     SceneView sv{};
-    sv.nodes = d_nodes.ptr; sv.tris = d_tris.ptr; sv.tris_by_id = d_tris_by_id.ptr; sv.tri_instance = d_tri_instance.ptr;
+    sv.nodes = d_nodes.ptr; sv.tris = d_tris.ptr; sv.tris_by_id = d_tris_by_id.ptr; sv.shade_tris = d_shade_tris.ptr; sv.tri_instance = d_tri_instance.ptr;
     sv.inst_first_tri = d_inst_first_tri.ptr; sv.primitives = d_instances.ptr; sv.materials = d_materials.ptr;
     sv.lights = d_lights.ptr; sv.cameras = d_cameras.ptr;
     sv.textures = d_textures.ptr; sv.tex_arena = d_tex_arena.ptr; sv.texture_count = (uint32_t)host_textures.size();
@@ -415,11 +416,11 @@ int configure_traversal(hala_rt_renderer* r) {
 
 int build_bvh(hala_rt_renderer* r) {
   const uint32_t n = r->hs.triangle_count;
-  RT_HIP(r->d_tris_by_id.resize(n)); RT_HIP(r->d_tris.resize(n)); RT_HIP(r->d_tri_instance.resize(n));
+  RT_HIP(r->d_tris_by_id.resize(n)); RT_HIP(r->d_tris.resize(n)); RT_HIP(r->d_tri_instance.resize(n)); RT_HIP(r->d_shade_tris.resize(n));
   RT_HIP(r->d_nodes.resize(std::max<uint32_t>(n, 2) - 1));
   r->bvh.primitives = r->d_instances.ptr; r->bvh.inst_first_tri = r->d_inst_first_tri.ptr;
   r->bvh.instance_count = (uint32_t)r->hs.instances.size(); r->bvh.tri_count = n;
-  r->bvh.tris_by_id = r->d_tris_by_id.ptr; r->bvh.tris = r->d_tris.ptr; r->bvh.tri_instance = r->d_tri_instance.ptr; r->bvh.nodes = r->d_nodes.ptr;
+  r->bvh.tris_by_id = r->d_tris_by_id.ptr; r->bvh.shade_tris = r->d_shade_tris.ptr; r->bvh.tris = r->d_tris.ptr; r->bvh.tri_instance = r->d_tri_instance.ptr; r->bvh.nodes = r->d_nodes.ptr;
   uint32_t leaf_max = kLeafMax;
   if (const char* ev = getenv("HALART_LEAF_MAX")) leaf_max = std::min(8u, std::max(1u, (uint32_t)atoi(ev)));  // tuning knob
   const std::string e = bvh_build(r->bvh, leaf_max, r->stream);

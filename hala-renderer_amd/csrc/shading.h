@@ -492,21 +492,22 @@ RT_DI Surface make_surface(const SceneView& sv, float pixel_spread, f3 o, f3 d, 
   Surface sf;
   const float4* tp = reinterpret_cast<const float4*>(sv.tris_by_id + prim);
   const float4 tb = tp[1], tc = tp[2];
-  const uint32_t inst = sv.tri_instance[prim];
+  // one 112-B record holds the three vertices' attributes, the instance and the material of the hit triangle
+  const float4* sp = reinterpret_cast<const float4*>(sv.shade_tris + prim);
+  const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3], s6 = sp[6];
+  const uint32_t inst = __float_as_uint(s6.x), material = __float_as_uint(s6.y);
   const hala_gpu_mesh_data& md = sv.primitives[inst];
-  const uint32_t lt = prim - sv.inst_first_tri[inst];
-  const uint32_t* idx = reinterpret_cast<const uint32_t*>(md.indices) + 3 * (size_t)lt;
-  const hala_vertex* vb = reinterpret_cast<const hala_vertex*>(md.vertices);
-  const hala_vertex& a = vb[idx[0]];
-  const hala_vertex& b = vb[idx[1]];
-  const hala_vertex& c = vb[idx[2]];
+  struct VA { float normal[3], tex_coord[2], tangent[3]; };
+  const VA a = {{s0.x, s0.y, s0.z}, {s2.y, s2.z}, {0.0f, 0.0f, 0.0f}};
+  const VA b = {{s0.w, s1.x, s1.y}, {s2.w, s3.x}, {0.0f, 0.0f, 0.0f}};
+  const VA c = {{s1.z, s1.w, s2.x}, {s3.y, s3.z}, {0.0f, 0.0f, 0.0f}};
   float w0 = 1.0f - u - v;
   f3 nl = madd3(ld3(c.normal), v, madd3(ld3(b.normal), u, ld3(a.normal) * w0));
   sf.ns = normalize3(transform_normal(md.transform, nl));
   const f3 gcross = cross3(mk3(tb.x, tb.y, tb.z), mk3(tc.x, tc.y, tc.z));
   sf.ng = normalize3(gcross);
   sf.P = madd3(d, t, o);
-  const hala_gpu_material& m = sv.materials[md.material_index];
+  const hala_gpu_material& m = sv.materials[material];
   sf.mat.base = ld3(m.base_color);
   sf.mat.emission = ld3(m.emission);
   sf.mat.ax = m.ax; sf.mat.ay = m.ay; sf.mat.type = m.type;
@@ -553,7 +554,8 @@ RT_DI Surface make_surface(const SceneView& sv, float pixel_spread, f3 o, f3 d, 
     }
     if (has_nrm) {
       const float4 s = tex_sample(sv, m.normal_map_index, tu, tv, tex_lod(sv, m.normal_map_index, lod_base));
-      const f3 tl = madd3(ld3(c.tangent), v, madd3(ld3(b.tangent), u, ld3(a.tangent) * w0));
+      const float4 s4 = sp[4], s5 = sp[5];  // tangents: s3.w s4.x s4.y | s4.z s4.w s5.x | s5.y s5.z s5.w
+      const f3 tl = madd3(mk3(s5.y, s5.z, s5.w), v, madd3(mk3(s4.z, s4.w, s5.x), u, mk3(s3.w, s4.x, s4.y) * w0));
       f3 tw = transform_vector(md.transform, tl);
       tw = tw - sf.ns * dot3(sf.ns, tw);  // Gram-Schmidt against the shading normal
       const float tl2 = dot3(tw, tw);
