@@ -148,10 +148,10 @@ struct Control {
   unsigned long long primary_steps[2];  // counting launches: steps[0] as it stood after the depth-0 launch (camera rays only)
 };
 
-// wavefront path state, SoA, indexed by pixel slot
+// per-path records indexed by path slot (everything a live path needs from bounce to bounce travels in its queue entry)
 struct PathState {
-  float4* throughput_pdf;  // T.xyz, pdf of the last BSDF sample
-  float4* radiance_rng;    // L.xyz, rng counter (bits)
+  float4* radiance;        // L.xyz of the path: set by the depth-0 shade, added to by later shades (rarely: light hit,
+                           // environment, emission) and by the shadow passes
   float4* albedo;          // first-hit AOVs of this sample
   float4* normal;
 };
@@ -164,8 +164,8 @@ struct ShadowEntry {  // 48 B: one NEE connection = shadow ray + the contributio
 static_assert(sizeof(ShadowEntry) == 48, "shadow entry is 48 B");
 
 struct Queues {
-  hala_ray* rays[2];
-  uint32_t* slots[2];
+  hala_ray* rays[2];  // bounce rays; tmin / tmax are implied (0 / FLT_MAX): their fields carry the path slot / the RNG counter
+  float4* state[2];  // throughput.xyz | pdf of the last BSDF sample, next to the ray of the same queue entry
   hala_hit* hits;
   // compact connection queues of the current bounce: [0] light NEE, [1] environment NEE.  A path owns at most one entry
   // per queue, the two queues are traced by consecutive launches, so contributions land in spec order without atomics.

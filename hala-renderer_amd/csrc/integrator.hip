@@ -171,10 +171,11 @@ struct BatchSource {
   const hala_ray* rays;
   hala_hit* hits;
   bool any;
+  bool queue;  // the renderer's own bounce-ray queue: tmin = 0, tmax = FLT_MAX, their fields carry path slot and RNG counter
   RT_DI bool load(uint32_t i, f3* o, f3* d, float* tmin, float* tmax, Payload*) const {
     const float4* rp = reinterpret_cast<const float4*>(rays + i);
     const float4 ro = rp[0], rd = rp[1];
-    *o = mk3(ro.x, ro.y, ro.z); *d = mk3(rd.x, rd.y, rd.z); *tmin = ro.w; *tmax = rd.w;
+    *o = mk3(ro.x, ro.y, ro.z); *d = mk3(rd.x, rd.y, rd.z); *tmin = queue ? 0.0f : ro.w; *tmax = queue ? kTMax : rd.w;
     return true;
   }
   RT_DI void done(uint32_t i, const Trav& t, const Payload&) const {
@@ -218,7 +219,7 @@ struct CameraSource {
 struct ShadowSource {
   struct Payload { float4 cs; };  // contribution.xyz | pixel slot, fetched with the ray (one coalesced 48-B record)
   const ShadowEntry* entries;
-  float4* radiance_rng;
+  float4* radiance;
   RT_DI bool load(uint32_t i, f3* o, f3* d, float* tmin, float* tmax, Payload* p) const {
     const float4* e = reinterpret_cast<const float4*>(entries + i);
     const float4 ro = e[0], rd = e[1];
@@ -231,7 +232,7 @@ struct ShadowSource {
   // no ordering freedom) and the lane does not stall on a read-modify-write round trip.
   RT_DI void done(uint32_t, const Trav& t, const Payload& p) const {
     if (t.best.prim != kAbsent) return;  // occluded
-    float* l = reinterpret_cast<float*>(radiance_rng + __float_as_uint(p.cs.w));
+    float* l = reinterpret_cast<float*>(radiance + __float_as_uint(p.cs.w));
     atomicAdd(l + 0, p.cs.x);
     atomicAdd(l + 1, p.cs.y);
     atomicAdd(l + 2, p.cs.z);
@@ -264,7 +265,7 @@ k_trace_batch(SceneView sv, const hala_ray* __restrict__ rays, hala_hit* __restr
   if (account && blockIdx.x == 0 && threadIdx.x == 0) {
     if (ANY) ctl->rays_shadow += n; else ctl->rays_closest += n;
   }
-  BatchSource src{rays, hits, ANY};
+  BatchSource src{rays, hits, ANY, account != 0};
   persistent_trace<ANY, COUNT, STAGED>(sv, lds, spill, work, n, refill, src, sc);
   if (COUNT) flush_counters(ctl, ANY ? 1 : 0, sc);
 }
@@ -296,7 +297,7 @@ k_trace_shadow(SceneView sv, Queues q, PathState ps, Control* __restrict__ ctl, 
   const uint32_t n = ctl->n_shadow[kind][depth];
   uint2* spill = spill_base ? spill_base + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * kStackSpill : nullptr;
   StepCounters sc;
-  ShadowSource src{q.shadow[kind], ps.radiance_rng};
+  ShadowSource src{q.shadow[kind], ps.radiance};
   persistent_trace<true, COUNT, STAGED>(sv, lds, spill, &ctl->work_shadow[kind], n, refill, src, sc);
   if (COUNT) flush_counters(ctl, 1, sc);
 }
@@ -330,30 +331,28 @@ __global__ void __launch_bounds__(kShadeThreads, RT_SHADE_WAVES) k_shade(FrameCo
   float4 conn[2][3];  // the two NEE connections of this path, written to the compact queues after the block scan
   uint32_t slot = 0;
   f3 o, d;
-  uint32_t rng = 0;
+  uint32_t rng = 0, rng_out = 0;                          // RNG counter on entry / for the next queue entry
+  float4 state_out = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // throughput | pdf for the next queue entry
   bool real = active;  // false: padding slot of a sharded frame (depth 0 only; later queues hold real paths only)
   if (PRIMARY && active) {
     slot = i;
     real = primary_ray(fc, sv, slot, &o, &d, &rng);
     if (!real) {  // resolve reads every slot of the rank's tile buffer
-      ps.radiance_rng[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      ps.radiance[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       ps.albedo[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       ps.normal[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
   }
   if (real) {
+    // L: what this bounce adds to the path's radiance (at most one term: light hit | environment | emission)
     f3 T = splat3(1.0f), L = splat3(0.0f);
     float prev_pdf = 0.0f;
-    if (!PRIMARY) {
-      slot = q.slots[in][i];
+    if (!PRIMARY) {  // the whole state of a live path is its queue entry: coalesced reads, no gather by slot
       const float4* rp = reinterpret_cast<const float4*>(q.rays[in] + i);
-      const float4 ro = rp[0], rd = rp[1];
+      const float4 ro = rp[0], rd = rp[1], st = q.state[in][i];
       o = mk3(ro.x, ro.y, ro.z); d = mk3(rd.x, rd.y, rd.z);
-      const float4 tp = ps.throughput_pdf[slot];
-      const float4 lr = ps.radiance_rng[slot];
-      T = mk3(tp.x, tp.y, tp.z); L = mk3(lr.x, lr.y, lr.z);
-      prev_pdf = tp.w;
-      rng = __float_as_uint(lr.w);
+      slot = __float_as_uint(ro.w); rng = __float_as_uint(rd.w);
+      T = mk3(st.x, st.y, st.z); prev_pdf = st.w;
     }
     const float4 hv = reinterpret_cast<const float4*>(q.hits)[i];
     const uint32_t hit_prim = __float_as_uint(hv.w);
@@ -405,7 +404,6 @@ __global__ void __launch_bounds__(kShadeThreads, RT_SHADE_WAVES) k_shade(FrameCo
         if (alive) {
           no = madd3(sf.ng, -sv.ray_eps, sf.P);
           nd = d;
-          ps.throughput_pdf[slot] = make_float4(T.x, T.y, T.z, prev_pdf);
         }
       } else {
       const f3 em = sf.mat.emission;
@@ -476,12 +474,17 @@ __global__ void __launch_bounds__(kShadeThreads, RT_SHADE_WAVES) k_shade(FrameCo
           const float side = dot3(wi, sf.ng) >= 0.0f ? sv.ray_eps : -sv.ray_eps;
           no = madd3(sf.ng, side, sf.P);
           nd = wi;
-          ps.throughput_pdf[slot] = make_float4(T.x, T.y, T.z, prev_pdf);
         }
       }
       }  // !through
     }
-    ps.radiance_rng[slot] = make_float4(L.x, L.y, L.z, __uint_as_float(rng));
+    if (PRIMARY) ps.radiance[slot] = make_float4(L.x, L.y, L.z, 0.0f);
+    else if (L.x != 0.0f || L.y != 0.0f || L.z != 0.0f) {  // radiance += term (this launch touches the word once: a plain update)
+      const float4 l = ps.radiance[slot];
+      ps.radiance[slot] = make_float4(l.x + L.x, l.y + L.y, l.z + L.z, 0.0f);
+    }
+    rng_out = rng;
+    state_out = make_float4(T.x, T.y, T.z, prev_pdf);
   }
   // ballot compaction (block level) of the surviving paths and of the two kinds of NEE connections
   uint32_t pos[3];
@@ -489,9 +492,9 @@ __global__ void __launch_bounds__(kShadeThreads, RT_SHADE_WAVES) k_shade(FrameCo
   block_compact3(s_compact, keep, counters, &ctl->rays_shadow, pos);
   if (keep[0]) {
     float4* rp = reinterpret_cast<float4*>(q.rays[out] + pos[0]);
-    rp[0] = make_float4(no.x, no.y, no.z, 0.0f);
-    rp[1] = make_float4(nd.x, nd.y, nd.z, kTMax);
-    q.slots[out][pos[0]] = slot;
+    rp[0] = make_float4(no.x, no.y, no.z, __uint_as_float(slot));
+    rp[1] = make_float4(nd.x, nd.y, nd.z, __uint_as_float(rng_out));
+    q.state[out][pos[0]] = state_out;
   }
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
@@ -512,7 +515,7 @@ __global__ void __launch_bounds__(256) k_resolve(FrameConst fc, PathState ps, fl
   float4 a = accum[pslot], b = albedo[pslot], n = normal[pslot];
   for (uint32_t k = 0; k < fc.samples; ++k) {  // the batch's samples, folded in frame order
     const uint32_t slot = k * fc.pixel_slots + pslot;
-    const float4 lr = ps.radiance_rng[slot];
+    const float4 lr = ps.radiance[slot];
     f3 L = mk3(lr.x, lr.y, lr.z);
     if (!(isfinite(L.x) && isfinite(L.y) && isfinite(L.z))) L = splat3(0.0f);
     const uint32_t fi = fc.u.frame_index + k;

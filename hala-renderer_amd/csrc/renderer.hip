@@ -145,9 +145,9 @@ struct hala_rt_renderer {
   DeviceArray<float4> img_local[4];  // accum, albedo, normal, final (slot order)
   DeviceArray<float4> img_full[4];   // row-major, only after scatter_gathered_tiles (world > 1)
   bool full_valid[4] = {false, false, false, false};
-  DeviceArray<float4> ps_tp, ps_lr, ps_alb, ps_nrm;
+  DeviceArray<float4> ps_lr, ps_alb, ps_nrm;
   DeviceArray<hala_ray> q_rays[2];
-  DeviceArray<uint32_t> q_slots[2];
+  DeviceArray<float4> q_state[2];
   DeviceArray<hala_hit> q_hits;
   DeviceArray<ShadowEntry> q_shadow[2];
   DeviceArray<Control> d_ctl;
@@ -190,11 +190,11 @@ struct hala_rt_renderer {
   }
   Queues queues() const {
     Queues q{};
-    q.rays[0] = q_rays[0].ptr; q.rays[1] = q_rays[1].ptr; q.slots[0] = q_slots[0].ptr; q.slots[1] = q_slots[1].ptr;
+    q.rays[0] = q_rays[0].ptr; q.rays[1] = q_rays[1].ptr; q.state[0] = q_state[0].ptr; q.state[1] = q_state[1].ptr;
     q.hits = q_hits.ptr; q.shadow[0] = q_shadow[0].ptr; q.shadow[1] = q_shadow[1].ptr;
     return q;
   }
-  PathState path_state() const { return PathState{ps_tp.ptr, ps_lr.ptr, ps_alb.ptr, ps_nrm.ptr}; }
+  PathState path_state() const { return PathState{ps_lr.ptr, ps_alb.ptr, ps_nrm.ptr}; }
 
   FrameConst frame_const(const hala_global_uniform& u, uint32_t samples = 1) const {
     FrameConst fc{};
@@ -300,8 +300,8 @@ void compute_tiling(hala_rt_renderer* r) {
 int alloc_wavefront(hala_rt_renderer* r, uint32_t samples) {
   const size_t n = (size_t)r->slot_count * samples;
   if (n > 0xfffffff0ull) RT_FAIL("The sample batch is too large for 32-bit path slots.");
-  RT_HIP(r->ps_tp.resize(n)); RT_HIP(r->ps_lr.resize(n)); RT_HIP(r->ps_alb.resize(n)); RT_HIP(r->ps_nrm.resize(n));
-  RT_HIP(r->q_rays[0].resize(n)); RT_HIP(r->q_rays[1].resize(n)); RT_HIP(r->q_slots[0].resize(n)); RT_HIP(r->q_slots[1].resize(n));
+  RT_HIP(r->ps_lr.resize(n)); RT_HIP(r->ps_alb.resize(n)); RT_HIP(r->ps_nrm.resize(n));
+  RT_HIP(r->q_rays[0].resize(n)); RT_HIP(r->q_rays[1].resize(n)); RT_HIP(r->q_state[0].resize(n)); RT_HIP(r->q_state[1].resize(n));
   RT_HIP(r->q_hits.resize(n)); RT_HIP(r->q_shadow[0].resize(n)); RT_HIP(r->q_shadow[1].resize(n));
   r->batch_capacity = samples;
   return HALA_OK;
