@@ -25,7 +25,10 @@ RT_DI uint32_t wave_sum(uint32_t v) {
 // Block-level compaction of up to two predicates at once: one atomic per workgroup and counter instead of one per
 // wave (a single counter word takes ~88 atomics/us; a 2 M-path launch of 64-lane waves would need 32 K of them).
 // All threads of the block must call it.  Returns this lane's output index for each predicate.
-constexpr int kShadeThreads = 512;
+#ifndef RT_SHADE_THREADS
+#define RT_SHADE_THREADS 512
+#endif
+constexpr int kShadeThreads = RT_SHADE_THREADS;
 struct BlockCompact {
   uint32_t cnt[3][kShadeThreads / 64];
   uint32_t base[3];
