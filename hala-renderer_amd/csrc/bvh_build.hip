@@ -4,7 +4,8 @@
 //   flatten   every instance (node x primitive, in the reference's instance order gpu_uploader.rs:843-875) is
 //             transformed to world space once -> one triangle soup, one BVH (288 GB of HBM make the copy free and
 //             single-level traversal needs no per-instance ray transform)
-//   build     60-bit Morton codes (+ 2-bit size class) -> rocPRIM radix sort -> Karras 2012 binary hierarchy ->
+//   build     60-bit Morton codes (+ 2-bit size class) -> rocPRIM radix sort -> binary hierarchy: PLOC (nearest-neighbour
+//             clustering along the Morton order) for >= 4096 triangles, Karras 2012 LBVH below ->
 //             bottom-up AABB fit with arrival counters -> subtrees of <= leaf_max triangles become leaves ->
 //             top-down collapse into 4-wide nodes, breadth-first, by surface area -> 64-B compressed nodes
 //             (8-bit child boxes quantised conservatively against the node's own box, RENDER_SPEC §4.1b)
