@@ -5,8 +5,9 @@
   workload : configs[1] — Cornell box (32 triangles), 1920x1080, 4 spp, diffuse-only closest hit, max_depth 5, rr_depth 3
   step     : one frame = update_batch(4) == 4 x update() (the reference renders 1 spp per update,
              src/rt_renderer.rs:458-464; the four samples travel through the wavefront kernels together) + render()
-  N > 1    : weak scaling — every rank renders one 1920x1080-pixel share of a (1920*kx) x (1080*ky) frame (kx*ky = N),
-             cut into 32x32 tiles dealt to the ranks by a fixed permutation; after the 4 spp the accumulated image is
+  N > 1    : weak scaling — the same view at sqrt(N) x the linear resolution (2720x1530, 3840x2160, 5440x3060 for N = 2, 4,
+             8), cut into 32x32 tiles dealt to the ranks by a fixed permutation: every rank renders ~1920x1080 pixels
+             with the ray statistics of the 1-GPU frame; after the 4 spp the accumulated image is
              all-gathered over RCCL (one collective per frame) and de-interleaved on every rank.
 
 Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (closest-hit traversal) with the
@@ -26,13 +27,13 @@ BASE_W, BASE_H, SPP, MAX_DEPTH, RR_DEPTH, TILE = 1920, 1080, 4, 5, 3, 32
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def grid_for(n):
-    best = (n, 1)
-    for a in range(1, n + 1):
-        if n % a == 0 and a >= n // a:
-            best = (a, n // a)
-            break
-    return best  # (kx, ky) with kx >= ky, as square as the divisors allow
+def frame_for(n):
+    """Weak scaling: N GPUs render the SAME view (same camera, 16:9) at sqrt(N) x the linear resolution, so that every rank's
+    share of 32x32 tiles — dealt over the whole image — holds the same number of pixels with the same ray statistics as the
+    1-GPU frame.  Width is rounded up to a whole tile: 1920x1080, 2720x1530, 3840x2160, 5440x3060 for N = 1, 2, 4, 8."""
+    import math
+    w = int(math.ceil(BASE_W * math.sqrt(n) / TILE)) * TILE
+    return w, int(round(w * BASE_H / BASE_W))
 
 
 def cpu_baseline(scene_fn):
@@ -94,8 +95,7 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    kx, ky = grid_for(world)
-    W, Hh = BASE_W * kx, BASE_H * ky
+    W, Hh = frame_for(world)
     aspect = W / Hh
 
     def scene_fn():
@@ -217,7 +217,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt_all / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"configs[1]: procedural Cornell box (32 triangles), {W}x{Hh} ({BASE_W}x{BASE_H} pixels per GPU), {SPP} spp, diffuse-only closest hit",
+            "config": {"workload": f"configs[1]: procedural Cornell box (32 triangles), {W}x{Hh} (~{BASE_W}x{BASE_H} pixels per GPU), {SPP} spp, diffuse-only closest hit",
                        "resolution": [W, Hh], "spp": SPP, "max_depth": MAX_DEPTH, "rr_depth": RR_DEPTH,
                        "parallelism": f"pixel-tile shard {TILE}x{TILE} over {world} rank(s)" + (", one RCCL all-gather of the accumulated image per frame" if world > 1 else ""),
                        "rays_per_frame": int(rays_all / args.steps), "ms_per_frame": round(dt_all / args.steps * 1e3, 4)},
