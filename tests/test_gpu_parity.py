@@ -638,3 +638,47 @@ def test_render_opacity_bit_exact(halart, oracle):
     opaque, _ = oracle.OracleScene(scenes.cornell_box()).render(64, 64, frames=3, max_depth=6, rr_depth=2)
     assert np.abs(opaque[0][..., :3] - imgs[0][..., :3]).mean() > 0.02
     r.close()
+
+
+def test_full_size_scene_bvh_and_rays(halart, oracle):
+    """BASELINE configs[3] size (~1 M triangles, instanced meshes, PLOC builder): the tree passes the structural check with
+    the bit-exact flattening, a sample of rays agrees with brute force over all triangles, and size-independent properties
+    hold for a large batch: any-hit == (closest hit exists), hit ids are valid, a hit re-traced with tmax just below its t
+    misses"""
+    s = scenes.sponza_class(target_triangles=1_000_000, disney=False)
+    r = make_renderer(halart, s, 16, 16)
+    osc = oracle.OracleScene(s)
+    info = r.bvh_info()
+    assert info.triangle_count == osc.triangle_count > 900_000
+    nodes, tris = r.download_bvh()
+    rc, depth = oracle.validate_bvh(nodes, tris, osc.triangles())
+    assert rc == 0 and depth == info.max_depth
+    rays = osc.camera_rays(640, 360, 0)
+    got = r.trace_rays_host(rays, 0)
+    sub = slice(0, None, len(rays) // 1500)
+    assert got[sub].tobytes() == osc.trace(rays[sub], 0, brute=True).tobytes()
+    hit = got["prim"] != 0xFFFFFFFF
+    assert hit.mean() > 0.5 and got["prim"][hit].max() < info.triangle_count
+    anyh = r.trace_rays_host(rays, 1)
+    assert np.array_equal(anyh["t"] > 0, hit)
+    again = rays[hit].copy()
+    again["tmax"] = got["t"][hit] * np.float32(0.999)
+    closer = r.trace_rays_host(again, 0)
+    assert np.all(closer["t"][closer["prim"] != 0xFFFFFFFF] < again["tmax"][closer["prim"] != 0xFFFFFFFF])
+    assert (closer["prim"] != 0xFFFFFFFF).mean() < 0.01  # nothing in front of a closest hit (up to grazing ties)
+    r.close()
+
+
+def test_headline_config_full_resolution_bit_exact(halart, oracle):
+    """BASELINE configs[1] at its own size: Cornell box, 1920x1080, max_depth 5, rr_depth 3; two of the four samples, rendered
+    as one batch like bench.py does, against the oracle pixel for pixel (8.3 M paths), plus the ray totals"""
+    s = scenes.cornell_box(aspect=1920 / 1080)
+    r = make_renderer(halart, s, 1920, 1080)
+    r.update_batch(2)
+    r.render()
+    imgs, st = oracle.OracleScene(s).render(1920, 1080, frames=2)
+    assert_images_equal(r, imgs)
+    stg = r.statistics()
+    assert (stg.rays_closest_total, stg.rays_shadow_total) == (st.rays_closest, st.rays_shadow)
+    assert stg.rays_primary_total == 2 * 1920 * 1080
+    r.close()
