@@ -1,0 +1,501 @@
+// gltf_loader.cpp — host C++ restatement of src/scene/loader/gltf_loader.rs behind the C ABI:
+// `hala_scene_load_gltf` is cpu::HalaScene::new (src/scene/cpu/scene.rs:40-55); the scene it returns is the borrowed
+// `hala_scene_desc` that `hala_rt_set_scene` consumes.  Rule by rule like the reference (each rule cites its lines); the
+// reference delegates parsing to the `gltf` and `image` crates — here: the library's own JSON reader, base64, accessor
+// decoding, and a PNG decoder over zlib (8/16-bit, grey / RGB / palette / alpha, non-interlaced).  JPEG and interlaced PNG
+// images are reported as "Unsupported image format." (the Python mirror hala-renderer_amd/gltf_loader.py decodes those with PIL).
+#include <zlib.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/halart.h"
+#include "host_util.h"
+
+using rt::JsonValue;
+
+struct hala_scene {
+  std::deque<std::string> names;  // stable addresses for hala_node_desc::name
+  std::vector<hala_node_desc> nodes;
+  std::deque<std::vector<uint32_t>> indices;
+  std::deque<std::vector<hala_vertex>> vertices;
+  std::deque<std::vector<hala_primitive_desc>> prims;
+  std::vector<hala_mesh_desc> meshes;
+  std::vector<hala_material_desc> materials;
+  std::vector<hala_light_desc> lights;
+  std::vector<hala_camera_desc> cameras;
+  std::vector<hala_index_pair> tex2img, img2data;
+  std::deque<std::vector<uint8_t>> pixels;
+  std::vector<hala_image_desc> images;
+  hala_scene_desc desc{};
+};
+
+namespace {
+
+struct LoadError { std::string msg; };
+[[noreturn]] void fail(const std::string& m) { throw LoadError{m}; }
+
+// ---- JSON helpers ---------------------------------------------------------------------------------------------------
+const JsonValue* get(const JsonValue& o, const char* key) { return o.kind == JsonValue::Object ? o.find(key) : nullptr; }
+double num(const JsonValue& o, const char* key, double dflt) {
+  const JsonValue* v = get(o, key);
+  return (v && v->kind == JsonValue::Number) ? v->num : dflt;
+}
+bool has(const JsonValue& o, const char* key) { return get(o, key) != nullptr; }
+uint32_t index_or_invalid(const JsonValue& o, const char* key) {
+  const JsonValue* v = get(o, key);
+  return (v && v->kind == JsonValue::Number) ? (uint32_t)v->num : HALA_INVALID_INDEX;
+}
+const std::vector<JsonValue>& arr(const JsonValue& o, const char* key) {
+  static const std::vector<JsonValue> empty;
+  const JsonValue* v = get(o, key);
+  return (v && v->kind == JsonValue::Array) ? v->items : empty;
+}
+void floats(const JsonValue& o, const char* key, float* out, int n, const float* dflt) {
+  const JsonValue* v = get(o, key);
+  for (int i = 0; i < n; ++i) out[i] = (v && v->kind == JsonValue::Array && (size_t)i < v->items.size()) ? (float)v->items[i].num : dflt[i];
+}
+
+// ---- bytes: files, data URIs ----------------------------------------------------------------------------------------
+std::vector<uint8_t> read_file(const std::string& path) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) fail("Open file \"" + path + "\" failed.");
+  return std::vector<uint8_t>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+}
+std::vector<uint8_t> base64_decode(const std::string& s, size_t from) {
+  static int8_t table[256];
+  static bool init = false;
+  if (!init) {
+    memset(table, -1, sizeof(table));
+    const char* a = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
+    for (int i = 0; i < 64; ++i) table[(uint8_t)a[i]] = (int8_t)i;
+    init = true;
+  }
+  std::vector<uint8_t> out;
+  uint32_t acc = 0; int bits = 0;
+  for (size_t i = from; i < s.size(); ++i) {
+    const int8_t v = table[(uint8_t)s[i]];
+    if (v < 0) continue;  // padding, whitespace
+    acc = (acc << 6) | (uint32_t)v; bits += 6;
+    if (bits >= 8) { bits -= 8; out.push_back((uint8_t)(acc >> bits)); }
+  }
+  return out;
+}
+struct Doc {
+  std::string dir;
+  JsonValue j;
+  std::vector<std::vector<uint8_t>> buffers;
+  std::vector<uint8_t> load_uri(const std::string& uri) const {
+    if (uri.rfind("data:", 0) == 0) {
+      const size_t comma = uri.find(',');
+      if (comma == std::string::npos) fail("Malformed data URI.");
+      return base64_decode(uri, comma + 1);
+    }
+    return read_file(dir.empty() ? uri : dir + "/" + uri);
+  }
+};
+
+// ---- accessors ------------------------------------------------------------------------------------------------------
+struct Accessor { std::vector<double> v; int ncomp = 0; size_t count = 0; };
+Accessor read_accessor(const Doc& d, uint32_t idx) {
+  const auto& accs = arr(d.j, "accessors");
+  if (idx >= accs.size()) fail("Accessor index out of range.");
+  const JsonValue& a = accs[idx];
+  const auto& views = arr(d.j, "bufferViews");
+  const uint32_t bvi = index_or_invalid(a, "bufferView");
+  if (bvi >= views.size()) fail("Accessor without a buffer view (sparse accessors are not supported).");
+  const JsonValue& bv = views[bvi];
+  const uint32_t bi = index_or_invalid(bv, "buffer");
+  if (bi >= d.buffers.size()) fail("Buffer index out of range.");
+  const int ct = (int)num(a, "componentType", 0);
+  const JsonValue* ty = get(a, "type");
+  static const std::map<std::string, int> ncomp = {{"SCALAR", 1}, {"VEC2", 2}, {"VEC3", 3}, {"VEC4", 4}, {"MAT2", 4}, {"MAT3", 9}, {"MAT4", 16}};
+  if (!ty || !ncomp.count(ty->str)) fail("Unknown accessor type.");
+  int size = 0;
+  switch (ct) { case 5120: case 5121: size = 1; break; case 5122: case 5123: size = 2; break; case 5125: case 5126: size = 4; break; default: fail("Unknown component type."); }
+  Accessor out;
+  out.ncomp = ncomp.at(ty->str);
+  out.count = (size_t)num(a, "count", 0);
+  const size_t off = (size_t)num(bv, "byteOffset", 0) + (size_t)num(a, "byteOffset", 0);
+  size_t stride = (size_t)num(bv, "byteStride", 0);
+  if (stride == 0) stride = (size_t)size * out.ncomp;
+  const std::vector<uint8_t>& buf = d.buffers[bi];
+  if (out.count && off + (out.count - 1) * stride + (size_t)size * out.ncomp > buf.size()) fail("Accessor reads past the end of its buffer.");
+  const JsonValue* nrm = get(a, "normalized");
+  const bool normalized = nrm && nrm->kind == JsonValue::Bool && nrm->b && ct != 5126;
+  out.v.resize(out.count * out.ncomp);
+  for (size_t i = 0; i < out.count; ++i)
+    for (int c = 0; c < out.ncomp; ++c) {
+      const uint8_t* p = buf.data() + off + i * stride + (size_t)c * size;
+      double x = 0.0, mx = 1.0;
+      switch (ct) {
+        case 5120: { int8_t t; memcpy(&t, p, 1); x = t; mx = 127.0; break; }
+        case 5121: { uint8_t t; memcpy(&t, p, 1); x = t; mx = 255.0; break; }
+        case 5122: { int16_t t; memcpy(&t, p, 2); x = t; mx = 32767.0; break; }
+        case 5123: { uint16_t t; memcpy(&t, p, 2); x = t; mx = 65535.0; break; }
+        case 5125: { uint32_t t; memcpy(&t, p, 4); x = t; mx = 4294967295.0; break; }
+        default: { float t; memcpy(&t, p, 4); x = t; break; }
+      }
+      out.v[i * out.ncomp + c] = normalized ? (double)((float)x / (float)mx) : x;
+    }
+  return out;
+}
+
+// gltf::scene::Transform::matrix(): explicit matrix, or T*R*S evaluated in double and rounded once; column-major out
+void node_matrix(const JsonValue& n, float m[16]) {
+  if (const JsonValue* mv = get(n, "matrix")) {
+    for (int i = 0; i < 16; ++i) m[i] = (size_t)i < mv->items.size() ? (float)mv->items[i].num : (i % 5 == 0 ? 1.0f : 0.0f);
+    return;
+  }
+  // T * R * S from the JSON numbers themselves (double), rounded to binary32 once, like the Python mirror
+  auto dbl = [&](const char* key, int i, double dflt) { const JsonValue* v = get(n, key); return (v && (size_t)i < v->items.size()) ? v->items[i].num : dflt; };
+  const double x = dbl("rotation", 0, 0), y = dbl("rotation", 1, 0), z = dbl("rotation", 2, 0), w = dbl("rotation", 3, 1);
+  const double s[3] = {dbl("scale", 0, 1), dbl("scale", 1, 1), dbl("scale", 2, 1)};
+  const double r[3][3] = {{1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)},
+                          {2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)},
+                          {2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)}};
+  for (int c = 0; c < 3; ++c) {
+    for (int rr = 0; rr < 3; ++rr) m[4 * c + rr] = (float)(r[rr][c] * s[c]);
+    m[4 * c + 3] = 0.0f;
+  }
+  m[12] = (float)dbl("translation", 0, 0); m[13] = (float)dbl("translation", 1, 0); m[14] = (float)dbl("translation", 2, 0); m[15] = 1.0f;
+}
+
+// ---- PNG over zlib --------------------------------------------------------------------------------------------------
+uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+// decodes to RGBA8 (16-bit samples keep their high byte, like image::DynamicImage::into_rgba8's >> 8 ... rounding aside)
+bool decode_png(const std::vector<uint8_t>& raw, uint32_t* w, uint32_t* h, std::vector<uint8_t>* rgba) {
+  static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+  if (raw.size() < 33 || memcmp(raw.data(), sig, 8) != 0) return false;
+  size_t pos = 8;
+  uint32_t width = 0, height = 0;
+  int depth = 0, ctype = 0, interlace = 0;
+  std::vector<uint8_t> idat, plte, trns;
+  while (pos + 12 <= raw.size()) {
+    const uint32_t len = be32(&raw[pos]);
+    const char* type = reinterpret_cast<const char*>(&raw[pos + 4]);
+    if (pos + 12 + (size_t)len > raw.size()) return false;
+    const uint8_t* data = &raw[pos + 8];
+    if (!memcmp(type, "IHDR", 4)) { width = be32(data); height = be32(data + 4); depth = data[8]; ctype = data[9]; interlace = data[12]; }
+    else if (!memcmp(type, "PLTE", 4)) plte.assign(data, data + len);
+    else if (!memcmp(type, "tRNS", 4)) trns.assign(data, data + len);
+    else if (!memcmp(type, "IDAT", 4)) idat.insert(idat.end(), data, data + len);
+    else if (!memcmp(type, "IEND", 4)) break;
+    pos += 12 + (size_t)len;
+  }
+  if (!width || !height || interlace != 0) return false;
+  int channels = 0;
+  switch (ctype) { case 0: channels = 1; break; case 2: channels = 3; break; case 3: channels = 1; break; case 4: channels = 2; break; case 6: channels = 4; break; default: return false; }
+  if (!(depth == 8 || depth == 16 || (depth < 8 && (ctype == 0 || ctype == 3)))) return false;
+  const size_t bpp_bits = (size_t)channels * depth, row_bytes = (width * bpp_bits + 7) / 8, bpp = std::max<size_t>(1, bpp_bits / 8);
+  std::vector<uint8_t> data((row_bytes + 1) * height);
+  uLongf out_len = (uLongf)data.size();
+  if (uncompress(data.data(), &out_len, idat.data(), (uLong)idat.size()) != Z_OK || out_len != data.size()) return false;
+  std::vector<uint8_t> prev(row_bytes, 0), cur(row_bytes);
+  rgba->assign((size_t)width * height * 4, 255);
+  for (uint32_t y = 0; y < height; ++y) {
+    const uint8_t* in = &data[(row_bytes + 1) * y];
+    const int filter = in[0];
+    for (size_t i = 0; i < row_bytes; ++i) {
+      const int a = i >= bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
+      int x = in[1 + i];
+      switch (filter) {
+        case 0: break;
+        case 1: x += a; break;
+        case 2: x += b; break;
+        case 3: x += (a + b) / 2; break;
+        case 4: { const int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c); x += (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); break; }
+        default: return false;
+      }
+      cur[i] = (uint8_t)x;
+    }
+    for (uint32_t xx = 0; xx < width; ++xx) {
+      uint8_t* px = &(*rgba)[((size_t)y * width + xx) * 4];
+      auto sample = [&](int ch) -> uint32_t {  // 8-bit value of channel ch of pixel xx
+        if (depth == 8) return cur[(size_t)xx * channels + ch];
+        if (depth == 16) return cur[((size_t)xx * channels + ch) * 2];
+        const size_t bit = (size_t)xx * depth;
+        const uint32_t v = (cur[bit / 8] >> (8 - depth - (bit % 8))) & ((1u << depth) - 1u);
+        return ctype == 3 ? v : v * 255u / ((1u << depth) - 1u);
+      };
+      if (ctype == 3) {
+        const uint32_t idx = sample(0);
+        if ((size_t)idx * 3 + 2 >= plte.size()) return false;
+        px[0] = plte[idx * 3]; px[1] = plte[idx * 3 + 1]; px[2] = plte[idx * 3 + 2];
+        px[3] = idx < trns.size() ? trns[idx] : 255;
+      } else if (ctype == 0 || ctype == 4) {
+        px[0] = px[1] = px[2] = (uint8_t)sample(0);
+        px[3] = ctype == 4 ? (uint8_t)sample(1) : 255;
+      } else {
+        px[0] = (uint8_t)sample(0); px[1] = (uint8_t)sample(1); px[2] = (uint8_t)sample(2);
+        px[3] = ctype == 6 ? (uint8_t)sample(3) : 255;
+      }
+    }
+    prev.swap(cur);
+  }
+  *w = width; *h = height;
+  return true;
+}
+
+// ---- the loader (gltf_loader.rs:121-227) ----------------------------------------------------------------------------
+void load_mesh(const Doc& d, const JsonValue& mesh, hala_scene* s) {  // :232-313
+  const JsonValue* nm = get(mesh, "name");
+  const std::string name = nm ? nm->str : "<Unnamed>";
+  std::vector<hala_primitive_desc> prims;
+  for (const JsonValue& p : arr(mesh, "primitives")) {
+    const JsonValue* attr = get(p, "attributes");
+    if (!has(p, "indices")) fail("Read indices from mesh \"" + name + "\" failed.");  // :243
+    const Accessor ia = read_accessor(d, index_or_invalid(p, "indices"));
+    std::vector<uint32_t> idx(ia.v.size());
+    for (size_t i = 0; i < idx.size(); ++i) idx[i] = (uint32_t)ia.v[i];  // into_u32 :244
+    static const char* req[3][2] = {{"POSITION", "positions"}, {"NORMAL", "normals"}, {"TEXCOORD_0", "tex_coords"}};
+    for (auto& r : req)
+      if (!attr || !has(*attr, r[0])) fail(std::string("Read ") + r[1] + " from mesh \"" + name + "\" failed.");  // :246-252
+    const Accessor pos = read_accessor(d, index_or_invalid(*attr, "POSITION")), nrm = read_accessor(d, index_or_invalid(*attr, "NORMAL")),
+                   uv = read_accessor(d, index_or_invalid(*attr, "TEXCOORD_0"));
+    if (pos.ncomp != 3 || nrm.ncomp != 3 || uv.ncomp != 2 || nrm.count != pos.count || uv.count != pos.count) fail("Read positions from mesh \"" + name + "\" failed.");
+    std::vector<hala_vertex> v(pos.count);
+    for (size_t i = 0; i < pos.count; ++i) {
+      for (int c = 0; c < 3; ++c) { v[i].position[c] = (float)pos.v[3 * i + c]; v[i].normal[c] = (float)nrm.v[3 * i + c]; v[i].tangent[c] = 0.0f; }
+      v[i].tex_coord[0] = (float)uv.v[2 * i]; v[i].tex_coord[1] = (float)uv.v[2 * i + 1];
+    }
+    if (has(*attr, "TANGENT")) {  // xyz / w (:255-259)
+      const Accessor t4 = read_accessor(d, index_or_invalid(*attr, "TANGENT"));
+      if (t4.ncomp != 4 || t4.count != pos.count) fail("Read tangents from mesh \"" + name + "\" failed.");
+      for (size_t i = 0; i < pos.count; ++i)
+        for (int c = 0; c < 3; ++c) v[i].tangent[c] = (float)t4.v[4 * i + c] / (float)t4.v[4 * i + 3];
+    } else {  // per-triangle UV tangent, last writer wins (:260-286); binary32 operations in the reference's order
+      for (size_t t = 0; t + 2 < idx.size(); t += 3) {
+        const uint32_t i0 = idx[t], i1 = idx[t + 1], i2 = idx[t + 2];
+        if (i0 >= v.size() || i1 >= v.size() || i2 >= v.size()) fail("Index out of range in mesh \"" + name + "\".");
+        float dp1[3], dp2[3];
+        for (int c = 0; c < 3; ++c) { dp1[c] = v[i1].position[c] - v[i0].position[c]; dp2[c] = v[i2].position[c] - v[i0].position[c]; }
+        const float du1[2] = {v[i1].tex_coord[0] - v[i0].tex_coord[0], v[i1].tex_coord[1] - v[i0].tex_coord[1]};
+        const float du2[2] = {v[i2].tex_coord[0] - v[i0].tex_coord[0], v[i2].tex_coord[1] - v[i0].tex_coord[1]};
+        const float a = du1[0] * du2[1], b = du1[1] * du2[0];
+        const float invdet = 1.0f / (a - b);
+        float tg[3], len2 = 0.0f;
+        for (int c = 0; c < 3; ++c) { const float p = dp1[c] * du2[1], q = dp2[c] * du1[1]; tg[c] = (p - q) * invdet; }
+        for (int c = 0; c < 3; ++c) { const float sq = tg[c] * tg[c]; len2 = c == 0 ? sq : len2 + sq; }
+        const float len = std::sqrt(len2);
+        for (int c = 0; c < 3; ++c) { const float n = tg[c] / len; v[i0].tangent[c] = v[i1].tangent[c] = v[i2].tangent[c] = n; }
+      }
+    }
+    s->indices.push_back(std::move(idx));
+    s->vertices.push_back(std::move(v));
+    hala_primitive_desc pd{};
+    pd.indices = s->indices.back().data(); pd.index_count = (uint32_t)s->indices.back().size();
+    pd.vertices = s->vertices.back().data(); pd.vertex_count = (uint32_t)s->vertices.back().size();
+    pd.material_index = index_or_invalid(p, "material");  // :298
+    prims.push_back(pd);
+  }
+  s->prims.push_back(std::move(prims));
+  s->meshes.push_back(hala_mesh_desc{s->prims.back().data(), (uint32_t)s->prims.back().size()});
+}
+
+hala_material_desc load_material(const JsonValue& m) {  // :318-385 (+ _MaterialCustomInfo :63-114)
+  static const JsonValue none;
+  const JsonValue& pbr = get(m, "pbrMetallicRoughness") ? *get(m, "pbrMetallicRoughness") : none;
+  const JsonValue& ext = get(m, "extensions") ? *get(m, "extensions") : none;
+  hala_material_desc o{};
+  const float zero3[3] = {0, 0, 0}, one3[3] = {1, 1, 1}, one4[4] = {1, 1, 1, 1};
+  if (const JsonValue* ex = get(m, "extras")) {
+    if (!has(*ex, "type")) fail("Parse material extras failed.");  // `type` has no serde default (:65-66)
+    o.type = (uint32_t)num(*ex, "type", 0);
+    o.opacity = (float)num(*ex, "opacity", 1.0); o.anisotropic = (float)num(*ex, "anisotropic", 0.0); o.subsurface = (float)num(*ex, "subsurface", 0.0);
+    o.specular_tint = (float)num(*ex, "specular_tint", 0.0); o.sheen = (float)num(*ex, "sheen", 0.0); o.sheen_tint = (float)num(*ex, "sheen_tint", 0.0);
+    o.clearcoat = (float)num(*ex, "clearcoat", 0.0); o.clearcoat_roughness = (float)num(*ex, "clearcoat_roughness", 0.0);
+    floats(*ex, "clearcoat_tint", o.clearcoat_tint, 3, zero3);  // serde default [0,0,0] when extras exist (:83-84)
+    o.medium_type = (uint32_t)num(*ex, "medium_type", 0); floats(*ex, "medium_color", o.medium_color, 3, zero3);
+    o.medium_density = (float)num(*ex, "medium_density", 0.0); o.medium_anisotropy = (float)num(*ex, "medium_anisotropy", 0.0);
+  } else {  // Default impl (:95-113)
+    o.type = 0; o.opacity = 1.0f;
+    memcpy(o.clearcoat_tint, one3, 12);
+  }
+  if (o.type > 1) fail("Invalid material type.");
+  float bc[4];
+  floats(pbr, "baseColorFactor", bc, 4, one4);
+  memcpy(o.base_color, bc, 12);
+  floats(m, "emissiveFactor", o.emission, 3, zero3);
+  if (const JsonValue* es = get(ext, "KHR_materials_emissive_strength")) {  // :336-338
+    const float k = (float)num(*es, "emissiveStrength", 1.0);
+    for (float& e : o.emission) e *= k;
+  }
+  o.metallic = (float)num(pbr, "metallicFactor", 1.0); o.roughness = (float)num(pbr, "roughnessFactor", 1.0);
+  const JsonValue* tr = get(ext, "KHR_materials_transmission");
+  o.specular_transmission = tr ? (float)num(*tr, "transmissionFactor", 0.0) : 0.0f;
+  const JsonValue* ior = get(ext, "KHR_materials_ior");
+  o.ior = ior ? (float)num(*ior, "ior", 1.5) : 1.5f;  // :344
+  auto tex = [](const JsonValue& o2, const char* key) { const JsonValue* t = get(o2, key); return t ? index_or_invalid(*t, "index") : HALA_INVALID_INDEX; };  // :346-353
+  o.base_color_map_index = tex(pbr, "baseColorTexture"); o.emission_map_index = tex(m, "emissiveTexture");
+  o.normal_map_index = tex(m, "normalTexture"); o.metallic_roughness_map_index = tex(pbr, "metallicRoughnessTexture");
+  return o;
+}
+
+hala_light_desc load_light(const JsonValue& l) {  // :434-487
+  hala_light_desc o{};
+  const float one3[3] = {1, 1, 1};
+  floats(l, "color", o.color, 3, one3);
+  float intensity = (float)num(l, "intensity", 1.0), p0 = 0.0f, p1 = 0.0f;
+  const JsonValue* kind = get(l, "type");
+  const std::string k = kind ? kind->str : "";
+  uint32_t type;
+  if (k == "directional") type = 1;
+  else if (k == "point") type = 0;
+  else {
+    type = 2;
+    static const JsonValue none;
+    const JsonValue& spot = get(l, "spot") ? *get(l, "spot") : none;
+    p0 = (float)num(spot, "innerConeAngle", 0.0); p1 = (float)num(spot, "outerConeAngle", 0.78539816339744830962);
+  }
+  if (const JsonValue* ex = get(l, "extras")) {  // :449-459
+    const int t = (int)num(*ex, "type", 0);
+    if (t == 1) type = 3; else if (t == 2) type = 4;
+    p0 = (float)num(*ex, "param0", 0.0); p1 = (float)num(*ex, "param1", 0.0);
+  }
+  auto clamp90 = [](float x) { return std::min(std::max(x, 0.0f), 90.0f); };
+  if (type == 1) p0 = clamp90(p0) * (3.14159265358979323846f / 180.0f);  // f32::to_radians (:461-464)
+  else if (type == 2) {  // clamp of radians to [0, 90] is the reference's own quirk (:465-471)
+    p0 = clamp90(p0); p1 = clamp90(p1);
+    if (p0 > p1) std::swap(p0, p1);
+  } else if (type == 3) intensity = intensity / ((0.5f * p0) * p1);  // :472-476
+  o.intensity = intensity; o.light_type = type; o.param0 = p0; o.param1 = p1;
+  return o;
+}
+
+hala_camera_desc load_camera(const JsonValue& c) {  // :492-538
+  hala_camera_desc o{};
+  const JsonValue* type = get(c, "type");
+  if (type && type->str == "orthographic") {
+    static const JsonValue none;
+    const JsonValue& ob = get(c, "orthographic") ? *get(c, "orthographic") : none;
+    o.type = 1; o.xmag = (float)num(ob, "xmag", 1.0); o.ymag = (float)num(ob, "ymag", 1.0);
+    o.aspect = 1.0f; o.yfov = 0.7f; o.znear = 0.1f; o.zfar = 1000.0f; o.focal_distance = 10.0f;
+    return o;
+  }
+  static const JsonValue none;
+  const JsonValue& p = get(c, "perspective") ? *get(c, "perspective") : none;
+  o.type = 0;
+  o.aspect = (float)num(p, "aspectRatio", 1.0); o.yfov = (float)num(p, "yfov", 0.7); o.znear = (float)num(p, "znear", 0.1);
+  o.zfar = (float)num(p, "zfar", 1000.0);  // :511-514
+  const JsonValue* ex = get(c, "extras");
+  o.focal_distance = ex ? (float)num(*ex, "focal_dist", 10.0) : 10.0f;  // :38-49, :519-525
+  o.aperture = ex ? (float)num(*ex, "aperture", 0.0) : 0.0f;
+  return o;  // xmag / ymag stay 0: orthographic only
+}
+
+void load(const std::string& path, hala_scene* s) {
+  Doc d;
+  const size_t slash = path.find_last_of("/\\");
+  d.dir = slash == std::string::npos ? "" : path.substr(0, slash);
+  std::string text;
+  try {
+    const std::vector<uint8_t> raw = read_file(path);
+    text.assign(raw.begin(), raw.end());
+  } catch (const LoadError&) { fail("Load glTF file \"" + path + "\" failed."); }  // :123-124
+  if (!rt::json_parse(text.c_str(), &d.j).empty()) fail("Load glTF file \"" + path + "\" failed.");
+  try {
+    for (const JsonValue& b : arr(d.j, "buffers")) {
+      const JsonValue* uri = get(b, "uri");
+      if (!uri) fail("Buffer without a uri (GLB is not a .gltf).");
+      d.buffers.push_back(d.load_uri(uri->str));
+    }
+  } catch (const LoadError&) { fail("Load glTF file \"" + path + "\" failed."); }
+  const auto& scenes = arr(d.j, "scenes");
+  if (scenes.empty()) fail("No scene in glTF file \"" + path + "\".");  // :130
+  const auto& jnodes = arr(d.j, "nodes");
+  // BFS from the scene roots, parents before children (:134-173); the reference walks all scenes into one node list
+  for (const JsonValue& sc : scenes) {
+    std::deque<std::pair<int32_t, uint32_t>> queue;
+    for (const JsonValue& r : arr(sc, "nodes")) queue.emplace_back(-1, (uint32_t)r.num);
+    while (!queue.empty()) {
+      const auto [parent, idx] = queue.front();
+      queue.pop_front();
+      if (idx >= jnodes.size()) fail("Node index out of range.");
+      const JsonValue& n = jnodes[idx];
+      const JsonValue* nm = get(n, "name");
+      s->names.push_back(nm ? nm->str : "<Unnamed>");
+      hala_node_desc nd{};
+      nd.name = s->names.back().c_str(); nd.parent = parent;
+      node_matrix(n, nd.local_transform);
+      nd.mesh_index = index_or_invalid(n, "mesh"); nd.camera_index = index_or_invalid(n, "camera");
+      nd.light_index = HALA_INVALID_INDEX;
+      if (const JsonValue* e = get(n, "extensions")) if (const JsonValue* kl = get(*e, "KHR_lights_punctual")) nd.light_index = index_or_invalid(*kl, "light");
+      const int32_t cur = (int32_t)s->nodes.size();
+      s->nodes.push_back(nd);
+      for (const JsonValue& c : arr(n, "children")) queue.emplace_back(cur, (uint32_t)c.num);
+    }
+  }
+  for (const JsonValue& m : arr(d.j, "meshes")) load_mesh(d, m, s);
+  for (const JsonValue& m : arr(d.j, "materials")) s->materials.push_back(load_material(m));
+  uint32_t k = 0;
+  for (const JsonValue& t : arr(d.j, "textures")) s->tex2img.push_back(hala_index_pair{k++, index_or_invalid(t, "source")});  // :188-192
+  const auto& images = arr(d.j, "images");
+  for (uint32_t i = 0; i < images.size(); ++i) s->img2data.push_back(hala_index_pair{i, i});  // :193-197
+  for (const JsonValue& im : images) {  // :391-429: 8-bit RGB is padded to RGBA with alpha 255 and tagged *_SRGB
+    std::vector<uint8_t> raw;
+    if (const JsonValue* uri = get(im, "uri")) raw = d.load_uri(uri->str);
+    else {
+      const auto& views = arr(d.j, "bufferViews");
+      const uint32_t bvi = index_or_invalid(im, "bufferView");
+      if (bvi >= views.size()) fail("Image without data.");
+      const uint32_t bi = index_or_invalid(views[bvi], "buffer");
+      const size_t off = (size_t)num(views[bvi], "byteOffset", 0), len = (size_t)num(views[bvi], "byteLength", 0);
+      if (bi >= d.buffers.size() || off + len > d.buffers[bi].size()) fail("Image buffer view out of range.");
+      raw.assign(d.buffers[bi].begin() + off, d.buffers[bi].begin() + off + len);
+    }
+    uint32_t w = 0, h = 0;
+    std::vector<uint8_t> px;
+    if (!decode_png(raw, &w, &h, &px)) fail("Unsupported image format.");
+    s->pixels.push_back(std::move(px));
+    s->images.push_back(hala_image_desc{HALA_FORMAT_R8G8B8A8_SRGB, w, h, s->pixels.back().data(), s->pixels.back().size()});
+  }
+  if (const JsonValue* e = get(d.j, "extensions")) if (const JsonValue* kl = get(*e, "KHR_lights_punctual"))
+    for (const JsonValue& l : arr(*kl, "lights")) s->lights.push_back(load_light(l));
+  for (const JsonValue& c : arr(d.j, "cameras")) s->cameras.push_back(load_camera(c));
+  hala_scene_desc& o = s->desc;
+  o.nodes = s->nodes.data(); o.node_count = (uint32_t)s->nodes.size();
+  o.meshes = s->meshes.data(); o.mesh_count = (uint32_t)s->meshes.size();
+  o.materials = s->materials.data(); o.material_count = (uint32_t)s->materials.size();
+  o.lights = s->lights.data(); o.light_count = (uint32_t)s->lights.size();
+  o.cameras = s->cameras.data(); o.camera_count = (uint32_t)s->cameras.size();
+  o.texture2image_mapping = s->tex2img.data(); o.texture_count = (uint32_t)s->tex2img.size();
+  o.image2data_mapping = s->img2data.data(); o.image_count = (uint32_t)s->img2data.size();
+  o.image_data = s->images.data(); o.image_data_count = (uint32_t)s->images.size();
+}
+
+}  // namespace
+
+extern "C" {
+
+int hala_scene_load_gltf(const char* path, hala_scene** out) {
+  if (!path || !out) RT_FAIL("Invalid argument.");
+  *out = nullptr;
+  const std::string p(path);
+  const size_t slash = p.find_last_of("/\\"), dot = p.find_last_of('.');
+  if (dot == std::string::npos || (slash != std::string::npos && dot < slash)) RT_FAIL("Get file \"" + p + "\" extension failed.");  // scene.rs:43-44
+  if (p.substr(dot) != ".gltf") RT_FAIL("Unsupported file \"" + p + "\".");  // :49
+  hala_scene* s = new hala_scene();
+  try {
+    load(p, s);
+  } catch (const LoadError& e) {
+    delete s;
+    RT_FAIL(e.msg);
+  } catch (const std::exception& e) {
+    delete s;
+    RT_FAIL(std::string("Load glTF file \"") + p + "\" failed: " + e.what());
+  }
+  *out = s;
+  return HALA_OK;
+}
+const hala_scene_desc* hala_scene_get_desc(const hala_scene* s) { return s ? &s->desc : nullptr; }
+void hala_scene_free(hala_scene* s) { delete s; }
+
+}  // extern "C"

@@ -77,6 +77,9 @@ class HalaRenderer:
     # -- scene / environment ------------------------------------------------------------------------------
     def set_scene(self, scene_in_cpu):
         """src/rt_renderer.rs:1161-1178"""
+        if hasattr(scene_in_cpu, "desc_ptr"):  # a scene the library loaded itself (NativeScene: hala_scene_load_gltf)
+            self._check(self._lib.hala_rt_set_scene(self._h, scene_in_cpu.desc_ptr()))
+            return
         holder = scene_in_cpu.to_desc()
         self._check(self._lib.hala_rt_set_scene(self._h, holder.ptr()))
 

@@ -253,6 +253,15 @@ typedef struct hala_scene_desc {
   const hala_image_desc* image_data;   uint32_t image_data_count;
 } hala_scene_desc;
 
+/* cpu::HalaScene::new (src/scene/cpu/scene.rs:40-55) + HalaGltfLoader::load (src/scene/loader/gltf_loader.rs:121-227): loads
+ * a `.gltf` file (external or base64 buffers; PNG images) into an owned scene whose borrowed description is what
+ * hala_rt_set_scene takes.  Error messages are the reference's ("Unsupported file ...", "No scene in glTF file ...",
+ * "Read indices from mesh ... failed.", "Invalid material type.", "Unsupported image format.", ...). */
+typedef struct hala_scene hala_scene;
+int hala_scene_load_gltf(const char* path, hala_scene** out);
+const hala_scene_desc* hala_scene_get_desc(const hala_scene* scene);
+void hala_scene_free(hala_scene* scene);
+
 /* ------------------------------------------------------------------------------------------------
  * Errors
  * ---------------------------------------------------------------------------------------------- */

@@ -1,0 +1,132 @@
+"""CPU tier: the library's own glTF loader (csrc/gltf_loader.cpp behind hala_scene_load_gltf — the C++ restatement of
+src/scene/loader/gltf_loader.rs and cpu::HalaScene::new) against the Python mirror of the same rules
+(hala-renderer_amd/gltf_loader.py, itself tested rule by rule in test_gltf_loader.py): the two `hala_scene_desc`s must be
+identical field for field, byte for byte, and the reference's error messages must come out of the C ABI."""
+import ctypes as C
+import json
+
+import numpy as np
+import pytest
+
+import hala_renderer_amd as H
+from gltf_writer import write_gltf
+from hala_renderer_amd import scenes
+from hala_renderer_amd.native_scene import NativeScene
+from test_oracle_host import light_scene
+
+
+def _bytes(x):
+    return bytes(memoryview(x))
+
+
+def assert_same_desc(a, b):
+    """a, b: _abi.SceneDesc"""
+    assert (a.node_count, a.mesh_count, a.material_count, a.light_count, a.camera_count) == (b.node_count, b.mesh_count, b.material_count, b.light_count, b.camera_count)
+    assert (a.texture_count, a.image_count, a.image_data_count) == (b.texture_count, b.image_count, b.image_data_count)
+    for i in range(a.node_count):
+        x, y = a.nodes[i], b.nodes[i]
+        assert (x.name, x.parent, x.mesh_index, x.camera_index, x.light_index) == (y.name, y.parent, y.mesh_index, y.camera_index, y.light_index)
+        assert _bytes(x.local_transform) == _bytes(y.local_transform), f"node {i} transform"
+    for i in range(a.mesh_count):
+        assert a.meshes[i].primitive_count == b.meshes[i].primitive_count
+        for k in range(a.meshes[i].primitive_count):
+            p, q = a.meshes[i].primitives[k], b.meshes[i].primitives[k]
+            assert (p.index_count, p.vertex_count, p.material_index) == (q.index_count, q.vertex_count, q.material_index)
+            assert C.string_at(p.indices, p.index_count * 4) == C.string_at(q.indices, q.index_count * 4)
+            assert C.string_at(p.vertices, p.vertex_count * 44) == C.string_at(q.vertices, q.vertex_count * 44), f"mesh {i} primitive {k} vertices"
+    for i in range(a.material_count):
+        assert _bytes(a.materials[i]) == _bytes(b.materials[i]), f"material {i}"
+    for i in range(a.light_count):
+        assert _bytes(a.lights[i]) == _bytes(b.lights[i]), f"light {i}"
+    for i in range(a.camera_count):
+        x, y = a.cameras[i], b.cameras[i]
+        assert x.type == y.type
+        if x.type == 0:
+            assert _bytes(x) == _bytes(y), f"camera {i}"
+        else:
+            assert (x.xmag, x.ymag) == (y.xmag, y.ymag)
+    for i in range(a.texture_count):
+        assert _bytes(a.texture2image_mapping[i]) == _bytes(b.texture2image_mapping[i])
+    for i in range(a.image_count):
+        assert _bytes(a.image2data_mapping[i]) == _bytes(b.image2data_mapping[i])
+    for i in range(a.image_data_count):
+        x, y = a.image_data[i], b.image_data[i]
+        assert (x.format, x.width, x.height, x.num_of_bytes) == (y.format, y.width, y.height, y.num_of_bytes)
+        assert C.string_at(x.data, x.num_of_bytes) == C.string_at(y.data, y.num_of_bytes), f"image {i}"
+
+
+def both(scene, tmp_path, **kw):
+    p = tmp_path / "scene.gltf"
+    write_gltf(scene, str(p), **kw)
+    py = H.HalaScene.new(str(p)).to_desc()
+    nat = NativeScene(str(p))
+    return py, nat
+
+
+@pytest.mark.parametrize("with_tangents", [True, False])
+def test_cornell_matches_python_mirror(tmp_path, with_tangents):
+    py, nat = both(scenes.cornell_box(), tmp_path, with_tangents=with_tangents)  # False: per-triangle UV tangents (:260-286)
+    assert_same_desc(nat.desc, py.desc)
+    nat.close()
+
+
+def test_instanced_scene_lights_and_textures_match(tmp_path):
+    s = scenes.sponza_class(target_triangles=3000)
+    scenes.attach_textures(s, sets=2, size=16)  # PNG data URIs (RGBA8)
+    py, nat = both(s, tmp_path)
+    assert_same_desc(nat.desc, py.desc)
+    nat.close()
+    py, nat = both(light_scene(), tmp_path)  # every light type incl. the quad / sphere `extras` convention and the spot clamp quirk
+    assert_same_desc(nat.desc, py.desc)
+    nat.close()
+
+
+def test_error_messages_are_the_references(tmp_path):
+    with pytest.raises(H.HalaRendererError, match="Unsupported file"):  # cpu/scene.rs:49
+        NativeScene(str(tmp_path / "scene.glb"))
+    with pytest.raises(H.HalaRendererError, match="extension failed"):  # :43-44
+        NativeScene(str(tmp_path / "scene"))
+    with pytest.raises(H.HalaRendererError, match="Load glTF file .* failed"):  # gltf_loader.rs:123-124
+        NativeScene(str(tmp_path / "missing.gltf"))
+    p = tmp_path / "scene.gltf"
+    write_gltf(scenes.cornell_box(), str(p))
+    doc = json.load(open(p))
+    bad = dict(doc); bad["scenes"] = []
+    json.dump(bad, open(tmp_path / "noscene.gltf", "w"))
+    with pytest.raises(H.HalaRendererError, match="No scene in glTF file"):  # :130
+        NativeScene(str(tmp_path / "noscene.gltf"))
+    bad = json.loads(json.dumps(doc)); del bad["meshes"][0]["primitives"][0]["attributes"]["NORMAL"]
+    json.dump(bad, open(tmp_path / "nonormal.gltf", "w"))
+    with pytest.raises(H.HalaRendererError, match="Read normals from mesh"):  # :246-252
+        NativeScene(str(tmp_path / "nonormal.gltf"))
+    bad = json.loads(json.dumps(doc)); bad["materials"][0]["extras"] = {"opacity": 0.5}
+    json.dump(bad, open(tmp_path / "notype.gltf", "w"))
+    with pytest.raises(H.HalaRendererError, match="Parse material extras failed"):  # :65-66, :324-325
+        NativeScene(str(tmp_path / "notype.gltf"))
+    bad = json.loads(json.dumps(doc)); bad["materials"][0]["extras"] = {"type": 5}
+    json.dump(bad, open(tmp_path / "badtype.gltf", "w"))
+    with pytest.raises(H.HalaRendererError, match="Invalid material type"):
+        NativeScene(str(tmp_path / "badtype.gltf"))
+    bad = json.loads(json.dumps(doc)); bad["images"] = [{"uri": "data:image/jpeg;base64,/9j/4AAQSkZJRgABAQ=="}]
+    json.dump(bad, open(tmp_path / "jpeg.gltf", "w"))
+    with pytest.raises(H.HalaRendererError, match="Unsupported image format"):  # image_data / gltf_loader.rs:424-427
+        NativeScene(str(tmp_path / "jpeg.gltf"))
+
+
+@pytest.mark.gpu
+def test_native_scene_renders_like_the_python_one(halart, oracle, tmp_path):
+    s = scenes.cornell_box()
+    p = tmp_path / "scene.gltf"
+    write_gltf(s, str(p))
+    nat = NativeScene(str(p))
+    r = halart.HalaRenderer("gltf-native", 48, 48, 4, 2, False, False, False, 0)
+    r.set_scene(nat)
+    r.commit()
+    r.update(); r.render()
+    q = halart.HalaRenderer("gltf-python", 48, 48, 4, 2, False, False, False, 0)
+    q.set_scene(H.HalaScene.new(str(p)))
+    q.commit()
+    q.update(); q.render()
+    assert r.read_image(0).tobytes() == q.read_image(0).tobytes()
+    assert float(r.read_image(0)[..., :3].mean()) > 0.01
+    r.close(); q.close(); nat.close()
