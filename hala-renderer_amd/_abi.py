@@ -192,5 +192,5 @@ EXPORTS = [
     "hala_rt_trace_rays_host", "hala_rt_trace_rays_indirect", "hala_rt_get_bvh_info", "hala_rt_download_bvh",
     "hala_rt_update_node_transform", "hala_rt_refit", "hala_envmap_build_distribution",
     "hala_tonemap_pixels", "hala_write_pfm", "hala_rtprog_parse_desc", "hala_version",
-    "hala_scene_load_gltf", "hala_scene_get_desc", "hala_scene_free",
+    "hala_scene_load_gltf", "hala_scene_get_desc", "hala_scene_free", "hala_load_float_image",
 ]

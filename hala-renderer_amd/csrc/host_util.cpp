@@ -1,6 +1,8 @@
 // host_util.cpp — error channel, JSON reader, and the host half of save_images / set_envmap:
 // tonemap operators and PFM writer (src/rt_renderer.rs:1256-1334), Radiance .hdr / .pfm decoding for
 // EnvMap::new_with_file (src/envmap.rs:48-60; the reference decodes through the `image` crate).
+#include <zlib.h>
+
 #include "host_util.h"
 
 #include <cmath>
@@ -270,15 +272,144 @@ static std::string load_hdr(FILE* f, HostImage* img) {
   return "";
 }
 
+// ---- OpenEXR, scanline images (the `image` crate's "exr" feature, Cargo.toml:21): compression NONE / RLE / ZIPS / ZIP,
+// HALF / FLOAT / UINT samples, channels R G B [A] or Y; tiled, deep, multi-part and PIZ/PXR24/B44/DWA files are refused ----
+static float half_to_float(uint16_t h) {
+  const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, exp = (h >> 10) & 0x1fu, man = h & 0x3ffu;
+  uint32_t bits;
+  if (exp == 0) {
+    if (man == 0) bits = sign;
+    else {  // subnormal: normalise
+      int e = -1; uint32_t m = man;
+      do { ++e; m <<= 1; } while (!(m & 0x400u));
+      bits = sign | ((uint32_t)(127 - 15 - e) << 23) | ((m & 0x3ffu) << 13);
+    }
+  } else if (exp == 31) bits = sign | 0x7f800000u | (man << 13);
+  else bits = sign | ((exp + 127 - 15) << 23) | (man << 13);
+  float f; memcpy(&f, &bits, 4);
+  return f;
+}
+static std::string load_exr(FILE* f, HostImage* img) {
+  std::vector<unsigned char> d;
+  { unsigned char buf[65536]; size_t n; while ((n = fread(buf, 1, sizeof(buf), f)) > 0) d.insert(d.end(), buf, buf + n); }
+  size_t p = 0;
+  auto need = [&](size_t n) { return p + n <= d.size(); };
+  auto rd32 = [&](size_t at) { uint32_t v; memcpy(&v, &d[at], 4); return v; };
+  if (!need(8) || rd32(0) != 20000630u) return "not an OpenEXR file";
+  const uint32_t version = rd32(4);
+  if ((version & 0xffu) != 2u || (version & 0x1a00u)) return "tiled, deep and multi-part OpenEXR files are not supported";
+  p = 8;
+  struct Chan { std::string name; int type; };
+  std::vector<Chan> chans;
+  int compression = -1, line_order = 0;
+  int32_t win[4] = {0, 0, -1, -1};
+  for (;;) {  // attributes: name\0 type\0 size value
+    if (!need(1)) return "truncated header";
+    if (d[p] == 0) { ++p; break; }
+    std::string name, type;
+    while (need(1) && d[p]) name += (char)d[p++];
+    ++p;
+    while (need(1) && d[p]) type += (char)d[p++];
+    ++p;
+    if (!need(4)) return "truncated header";
+    const uint32_t size = rd32(p); p += 4;
+    if (!need(size)) return "truncated header";
+    if (name == "channels") {
+      size_t q = p;
+      while (q < p + size && d[q]) {
+        Chan c;
+        while (q < p + size && d[q]) c.name += (char)d[q++];
+        ++q;
+        if (q + 16 > p + size) return "bad channel list";
+        c.type = (int)rd32(q);
+        if (rd32(q + 8) != 1u || rd32(q + 12) != 1u) return "subsampled channels are not supported";
+        q += 16;
+        chans.push_back(c);
+      }
+    } else if (name == "compression" && size >= 1) compression = d[p];
+    else if (name == "dataWindow" && size >= 16) memcpy(win, &d[p], 16);
+    else if (name == "lineOrder" && size >= 1) line_order = d[p];
+    p += size;
+  }
+  if (chans.empty() || win[2] < win[0] || win[3] < win[1]) return "missing channels or data window";
+  if (compression < 0 || compression > 3) return "only NONE / RLE / ZIPS / ZIP compressed OpenEXR files are supported";
+  (void)line_order;  // chunks carry their own y; the offset table is not needed
+  const uint32_t W = (uint32_t)(win[2] - win[0] + 1), H = (uint32_t)(win[3] - win[1] + 1);
+  int ci[4] = {-1, -1, -1, -1};  // R G B A
+  size_t line_bytes = 0;
+  std::vector<size_t> chan_off(chans.size());
+  for (size_t k = 0; k < chans.size(); ++k) {
+    chan_off[k] = line_bytes;
+    if (chans[k].type < 0 || chans[k].type > 2) return "bad pixel type";
+    line_bytes += (size_t)W * (chans[k].type == 1 ? 2 : 4);
+    if (chans[k].name == "R") ci[0] = (int)k; else if (chans[k].name == "G") ci[1] = (int)k;
+    else if (chans[k].name == "B") ci[2] = (int)k; else if (chans[k].name == "A") ci[3] = (int)k;
+    else if (chans[k].name == "Y" && ci[0] < 0) ci[0] = ci[1] = ci[2] = (int)k;
+  }
+  if (ci[0] < 0 || ci[1] < 0 || ci[2] < 0) return "no R, G, B (or Y) channels";
+  const uint32_t block = compression == 3 ? 16u : 1u, chunks = (H + block - 1) / block;
+  p += (size_t)chunks * 8;  // offset table
+  img->width = W; img->height = H; img->channels = ci[3] >= 0 ? 4 : 3;
+  img->pixels.assign((size_t)W * H * img->channels, 0.0f);
+  std::vector<unsigned char> raw, tmp;
+  for (uint32_t c = 0; c < chunks; ++c) {
+    if (!need(8)) return "truncated pixel data";
+    int32_t y0; memcpy(&y0, &d[p], 4);
+    const uint32_t size = rd32(p + 4);
+    p += 8;
+    if (!need(size) || y0 < win[1] || y0 > win[3]) return "bad chunk";
+    const uint32_t lines = std::min<uint32_t>(block, (uint32_t)(win[3] - y0 + 1));
+    const size_t want = line_bytes * lines;
+    if (compression == 0 || size == want) raw.assign(d.begin() + p, d.begin() + p + size);
+    else {
+      tmp.resize(want);
+      if (compression == 1) {  // RLE
+        size_t o = 0, q = p;
+        while (q < p + size && o < want) {
+          const int n = (signed char)d[q++];
+          if (n < 0) { const size_t k = (size_t)(-n); if (q + k > p + size || o + k > want) return "bad RLE data"; memcpy(&tmp[o], &d[q], k); q += k; o += k; }
+          else { const size_t k = (size_t)n + 1; if (q >= p + size || o + k > want) return "bad RLE data"; memset(&tmp[o], d[q++], k); o += k; }
+        }
+        if (o != want) return "bad RLE data";
+      } else {
+        uLongf out_len = (uLongf)want;
+        if (uncompress(tmp.data(), &out_len, &d[p], size) != Z_OK || out_len != want) return "bad ZIP data";
+      }
+      for (size_t i = 1; i < want; ++i) tmp[i] = (unsigned char)(tmp[i - 1] + tmp[i] - 128);  // predictor
+      raw.resize(want);
+      const size_t half = (want + 1) / 2;
+      for (size_t i = 0; i < want; ++i) raw[i] = (i & 1) ? tmp[half + i / 2] : tmp[i / 2];  // de-interleave
+    }
+    if (raw.size() != want) return "bad chunk size";
+    p += size;
+    for (uint32_t l = 0; l < lines; ++l) {
+      const uint32_t row = (uint32_t)(y0 - win[1]) + l;
+      for (uint32_t ch = 0; ch < img->channels; ++ch) {
+        const int k = ci[ch];
+        const unsigned char* src = &raw[line_bytes * l + chan_off[k]];
+        for (uint32_t x = 0; x < W; ++x) {
+          float v;
+          if (chans[k].type == 1) { uint16_t h; memcpy(&h, src + 2 * (size_t)x, 2); v = half_to_float(h); }
+          else if (chans[k].type == 2) memcpy(&v, src + 4 * (size_t)x, 4);
+          else { uint32_t u; memcpy(&u, src + 4 * (size_t)x, 4); v = (float)u; }
+          img->pixels[((size_t)row * W + x) * img->channels + ch] = v;
+        }
+      }
+    }
+  }
+  return "";
+}
+
 std::string load_float_image(const char* path, HostImage* img) {
   FILE* f = fopen(path, "rb");
   if (!f) return std::string("Failed to open image \"") + path + "\".";  // src/envmap.rs:49
-  unsigned char magic[2] = {0, 0};
-  const size_t got = fread(magic, 1, 2, f);
+  unsigned char magic[4] = {0, 0, 0, 0};
+  const size_t got = fread(magic, 1, 4, f);
   rewind(f);
   std::string e;
-  if (got == 2 && magic[0] == 'P' && (magic[1] == 'F' || magic[1] == 'f')) e = load_pfm(f, img);
-  else if (got == 2 && magic[0] == '#' && magic[1] == '?') e = load_hdr(f, img);
+  if (got >= 2 && magic[0] == 'P' && (magic[1] == 'F' || magic[1] == 'f')) e = load_pfm(f, img);
+  else if (got >= 2 && magic[0] == '#' && magic[1] == '?') e = load_hdr(f, img);
+  else if (got == 4 && magic[0] == 0x76 && magic[1] == 0x2f && magic[2] == 0x31 && magic[3] == 0x01) e = load_exr(f, img);
   else e = "unrecognised format";
   fclose(f);
   if (!e.empty()) return std::string("Failed to decode image \"") + path + "\". (" + e + ")";  // src/envmap.rs:53

@@ -983,6 +983,19 @@ int hala_write_pfm(const char* path, const float* rgba32f, uint32_t width, uint3
   return HALA_OK;
 }
 
+int hala_load_float_image(const char* path, uint32_t* width, uint32_t* height, uint32_t* channels, float* dst, size_t capacity_floats) {
+  if (!path || !width || !height || !channels) RT_FAIL("Invalid argument.");
+  HostImage img;
+  const std::string e = load_float_image(path, &img);
+  if (!e.empty()) RT_FAIL(e);
+  *width = img.width; *height = img.height; *channels = img.channels;
+  if (dst) {
+    if (capacity_floats < img.pixels.size()) RT_FAIL("The destination buffer is too small.");
+    memcpy(dst, img.pixels.data(), img.pixels.size() * sizeof(float));
+  }
+  return HALA_OK;
+}
+
 int hala_rtprog_parse_desc(const char* desc_json, hala_rtprog_desc_info* out) {
   // serde field names and defaults of HalaRayTracingProgramDesc (src/raytracing_program.rs:33-55)
   if (!desc_json || !out) RT_FAIL("Invalid argument.");

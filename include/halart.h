@@ -308,7 +308,8 @@ int hala_rt_set_scene(hala_rt_renderer* r, const hala_scene_desc* scene);
 /* set_envmap (src/rt_renderer.rs:1184-1195) -> EnvMap::new_with_file (src/envmap.rs:38-232).
  * _pixels takes the already decoded image (RGB or RGBA f32, row 0 = top) and applies the same
  * validation (NaN/Inf rejection :63-71), alpha := 1 repack (:72-89) and table build (:239-388);
- * _file decodes Radiance .hdr (RGBE) or .pfm itself and honours ./out/<stem>.dist_cache (:90-142). */
+ * _file decodes Radiance .hdr (RGBE), .pfm or scanline OpenEXR (NONE / RLE / ZIPS / ZIP; half, float) itself and honours
+ * ./out/<stem>.dist_cache (:90-142). */
 int hala_rt_set_envmap_pixels(hala_rt_renderer* r, const float* pixels, uint32_t channels,
                               uint32_t width, uint32_t height, float rotation_degrees);
 int hala_rt_set_envmap_file(hala_rt_renderer* r, const char* path, float rotation_degrees);
@@ -482,6 +483,11 @@ int hala_envmap_build_distribution(int device_ordinal, const float* rgba32f, uin
 /* save_images' host tonemap (src/rt_renderer.rs:1256-1316) applied in place to RGBA32F pixels. */
 void hala_tonemap_pixels(float* rgba32f, size_t pixel_count, int enable_tonemap, int enable_aces,
                          int use_simple_aces);
+/* The decoder behind hala_rt_set_envmap_file (`image::open(path)` of src/envmap.rs:48-53 for the float formats): fills
+ * width / height / channels (3 or 4); copies the row-0-is-top float pixels into dst when dst != NULL and capacity_floats
+ * is large enough.  No GPU involved. */
+int hala_load_float_image(const char* path, uint32_t* width, uint32_t* height, uint32_t* channels, float* dst,
+                          size_t capacity_floats);
 /* save_images' PFM writer (src/rt_renderer.rs:1318-1334). */
 int hala_write_pfm(const char* path, const float* rgba32f, uint32_t width, uint32_t height);
 

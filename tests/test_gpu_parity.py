@@ -682,3 +682,20 @@ def test_headline_config_full_resolution_bit_exact(halart, oracle):
     assert (stg.rays_closest_total, stg.rays_shadow_total) == (st.rays_closest, st.rays_shadow)
     assert stg.rays_primary_total == 2 * 1920 * 1080
     r.close()
+
+
+def test_envmap_from_openexr_file(halart, oracle, tmp_path, monkeypatch):
+    """set_envmap(path) with a ZIP-compressed half-float OpenEXR (the `exr` feature of the reference's image crate): the tables
+    built from the decoded pixels equal the oracle's tables of the same (half-rounded) pixels"""
+    from test_image_decoders import write_exr
+    env = scenes.sky_sun_envmap(64, 32)[..., :3].astype(np.float16).astype(f32)
+    monkeypatch.chdir(tmp_path)
+    os.makedirs("out")  # the reference writes ./out/<stem>.dist_cache next to the process (src/envmap.rs:90-142)
+    write_exr("sky.exr", env, "zip", True)
+    r = halart.HalaRenderer("envexr", 16, 16, 2, 1, False, False, False, 0)
+    r.set_envmap("sky.exr", 0.0)
+    t, m, c = r.env_distribution(64, 32)
+    rgba = np.concatenate([env, np.ones((32, 64, 1), f32)], axis=-1)
+    ot, om, oc = oracle.envmap_build_distribution(rgba)
+    assert f32(t).tobytes() == ot.tobytes() and m.tobytes() == om.tobytes() and c.tobytes() == oc.tobytes()
+    r.close()
