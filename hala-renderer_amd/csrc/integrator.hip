@@ -396,6 +396,16 @@ __global__ void __launch_bounds__(kShadeThreads, RT_SHADE_WAVES) k_shade(FrameCo
         ps.albedo[slot] = make_float4(sf.mat.base.x, sf.mat.base.y, sf.mat.base.z, 1.0f);
         ps.normal[slot] = make_float4(sf.ns.x, sf.ns.y, sf.ns.z, 1.0f);
       }
+      // §7.1e: what the medium of an object just crossed did to the segment that ends here (identity for every other hit)
+      if (sf.glow.x > 0.0f || sf.glow.y > 0.0f || sf.glow.z > 0.0f) {
+        const f3 g = T * sf.glow;
+        if (PRIMARY) L = L + g;
+        else {  // a second term may follow in this bounce (emission): this one goes to the path's radiance right away, in order
+          const float4 l = ps.radiance[slot];
+          ps.radiance[slot] = make_float4(l.x + g.x, l.y + g.y, l.z + g.z, 0.0f);
+        }
+      }
+      T = T * sf.absorb;
       bool through = false;
       if (sf.mat.opacity < 1.0f) {  // §7.1d: the surface is skipped with probability 1 - opacity (one extra random number)
         const float ro = rng_next(rng);

@@ -82,6 +82,25 @@ RT_DI void sincos_2pi(float u, float* s, float* c) {
   *s = q == 0 ? sa : (q == 1 ? ca : (q == 2 ? -sa : -ca));
   *c = q == 0 ? ca : (q == 1 ? -sa : (q == 2 ? -ca : sa));
 }
+// e^x for x <= 0 (RENDER_SPEC §2.2): 2^(x log2 e) = 2^n 2^f, n = floor, f in [0,1); 2^f = e^(f ln 2) by its Taylor polynomial
+// to the 8th power (relative error < 3e-8 before rounding); the scale by 2^n is exact.  Arguments >= 0 (and NaN) give 1.
+RT_DI float exp_neg_poly(float x) {
+  if (!(x < 0.0f)) return 1.0f;
+  float y = x * 1.44269504088896340736f;
+  if (y < -126.0f) return 0.0f;
+  float n = floorf(y);
+  float g = (y - n) * 0.69314718055994530942f;
+  float p = 2.48015873015873015873e-5f;
+  p = __fmaf_rn(p, g, 1.98412698412698412698e-4f);
+  p = __fmaf_rn(p, g, 1.38888888888888888889e-3f);
+  p = __fmaf_rn(p, g, 8.33333333333333333333e-3f);
+  p = __fmaf_rn(p, g, 4.16666666666666666667e-2f);
+  p = __fmaf_rn(p, g, 1.66666666666666666667e-1f);
+  p = __fmaf_rn(p, g, 0.5f);
+  p = __fmaf_rn(p, g, 1.0f);
+  p = __fmaf_rn(p, g, 1.0f);
+  return p * __uint_as_float((uint32_t)((int)n + 127) << 23);
+}
 RT_DI float acos_poly(float x) {
   float ax = fabsf(x);
   if (ax > 1.0f) ax = 1.0f;

@@ -421,7 +421,7 @@ static float intersect_light(const orc_gpu_light& l, V3 o, V3 d, float* pdf) {
 }
 
 // ---- RENDER_SPEC §6 surface reconstruction ----------------------------------------------------------------------
-struct Surface { V3 P, ns, ng; orc_gpu_material m; V3 base; Trans tr; float opacity; };  // opacity: §7.1d, material x base-colour-map alpha  // m: the packed material after texture modulation
+struct Surface { V3 P, ns, ng; orc_gpu_material m; V3 base; Trans tr; float opacity; V3 absorb, glow; };  // absorb / glow: §7.1e  // opacity: §7.1d, material x base-colour-map alpha  // m: the packed material after texture modulation
 
 static inline V3 transform_normal(const float* m, V3 n) {
   // inverse-transpose of the upper 3x3 = cofactor matrix / det; columns c0,c1,c2 of M
@@ -556,9 +556,17 @@ static Surface make_surface(const orc_scene* s, float pixel_spread, V3 o, V3 d, 
   sf.tr.trans = 0.0f; sf.tr.eta = sf.m.ior;
   if (sf.m.type == 1u) sf.tr.trans = sf.m.specular_transmission * (1.0f - sf.m.metallic);  // after the metallic map
   if (dot3(sf.ns, sf.ng) < 0.0f) sf.ng = -sf.ng;
+  sf.absorb = v3s(1.0f); sf.glow = v3s(0.0f);
   if (dot3(sf.ng, d) > 0.0f) {  // the path arrives from behind the surface: it is leaving the object
     sf.ns = -sf.ns; sf.ng = -sf.ng;
     sf.tr.eta = 1.0f / sf.m.ior;
+    const orc_gpu_material& pm = s->materials[inst.material_index];  // §7.1e: the medium of the object just crossed
+    float dt = pm.medium_density * h.t;
+    if (pm.medium_type == 1u)
+      sf.absorb = v3(exp_neg_poly(-(dt * (1.0f - pm.medium_color[0]))), exp_neg_poly(-(dt * (1.0f - pm.medium_color[1]))),
+                     exp_neg_poly(-(dt * (1.0f - pm.medium_color[2]))));
+    else if (pm.medium_type == 3u)
+      sf.glow = v3(pm.medium_color[0] * dt, pm.medium_color[1] * dt, pm.medium_color[2] * dt);
   }
   return sf;
 }
@@ -584,7 +592,7 @@ static PixelOut trace_path(const Frame& f, uint32_t px, uint32_t py, uint32_t fr
     // hittable analytic lights
     int hit_light = -1; float t_light = t_surf, light_pdf = 0.0f;
     for (uint32_t i = 0; i < nl; ++i) {
-      float lp;
+      float lp = 0.0f;
       float tl = intersect_light(s->lights[i], o, d, &lp);
       if (tl > 0.0f && tl < t_light) { t_light = tl; hit_light = (int)i; light_pdf = lp; }
     }
@@ -608,6 +616,8 @@ static PixelOut trace_path(const Frame& f, uint32_t px, uint32_t py, uint32_t fr
     }
     Surface sf = make_surface(s, f.pixel_spread, o, d, h);
     if (depth == 0) { out.albedo = sf.base; out.normal = sf.ns; }
+    if (sf.glow.x > 0.0f || sf.glow.y > 0.0f || sf.glow.z > 0.0f) L = L + T * sf.glow;  // §7.1e, before the absorption of the same segment... (only one of the two is ever set)
+    T = T * sf.absorb;
     if (sf.opacity < 1.0f) {  // §7.1d: the surface is skipped with probability 1 - opacity (one extra random number, drawn only here)
       float ro = rng_next(&rng);
       if (!(ro < sf.opacity)) { o = madd3(sf.ng, -s->ray_eps, sf.P); continue; }

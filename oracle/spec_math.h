@@ -94,6 +94,28 @@ static inline void sincos_rad(float a, float* s, float* c) {
   if (t >= 1.0f) t = 0.0f;
   sincos_2pi(t, s, c);
 }
+// e^x for x <= 0: 2^(x log2 e) = 2^n 2^f, n = floor, f in [0,1); 2^f = e^(f ln 2) by its Taylor polynomial to the 8th power;
+// the scale by 2^n is exact.  Arguments >= 0 (and NaN) give 1.
+static inline float exp_neg_poly(float x) {
+  if (!(x < 0.0f)) return 1.0f;
+  float y = x * 1.44269504088896340736f;
+  if (y < -126.0f) return 0.0f;
+  float n = floorf(y);
+  float g = (y - n) * 0.69314718055994530942f;
+  float p = 2.48015873015873015873e-5f;
+  p = fmaf(p, g, 1.98412698412698412698e-4f);
+  p = fmaf(p, g, 1.38888888888888888889e-3f);
+  p = fmaf(p, g, 8.33333333333333333333e-3f);
+  p = fmaf(p, g, 4.16666666666666666667e-2f);
+  p = fmaf(p, g, 1.66666666666666666667e-1f);
+  p = fmaf(p, g, 0.5f);
+  p = fmaf(p, g, 1.0f);
+  p = fmaf(p, g, 1.0f);
+  uint32_t bits = (uint32_t)((int)n + 127) << 23;
+  float scale;
+  memcpy(&scale, &bits, 4);
+  return p * scale;
+}
 // acos on [-1,1], Abramowitz & Stegun 4.4.46 (|err| <= 2e-8 before rounding)
 static inline float acos_poly(float x) {
   float ax = fabsf(x);

@@ -289,3 +289,9 @@ def probe_rng(pixel_id, frame_index, n):
     o = np.empty(n, dtype=np.float32)
     lib().orc_probe_rng(C.c_uint32(pixel_id), C.c_uint32(frame_index), fptr(o), C.c_size_t(n))
     return o
+
+
+def probe_exp_neg(x):
+    x = np.ascontiguousarray(x, dtype=np.float32); o = np.empty_like(x)
+    lib().orc_probe_exp_neg(fptr(x), fptr(o), C.c_size_t(x.size))
+    return o

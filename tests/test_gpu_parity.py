@@ -699,3 +699,22 @@ def test_envmap_from_openexr_file(halart, oracle, tmp_path, monkeypatch):
     ot, om, oc = oracle.envmap_build_distribution(rgba)
     assert f32(t).tobytes() == ot.tobytes() and m.tobytes() == om.tobytes() and c.tobytes() == oc.tobytes()
     r.close()
+
+
+@pytest.mark.parametrize("medium", ["absorb", "emissive"])
+def test_render_media_bit_exact(halart, oracle, medium):
+    """RENDER_SPEC §7.1e: Beer-Lambert absorption / emission along the segment inside a glass object (polynomial exp, same bits)"""
+    env = scenes.sky_sun_envmap(64, 32, sun_gain=100.0)
+    s = scenes.bunny_class(subdivisions=3, aspect=80 / 48, disney=True)
+    med = H.HalaMedium(1, (0.9, 0.4, 0.2), 2.5, 0.0) if medium == "absorb" else H.HalaMedium(3, (0.2, 0.5, 1.0), 0.8, 0.0)
+    s.materials[0] = H.HalaMaterial(type=1, base_color=(1.0, 1.0, 1.0), metallic=0.0, roughness=0.15, specular_transmission=1.0, ior=1.45,
+                                    emission=(0.05, 0.0, 0.0) if medium == "emissive" else (0.0, 0.0, 0.0), medium=med)
+    r = make_renderer(halart, s, 80, 48, max_depth=8, rr_depth=3, env=env)
+    for _ in range(3):
+        r.update(); r.render()
+    imgs, st = oracle.OracleScene(s, envmap=env).render(80, 48, frames=3, max_depth=8, rr_depth=3)
+    assert_images_equal(r, imgs)
+    s.materials[0].medium = H.HalaMedium()
+    plain, _ = oracle.OracleScene(s, envmap=env).render(80, 48, frames=3, max_depth=8, rr_depth=3)
+    assert np.abs(plain[0][16:32, 30:50, :3] - imgs[0][16:32, 30:50, :3]).mean() > 0.005
+    r.close()

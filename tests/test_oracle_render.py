@@ -309,3 +309,28 @@ def test_bvh4_traversal_and_validation_on_the_oracles_own_tree(oracle, name):
     bad = nodes.copy()
     bad[0, 7] = 0  # qhi.x of all four children of the root
     assert oracle.validate_bvh(bad, tris, None)[0] != 0
+
+
+def test_exp_neg_poly_accuracy(oracle):
+    """RENDER_SPEC §7.1e: the exponential the absorbing media use — no libm, same bits on CPU and GPU by construction"""
+    x = -np.concatenate([np.linspace(0, 20, 100001), np.logspace(-8, 2, 2001)]).astype(f32)
+    got = oracle.probe_exp_neg(x)
+    want = np.exp(x.astype(np.float64))
+    ok = want > 1e-37
+    assert np.max(np.abs(got[ok] - want[ok]) / want[ok]) < 4e-6
+    assert oracle.probe_exp_neg(np.array([0.0, 1.0, -1e9], dtype=f32)).tolist() == [1.0, 1.0, 0.0]
+    assert np.all(np.diff(got[:100001]) <= 0)  # monotone along the sweep
+
+
+def test_absorbing_glass_tints_with_thickness(oracle):
+    """white glass sphere with a red-absorbing medium in a white furnace: what comes through the thick centre is darker and more
+    saturated than the rim, channels the medium does not absorb pass as through clear glass"""
+    s = furnace_scene()
+    kw = dict(type=1, base_color=(1.0, 1.0, 1.0), metallic=0.0, roughness=0.05, specular_transmission=1.0, ior=1.3)
+    s.materials = [H.HalaMaterial(**kw)]
+    clear = oracle.OracleScene(s).render(32, 32, frames=96, max_depth=10, rr_depth=64, ground=(0.7,) * 3 + (1,), sky=(0.7,) * 3 + (1,))[0][0]
+    s.materials = [H.HalaMaterial(medium=H.HalaMedium(1, (1.0, 0.3, 0.3), 1.2, 0.0), **kw)]
+    tinted = oracle.OracleScene(s).render(32, 32, frames=96, max_depth=10, rr_depth=64, ground=(0.7,) * 3 + (1,), sky=(0.7,) * 3 + (1,))[0][0]
+    c, t = clear[12:20, 12:20, :3].mean(axis=(0, 1)), tinted[12:20, 12:20, :3].mean(axis=(0, 1))
+    assert abs(t[0] - c[0]) < 0.03 * c[0]          # red passes untouched (sigma_r = 0)
+    assert t[1] < 0.6 * c[1] and t[2] < 0.6 * c[2]  # green and blue are absorbed over ~2 radii
