@@ -55,6 +55,7 @@ pub mod sys {
   #[repr(C)] #[derive(Clone, Copy)] pub struct hala_hit { pub t: f32, pub u: f32, pub v: f32, pub prim: u32 }
   #[repr(C)] #[derive(Default)] pub struct hala_rt_info { pub width: u32, pub height: u32 }
 
+  #[repr(C)] pub struct hala_scene { _private: [u8; 0] }
   extern "C" {
     pub fn hala_last_error_message() -> *const c_char;
     pub fn hala_rt_create(name: *const c_char, width: u32, height: u32, device_ordinal: c_int, max_depth: u32, rr_depth: u32,
@@ -87,6 +88,11 @@ pub mod sys {
     pub fn hala_rt_set_tile_shard(r: *mut hala_rt_renderer, rank: u32, world: u32, tile_size: u32) -> c_int;
     pub fn hala_rt_tile_buffer(r: *mut hala_rt_renderer, which: c_int, d_ptr: *mut *mut c_void, bytes: *mut usize) -> c_int;
     pub fn hala_rt_scatter_gathered_tiles(r: *mut hala_rt_renderer, which: c_int, d_gathered: *const c_void, bytes: usize) -> c_int;
+    // cpu::HalaScene::new inside the library (for hosts without the Rust `src/scene` module)
+    pub fn hala_scene_load_gltf(path: *const c_char, out: *mut *mut hala_scene) -> c_int;
+    pub fn hala_scene_get_desc(scene: *const hala_scene) -> *const hala_scene_desc;
+    pub fn hala_scene_free(scene: *mut hala_scene);
+    pub fn hala_load_float_image(path: *const c_char, width: *mut u32, height: *mut u32, channels: *mut u32, dst: *mut f32, capacity_floats: usize) -> c_int;
   }
 }
 
@@ -190,6 +196,23 @@ impl HalaRenderer {
   pub fn set_tile_shard(&mut self, rank: u32, world: u32, tile_size: u32) -> Result<(), HalaRendererError> { check(unsafe { sys::hala_rt_set_tile_shard(self.h, rank, world, tile_size) }) }
 }
 impl Drop for HalaRenderer { fn drop(&mut self) { unsafe { sys::hala_rt_destroy(self.h) } } }
+
+/// A scene loaded by the library's own glTF reader (csrc/gltf_loader.cpp): what `cpu::HalaScene::new(path)` returns in the
+/// reference (src/scene/cpu/scene.rs:40-55), kept on the C side and handed to `set_scene` by reference.
+pub struct HalaNativeScene { h: *mut sys::hala_scene }
+impl HalaNativeScene {
+  pub fn new<P: AsRef<Path>>(path: P) -> Result<Self, HalaRendererError> {
+    let mut h = std::ptr::null_mut();
+    check(unsafe { sys::hala_scene_load_gltf(cpath(path).as_ptr(), &mut h) })?;
+    Ok(Self { h })
+  }
+}
+impl Drop for HalaNativeScene { fn drop(&mut self) { unsafe { sys::hala_scene_free(self.h) } } }
+impl HalaRenderer {
+  pub fn set_native_scene(&mut self, scene: &HalaNativeScene) -> Result<(), HalaRendererError> {
+    check(unsafe { sys::hala_rt_set_scene(self.h, sys::hala_scene_get_desc(scene.h)) })
+  }
+}
 
 /// src/raytracing_program.rs:70-341 — a ray batch traced against a committed renderer's acceleration structure.
 pub struct HalaRayTracingProgram<'a> { renderer: &'a HalaRenderer, rays: *const sys::hala_ray, hits: *mut sys::hala_hit, any_hit: bool }
