@@ -202,11 +202,14 @@ def main():
         lp = max(d(f"leaf_passes_{kind}_total"), 1)
         simt[kind] = {"node_path_lanes_of_64": round(d(f"nodes_{kind}_total") / ws, 1), "leaf_passes_per_wave_step": round(d(f"leaf_passes_{kind}_total") / ws, 2),
                       "leaf_path_lanes_of_64": round(d(f"leaf_lanes_{kind}_total") / lp, 1)}
-    traffic = None
+    traffic, valu = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic_closest.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            tj = json.load(open(tpath))
+            traffic = tj.get("hbm_bytes_per_launch")
+            valu = {"issue_utilisation": tj.get("valu_issue_utilisation"), "active_lanes_per_instruction": tj.get("active_lanes_per_valu_instruction"),
+                    "source": tj.get("source")}
         except Exception:
             traffic = None
 
@@ -237,7 +240,7 @@ def main():
                          "tris_per_ray": round(tris_per_ray, 3), "avg_launch_ms": round(avg_launch_ms, 5),
                          "launches": int(batch_launches), "rays_per_launch": round(rays_per_launch, 1),
                          "grays_per_s_in_kernel": round(rays_bounce / max(batch_ms, 1e-9) / 1e6, 3),
-                         "simt": simt,
+                         "simt": simt, "valu": valu,
                          "primary_kernel": {"kernel": "rt::k_trace_primary<false, true> (depth 0: camera rays generated in the lanes that trace them, 16 B hit write per ray)",
                                             "avg_launch_ms": round(primary_ms / max(primary_launches, 1), 5), "launches": int(primary_launches),
                                             "rays_per_launch": round(rays_primary / max(primary_launches, 1), 1),

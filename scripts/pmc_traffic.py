@@ -19,6 +19,10 @@ out = {
     "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request for wide (16 B/lane) coalesced reads -> x2 (MI355X_MICROARCH.md §HBM); "
                   "WRITE_SIZE taken as is; separate --pmc passes (scripts/pmc_collect.sh)",
     "hbm_bytes_per_launch": int(fetch_kb * 1024 * 2 + write_kb * 1024),
+    # what actually bounds the kernel (the BVH of this scene lives in LDS): VALU issue slots.  One SIMD issues one VALU
+    # instruction per 4 cycles; 1024 SIMDs; kernel cycles = GRBM_GUI_ACTIVE summed over the 8 XCDs / 8
+    "valu_issue_utilisation": round(v["SQ_INSTS_VALU"]["mean_per_launch"] / (1024 * (v["GRBM_GUI_ACTIVE"]["mean_per_launch"] / 8) / 4), 3),
+    "active_lanes_per_valu_instruction": round(v["SQ_THREAD_CYCLES_VALU"]["mean_per_launch"] / v["SQ_INSTS_VALU"]["mean_per_launch"], 1),
     "source": sys.argv[3],
 }
 json.dump(out, open(sys.argv[2], "w"), indent=1)
