@@ -2,8 +2,9 @@
 // `hala_scene_load_gltf` is cpu::HalaScene::new (src/scene/cpu/scene.rs:40-55); the scene it returns is the borrowed
 // `hala_scene_desc` that `hala_rt_set_scene` consumes.  Rule by rule like the reference (each rule cites its lines); the
 // reference delegates parsing to the `gltf` and `image` crates — here: the library's own JSON reader, base64, accessor
-// decoding, and a PNG decoder over zlib (8/16-bit, grey / RGB / palette / alpha, non-interlaced).  JPEG and interlaced PNG
-// images are reported as "Unsupported image format." (the Python mirror hala-renderer_amd/gltf_loader.py decodes those with PIL).
+// decoding, a PNG decoder over zlib (8/16-bit, grey / RGB / palette / alpha, non-interlaced) and a baseline JPEG decoder
+// (jpeg_decode.cpp).  Progressive JPEG and interlaced PNG images are reported as "Unsupported image format." (the Python
+// mirror hala-renderer_amd/gltf_loader.py decodes those with PIL).
 #include <zlib.h>
 
 #include <cmath>
@@ -20,6 +21,7 @@
 #include "host_util.h"
 
 using rt::JsonValue;
+namespace rt { bool decode_jpeg(const std::vector<uint8_t>& raw, uint32_t* w, uint32_t* h, std::vector<uint8_t>* rgba); }  // jpeg_decode.cpp
 
 struct hala_scene {
   std::deque<std::string> names;  // stable addresses for hala_node_desc::name
@@ -453,7 +455,7 @@ void load(const std::string& path, hala_scene* s) {
     }
     uint32_t w = 0, h = 0;
     std::vector<uint8_t> px;
-    if (!decode_png(raw, &w, &h, &px)) fail("Unsupported image format.");
+    if (!decode_png(raw, &w, &h, &px) && !rt::decode_jpeg(raw, &w, &h, &px)) fail("Unsupported image format.");
     s->pixels.push_back(std::move(px));
     s->images.push_back(hala_image_desc{HALA_FORMAT_R8G8B8A8_SRGB, w, h, s->pixels.back().data(), s->pixels.back().size()});
   }

@@ -130,3 +130,38 @@ def test_native_scene_renders_like_the_python_one(halart, oracle, tmp_path):
     assert r.read_image(0).tobytes() == q.read_image(0).tobytes()
     assert float(r.read_image(0)[..., :3].mean()) > 0.01
     r.close(); q.close(); nat.close()
+
+
+@pytest.mark.parametrize("variant", ["444", "420", "grey", "restart", "ragged"])
+def test_jpeg_textures_decode_like_pil(tmp_path, variant):
+    """baseline JPEG through the C++ loader vs PIL's decode of the same bytes: different inverse DCTs / chroma upsampling may
+    differ by a few levels, structure must not (smooth test image, so replicated chroma stays close to PIL's interpolation)"""
+    import base64
+    import io
+    from PIL import Image
+    w, h = (61, 37) if variant == "ragged" else (64, 48)
+    yy, xx = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+    img = np.stack([128 + 100 * np.sin(xx / 17.0), 128 + 100 * np.cos(yy / 13.0), 60 + 1.5 * xx + 1.2 * yy], -1).clip(0, 255).astype(np.uint8)
+    pil = Image.fromarray(img, "RGB").convert("L") if variant == "grey" else Image.fromarray(img, "RGB")
+    kw = dict(quality=92, subsampling=2 if variant in ("420", "ragged") else 0)
+    if variant == "restart":
+        kw["restart_marker_blocks"] = 3
+    bio = io.BytesIO()
+    pil.save(bio, format="JPEG", **kw)
+    want = np.array(Image.open(io.BytesIO(bio.getvalue())).convert("RGBA"), dtype=np.int32)
+    s = scenes.cornell_box()
+    scenes.attach_textures(s, sets=1, size=16)
+    p = tmp_path / "scene.gltf"
+    write_gltf(s, str(p))
+    doc = json.load(open(p))
+    doc["images"][0] = {"uri": "data:image/jpeg;base64," + base64.b64encode(bio.getvalue()).decode()}
+    json.dump(doc, open(p, "w"))
+    nat = NativeScene(str(p))
+    im = nat.desc.image_data[0]
+    assert (im.width, im.height, im.format) == (w, h, 1)
+    got = np.frombuffer(C.string_at(im.data, im.num_of_bytes), dtype=np.uint8).reshape(h, w, 4).astype(np.int32)
+    diff = np.abs(got - want)
+    assert diff[..., 3].max() == 0
+    sub = variant in ("420", "ragged")  # replicated chroma vs libjpeg's triangle-filter upsampling
+    assert diff[..., :3].mean() < (3.0 if sub else 1.5) and np.percentile(diff[..., :3], 99) <= (12 if sub else 6), (diff[..., :3].mean(), diff.max())
+    nat.close()
