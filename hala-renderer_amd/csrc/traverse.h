@@ -25,7 +25,7 @@ constexpr int kTraverseThreads = 256;
 #endif
 constexpr int kTraverseWavesPerSimd = RT_WAVES_PER_SIMD;
 #ifndef RT_WAVES_PER_SIMD_STAGED
-#define RT_WAVES_PER_SIMD_STAGED 4
+#define RT_WAVES_PER_SIMD_STAGED 4  // 128 VGPRs: room for the packed triangle-pair test; LDS-resident scenes have no latency to hide
 #endif
 constexpr int kTraverseWavesPerSimdStaged = RT_WAVES_PER_SIMD_STAGED;
 // Per-lane traversal stack: 8-B entries (ordering key = entry distance | slot, child reference).  96 B of LDS per lane
