@@ -13,6 +13,7 @@
 // Results are validated against the oracle through traversal results and a structural check, never topology.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstring>
 
 #include <rocprim/rocprim.hpp>
@@ -177,11 +178,17 @@ __global__ void __launch_bounds__(256) k_hierarchy(const unsigned long long* __r
 }
 
 __global__ void __launch_bounds__(256) k_leaf_boxes(const Box6* __restrict__ tri_box, const uint32_t* __restrict__ sorted_ids, uint32_t n,
-                                                     Box6* __restrict__ leaf_box, const Tri* __restrict__ tris_by_id, Tri* __restrict__ tris) {
+                                                     Box6* __restrict__ leaf_box, const Tri* __restrict__ tris_by_id, Tri* __restrict__ tris, float pad) {
   const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
   const uint32_t id = sorted_ids[k];
-  leaf_box[k] = tri_box[id];
+  // The slab test's plane distances carry a rounding error of a few ulp of the largest coordinate involved, like the triangle
+  // test's own; quantisation usually adds far more slack, but a plane that falls exactly on the grid gets none.  `pad` (2^-19 of
+  // the scene's largest coordinate) keeps a hit that lies exactly on a box face inside its box.
+  Box6 b = tri_box[id];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { b.mn[c] -= pad; b.mx[c] += pad; }
+  leaf_box[k] = b;
   const float4* src = reinterpret_cast<const float4*>(tris_by_id + id);
   float4* dst = reinterpret_cast<float4*>(tris + k);
   dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
@@ -500,8 +507,10 @@ static std::string flatten_and_bounds(BvhBuffers& b, BvhTopology& t, hipStream_t
 
 static std::string fit_and_emit(BvhBuffers& b, BvhTopology& t, hipStream_t s) {
   const uint32_t n = b.tri_count;
+  float amax = 0.0f;
+  for (int k = 0; k < 3; ++k) amax = std::max(amax, std::max(std::fabs(b.scene_min[k]), std::fabs(b.scene_max[k])));
   if (n) hipLaunchKernelGGL(k_leaf_boxes, dim3(nblk(n)), dim3(256), 0, s, t.tri_box.as<Box6>(), t.sorted_ids.as<uint32_t>(), n,
-                            t.leaf_box.as<Box6>(), b.tris_by_id, b.tris);
+                            t.leaf_box.as<Box6>(), b.tris_by_id, b.tris, amax * 1.9073486328125e-06f /* 2^-19 */);
   if (n <= t.leaf_max || n < 2) {
     hipLaunchKernelGGL(k_emit_single4, dim3(1), dim3(64), 0, s, t.leaf_box.as<Box6>(), n, b.nodes);
     b.node_count = 1;

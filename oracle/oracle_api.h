@@ -151,6 +151,8 @@ void orc_trace_rays_on_bvh4(const void* nodes64, uint32_t node_count, const void
 int orc_validate_bvh4(const void* nodes64, uint32_t node_count, const void* tris48, uint32_t tri_count,
                       const float* ref9, uint32_t* max_depth);
 
+// Makes orc_render traverse a tree the product built (same layout as above; node_count 0 switches back to the oracle's own).
+void orc_scene_use_bvh4(orc_scene* s, const void* nodes64, uint32_t node_count, const void* tris48, uint32_t tri_count);
 // The oracle's own SAH tree in the product's 4-wide format (greedy surface-area collapse, conservative quantisation) and
 // its triangles in that tree's order: a CPU-built tree to pin the two functions above on, and a quality yardstick for
 // the product's builder.  Returns the node count (query with nodes64_out == NULL); 0 on failure.

@@ -576,8 +576,6 @@ struct PixelOut { V3 L, albedo, normal; };
 
 static PixelOut trace_path(const Frame& f, uint32_t px, uint32_t py, uint32_t frame_index, orc_render_stats* st, Counters* ctr) {
   const orc_scene* s = f.s;
-  const Node* nodes = s->nodes.data();
-  const Tri* tris = s->tris.data();
   uint32_t rng = rng_init(py * f.p.width + px, frame_index);
   V3 o, d;
   camera_ray(f, px, py, &rng, &o, &d);
@@ -586,7 +584,7 @@ static PixelOut trace_path(const Frame& f, uint32_t px, uint32_t py, uint32_t fr
   PixelOut out; out.albedo = v3s(0.0f); out.normal = v3s(0.0f);
   const uint32_t nl = (uint32_t)s->light_count;
   for (uint32_t depth = 0; depth < f.p.max_depth; ++depth) {
-    Hit h = trace_closest(nodes, tris, o, d, 0.0f, kTMax, ctr);
+    Hit h = scene_trace_closest(s, o, d, 0.0f, kTMax, ctr);
     st->rays_closest++;
     float t_surf = h.prim != ORC_NONE ? h.t : kTMax;
     // hittable analytic lights
@@ -638,7 +636,7 @@ static PixelOut trace_path(const Frame& f, uint32_t px, uint32_t py, uint32_t fr
           V3 so = madd3(sf.ng, side, sf.P);
           float tmax = ls.dist >= kTMax ? kTMax : maxf(ls.dist - 2.0f * s->ray_eps, 0.0f);
           st->rays_shadow++;
-          bool occ = trace_any(nodes, tris, so, ls.wi, 0.0f, tmax, ctr);
+          bool occ = scene_trace_any(s, so, ls.wi, 0.0f, tmax, ctr);
           if (!occ) {
             float cosl = fabsf(dot3(sf.ns, ls.wi));
             V3 contrib;
@@ -664,7 +662,7 @@ static PixelOut trace_path(const Frame& f, uint32_t px, uint32_t py, uint32_t fr
           float side = dot3(wi, sf.ng) >= 0.0f ? s->ray_eps : -s->ray_eps;
           V3 so = madd3(sf.ng, side, sf.P);
           st->rays_shadow++;
-          bool occ = trace_any(nodes, tris, so, wi, 0.0f, kTMax, ctr);
+          bool occ = scene_trace_any(s, so, wi, 0.0f, kTMax, ctr);
           if (!occ) {
             float cosl = fabsf(dot3(sf.ns, wi));
             float w = power_heuristic(pdf_e, pdf_b);

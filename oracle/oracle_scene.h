@@ -78,6 +78,9 @@ struct orc_scene {
   orc::EnvMap env;
   std::vector<orc::Image> images;       // per cpu::HalaImageData
   std::vector<uint32_t> texture_image;  // texture index -> image (gpu_uploader.rs:336-338)
+  // optional: a tree handed over by the product (orc_scene_use_bvh4); the integrator then traverses IT (RENDER_SPEC §4.4b)
+  std::vector<orc::Node4> ext_nodes;
+  std::vector<orc::Tri> ext_tris;
 };
 
 namespace orc {
@@ -86,5 +89,8 @@ struct Hit { float t, u, v; uint32_t prim; };
 // RENDER_SPEC §4: closest / any traversal over (nodes, tris).
 Hit trace_closest(const Node* nodes, const Tri* tris, V3 o, V3 d, float tmin, float tmax, Counters* c);
 bool trace_any(const Node* nodes, const Tri* tris, V3 o, V3 d, float tmin, float tmax, Counters* c);
+// the same on the scene's tree of choice: the product's 4-wide tree if one was handed over, else the oracle's own BVH2
+Hit scene_trace_closest(const orc_scene* s, V3 o, V3 d, float tmin, float tmax, Counters* c);
+bool scene_trace_any(const orc_scene* s, V3 o, V3 d, float tmin, float tmax, Counters* c);
 V3 tonemap_select(V3 color, int enable_tonemap, int enable_aces, int use_simple_aces);
 }  // namespace orc

@@ -175,6 +175,15 @@ class OracleScene:
         lib().orc_scene_get_triangles(self._h, fptr(out))
         return out
 
+    def use_bvh(self, nodes_u32=None, tris_u32=None):
+        """render() then traverses this product-built tree (None: the oracle's own again)"""
+        if nodes_u32 is None:
+            lib().orc_scene_use_bvh4(self._h, C.c_void_p(0), C.c_uint32(0), C.c_void_p(0), C.c_uint32(0))
+            return
+        self._ext = (np.ascontiguousarray(nodes_u32), np.ascontiguousarray(tris_u32))
+        lib().orc_scene_use_bvh4(self._h, C.c_void_p(self._ext[0].ctypes.data), C.c_uint32(self._ext[0].size // 16),
+                                 C.c_void_p(self._ext[1].ctypes.data), C.c_uint32(self._ext[1].size // 12))
+
     def export_bvh4(self):
         """the oracle's SAH tree in the product's compressed 4-wide format: (nodes [n,16] u32, triangles [m,12] u32)"""
         fn = lib().orc_scene_export_bvh4
