@@ -9,7 +9,9 @@ import hala_renderer_amd as H
 from hala_renderer_amd import scenes
 import oracle_lib as O
 
-s = scenes.sponza_class(target_triangles=1_000_000, disney=False)
+which = sys.argv[2] if len(sys.argv) > 2 else "atrium"
+s = {"atrium": lambda: scenes.sponza_class(target_triangles=1_000_000, disney=False), "blob": lambda: scenes.bunny_class(subdivisions=6),
+     "cornell": lambda: scenes.cornell_box(aspect=16 / 9), "sheets": lambda: scenes.stacked_sheets(4096)}[which]()
 r = H.HalaRenderer("hunt", 64, 64, 5, 3, False, False, False, 0)
 r.set_scene(s); r.commit()
 osc = O.OracleScene(s)
@@ -30,6 +32,16 @@ for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 6):
         got = r.trace_rays_host(rr, 0)
         diff = np.nonzero((got["prim"] != want["prim"]) | (got["t"] != want["t"]))[0]
         total += len(rr); bad += len(diff)
+        # any-hit: segments that end just short of / just beyond the closest hit must be free / occluded
+        hitm = want["prim"] != 0xFFFFFFFF
+        seg = rr[hitm].copy()
+        seg["tmax"] = want["t"][hitm] * np.float32(1.001)
+        occ = r.trace_rays_host(seg, 1)["t"] > 0
+        ooc = osc.trace(seg, 1)["t"] > 0
+        bad_any = int((occ != ooc).sum())
+        total += len(seg); bad += bad_any
+        if bad_any:
+            print(label, "any-hit disagreements:", bad_any, "of", len(seg), "(gpu occluded", int(occ.sum()), "oracle", int(ooc.sum()), ")", flush=True)
         for i in diff[:5]:
             bf = osc.trace(rr[i:i + 1], 0, brute=True)[0]
             on_gpu_tree = O.trace_on_bvh(nodes, tris, rr[i:i + 1], 0)[0][0]
