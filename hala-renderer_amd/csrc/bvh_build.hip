@@ -54,49 +54,124 @@ RT_DI f3 transform_point(const float* m, f3 p) {
              __fmaf_rn(m[10], p.z, __fmaf_rn(m[6], p.y, m[2] * p.x)) + m[14]);
 }
 
-// one thread per global triangle id
+// one thread per global triangle id.  The three records a triangle gets (48-B Tri, 112-B ShadeTri, 24-B Box6) are staged in LDS and
+// leave the block as contiguous 16-B (8-B for the boxes) stores.  Scene bounds: NO global atomics here — a device-scope atomic
+// costs 11.4 ns per 128-B line however many waves issue it (scripts/microbench/atomic_rate.hip), and six of them per wave on one
+// line held this kernel at 1.07 ms per million triangles; each block leaves its bounds in block_ord and k_bounds_reduce folds them.
 __global__ void __launch_bounds__(256) k_flatten(const hala_gpu_mesh_data* __restrict__ prims, const uint32_t* __restrict__ first_tri,
                                                   uint32_t inst_count, uint32_t n, Tri* __restrict__ tris_by_id, ShadeTri* __restrict__ shade_tris,
                                                   uint32_t* __restrict__ tri_instance, Box6* __restrict__ tri_box,
-                                                  uint32_t* __restrict__ scene_ord /* [6] min xyz, max xyz */) {
-  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= n) return;
-  uint32_t lo = 0, hi = inst_count;  // last instance with first_tri <= g
-  while (hi - lo > 1u) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (first_tri[mid] <= g) lo = mid; else hi = mid;
-  }
-  const hala_gpu_mesh_data& md = prims[lo];
-  const uint32_t lt = g - first_tri[lo];
-  const uint32_t* idx = reinterpret_cast<const uint32_t*>(md.indices) + 3 * (size_t)lt;
-  const hala_vertex* vb = reinterpret_cast<const hala_vertex*>(md.vertices);
-  f3 v[3];
-#pragma unroll
-  for (int c = 0; c < 3; ++c) v[c] = transform_point(md.transform, ld3(vb[idx[c]].position));
-  const f3 e1 = v[1] - v[0], e2 = v[2] - v[0];
-  float4* out = reinterpret_cast<float4*>(tris_by_id + g);
-  out[0] = make_float4(v[0].x, v[0].y, v[0].z, __uint_as_float(g));
-  out[1] = make_float4(e1.x, e1.y, e1.z, 0.0f);
-  out[2] = make_float4(e2.x, e2.y, e2.z, 0.0f);
-  tri_instance[g] = lo;
-  ShadeTri st{};
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    const hala_vertex& vx = vb[idx[c]];
-    for (int k = 0; k < 3; ++k) { st.n[c][k] = vx.normal[k]; st.tg[c][k] = vx.tangent[k]; }
-    st.uv[c][0] = vx.tex_coord[0]; st.uv[c][1] = vx.tex_coord[1];
-  }
-  st.inst = lo; st.material = md.material_index;
-  shade_tris[g] = st;
+                                                  uint32_t* __restrict__ block_ord /* [gridDim.x][6] min xyz, max xyz */) {
+  __shared__ float4 stage[256 * 7];
+  __shared__ uint32_t wave_ord[4][6];
+  const uint32_t tid = threadIdx.x, base = blockIdx.x * 256u, g = base + tid;
+  const uint32_t cnt = min(256u, n - base);
+  uint32_t ord[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+  float4 tri[3];
   Box6 b;
-  b.mn[0] = fminf(v[0].x, fminf(v[1].x, v[2].x)); b.mx[0] = fmaxf(v[0].x, fmaxf(v[1].x, v[2].x));
-  b.mn[1] = fminf(v[0].y, fminf(v[1].y, v[2].y)); b.mx[1] = fmaxf(v[0].y, fmaxf(v[1].y, v[2].y));
-  b.mn[2] = fminf(v[0].z, fminf(v[1].z, v[2].z)); b.mx[2] = fmaxf(v[0].z, fmaxf(v[1].z, v[2].z));
-  tri_box[g] = b;
+  if (g < n) {
+    uint32_t lo = 0, hi = inst_count;  // last instance with first_tri <= g
+    while (hi - lo > 1u) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (first_tri[mid] <= g) lo = mid; else hi = mid;
+    }
+    const hala_gpu_mesh_data& md = prims[lo];
+    const uint32_t lt = g - first_tri[lo];
+    const uint32_t* idx = reinterpret_cast<const uint32_t*>(md.indices) + 3 * (size_t)lt;
+    const hala_vertex* vb = reinterpret_cast<const hala_vertex*>(md.vertices);
+    f3 v[3];
+    ShadeTri st{};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const hala_vertex& vx = vb[idx[c]];
+      v[c] = transform_point(md.transform, ld3(vx.position));
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { st.n[c][k] = vx.normal[k]; st.tg[c][k] = vx.tangent[k]; }
+      st.uv[c][0] = vx.tex_coord[0]; st.uv[c][1] = vx.tex_coord[1];
+    }
+    st.inst = lo; st.material = md.material_index;
+    const f3 e1 = v[1] - v[0], e2 = v[2] - v[0];
+    tri[0] = make_float4(v[0].x, v[0].y, v[0].z, __uint_as_float(g));
+    tri[1] = make_float4(e1.x, e1.y, e1.z, 0.0f);
+    tri[2] = make_float4(e2.x, e2.y, e2.z, 0.0f);
+    tri_instance[g] = lo;
+    b.mn[0] = fminf(v[0].x, fminf(v[1].x, v[2].x)); b.mx[0] = fmaxf(v[0].x, fmaxf(v[1].x, v[2].x));
+    b.mn[1] = fminf(v[0].y, fminf(v[1].y, v[2].y)); b.mx[1] = fmaxf(v[0].y, fmaxf(v[1].y, v[2].y));
+    b.mn[2] = fminf(v[0].z, fminf(v[1].z, v[2].z)); b.mx[2] = fmaxf(v[0].z, fmaxf(v[1].z, v[2].z));
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { ord[k] = f2ord(b.mn[k]); ord[3 + k] = f2ord(b.mx[k]); }
+    const float4* sp = reinterpret_cast<const float4*>(&st);
+#pragma unroll
+    for (int k = 0; k < 7; ++k) stage[tid * 7u + k] = sp[k];
+  }
+  __syncthreads();
+  {
+    float4* out = reinterpret_cast<float4*>(shade_tris + base);
+    for (uint32_t i = tid; i < cnt * 7u; i += 256u) out[i] = stage[i];
+  }
+  __syncthreads();
+  if (g < n) { stage[tid * 3u] = tri[0]; stage[tid * 3u + 1u] = tri[1]; stage[tid * 3u + 2u] = tri[2]; }
+  __syncthreads();
+  {
+    float4* out = reinterpret_cast<float4*>(tris_by_id + base);
+    for (uint32_t i = tid; i < cnt * 3u; i += 256u) out[i] = stage[i];
+  }
+  __syncthreads();
+  float2* stage2 = reinterpret_cast<float2*>(stage);
+  if (g < n) {
+    stage2[tid * 3u] = make_float2(b.mn[0], b.mn[1]); stage2[tid * 3u + 1u] = make_float2(b.mn[2], b.mx[0]);
+    stage2[tid * 3u + 2u] = make_float2(b.mx[1], b.mx[2]);
+  }
+  __syncthreads();
+  {
+    float2* out = reinterpret_cast<float2*>(tri_box + base);
+    for (uint32_t i = tid; i < cnt * 3u; i += 256u) out[i] = stage2[i];
+  }
+  // scene bounds of this block: wave shuffle reduction, then the four waves through LDS
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    atomicMin(&scene_ord[k], f2ord(b.mn[k]));
-    atomicMax(&scene_ord[3 + k], f2ord(b.mx[k]));
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+      ord[k] = min(ord[k], (uint32_t)__shfl_xor((int)ord[k], m, 64));
+      ord[3 + k] = max(ord[3 + k], (uint32_t)__shfl_xor((int)ord[3 + k], m, 64));
+    }
+  }
+  if ((tid & 63u) == 0u) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) wave_ord[tid >> 6][k] = ord[k];
+  }
+  __syncthreads();
+  if (tid < 6u) {
+    uint32_t v = wave_ord[0][tid];
+    for (int w = 1; w < 4; ++w) v = tid < 3u ? min(v, wave_ord[w][tid]) : max(v, wave_ord[w][tid]);
+    block_ord[blockIdx.x * 6u + tid] = v;
+  }
+}
+// one block: folds the per-block bounds of k_flatten into scene_ord[6]
+__global__ void __launch_bounds__(256) k_bounds_reduce(const uint32_t* __restrict__ block_ord, uint32_t blocks, uint32_t* __restrict__ scene_ord) {
+  __shared__ uint32_t wave_ord[4][6];
+  uint32_t ord[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+  for (uint32_t b = threadIdx.x; b < blocks; b += 256u) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { ord[k] = min(ord[k], block_ord[b * 6u + k]); ord[3 + k] = max(ord[3 + k], block_ord[b * 6u + 3 + k]); }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+      ord[k] = min(ord[k], (uint32_t)__shfl_xor((int)ord[k], m, 64));
+      ord[3 + k] = max(ord[3 + k], (uint32_t)__shfl_xor((int)ord[3 + k], m, 64));
+    }
+  }
+  if ((threadIdx.x & 63u) == 0u) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) wave_ord[threadIdx.x >> 6][k] = ord[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 6u) {
+    uint32_t v = wave_ord[0][threadIdx.x];
+    for (int w = 1; w < 4; ++w) v = threadIdx.x < 3u ? min(v, wave_ord[w][threadIdx.x]) : max(v, wave_ord[w][threadIdx.x]);
+    scene_ord[threadIdx.x] = v;
   }
 }
 
@@ -354,6 +429,38 @@ __global__ void __launch_bounds__(256) k_pack4(const uint4* __restrict__ refs4, 
   nodes[idx] = pack_node4(ch, n);
 }
 
+// Refit of one BFS level of the kept 4-wide topology.  node_box is re-used as scratch indexed by 4-NODE index here (the
+// binary boxes it held are not needed once the tree is collapsed): a node leaves the union of its children there for its
+// parent, one level up, which runs in a later launch.  Same boxes as a fresh fit (min / max are exact), no fences.
+__global__ void __launch_bounds__(256) k_refit_level(const uint4* __restrict__ refs4, uint32_t base, uint32_t size, const uint32_t* __restrict__ first,
+                                                      const uint32_t* __restrict__ last, const uint32_t* __restrict__ keep,
+                                                      const uint32_t* __restrict__ index4, const Box6* __restrict__ leaf_box, Box6* box4,
+                                                      BvhNode4* __restrict__ nodes) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= size) return;
+  const uint32_t idx = base + k;
+  const uint4 q = refs4[idx];
+  const uint32_t c[4] = {q.x, q.y, q.z, q.w};
+  Child4 ch[4];
+  int n = 0;
+  for (int s = 0; s < 4; ++s) {
+    const uint32_t r = c[s];
+    if (r == kAbsent) continue;
+    if (r & kLeafBit) { ch[n].box = leaf_box[r & ~kLeafBit]; ch[n].ref = leaf_ref(r & ~kLeafBit, 1u); }
+    else if (!keep[r]) {
+      const uint32_t f = first[r], l = last[r];
+      Box6 u = leaf_box[f];
+      for (uint32_t t = f + 1; t <= l; ++t) u = box_union(u, leaf_box[t]);
+      ch[n].box = u; ch[n].ref = leaf_ref(f, l - f + 1u);
+    } else { ch[n].box = box4[index4[r]]; ch[n].ref = index4[r]; }
+    ++n;
+  }
+  nodes[idx] = pack_node4(ch, n);
+  Box6 all = ch[0].box;
+  for (int s = 1; s < n; ++s) all = box_union(all, ch[s].box);
+  box4[idx] = all;
+}
+
 // scene of <= leaf_max triangles: one 4-node with a single leaf child
 __global__ void k_emit_single4(const Box6* __restrict__ leaf_box, uint32_t n, BvhNode4* __restrict__ nodes) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -412,7 +519,8 @@ __global__ void __launch_bounds__(256) k_ploc_apply(const uint32_t* __restrict__
                                                      const uint32_t* __restrict__ cl_ref, const Box6* __restrict__ cl_box,
                                                      uint32_t* __restrict__ cl_ref_out, Box6* __restrict__ cl_box_out,
                                                      uint32_t* __restrict__ left, uint32_t* __restrict__ right, uint32_t* __restrict__ node_parent,
-                                                     uint32_t* __restrict__ leaf_parent, uint32_t* __restrict__ subtree) {
+                                                     uint32_t* __restrict__ leaf_parent, uint32_t* __restrict__ subtree,
+                                                     Box6* __restrict__ node_box, float pad) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m || !keepc[i]) return;
   const uint32_t pos = keep_scan[i];
@@ -424,7 +532,14 @@ __global__ void __launch_bounds__(256) k_ploc_apply(const uint32_t* __restrict__
   if (rb & kLeafBit) leaf_parent[rb & ~kLeafBit] = id; else node_parent[rb] = id;
   subtree[id] = ploc_size(ra, subtree) + ploc_size(rb, subtree);
   cl_ref_out[pos] = id;
-  cl_box_out[pos] = box_union(cl_box[i], cl_box[j]);
+  const Box6 u = box_union(cl_box[i], cl_box[j]);
+  cl_box_out[pos] = u;
+  // the fitted box of node id, without a bottom-up pass: the leaf boxes are the triangle boxes widened by `pad` (k_leaf_boxes),
+  // and x -> fl(x -/+ pad) is monotone, so widening the union gives bit for bit the union of the widened boxes
+  Box6 w;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { w.mn[c] = u.mn[c] - pad; w.mx[c] = u.mx[c] + pad; }
+  node_box[id] = w;
 }
 // position of leaf k / first position of node i in the depth-first order of the finished tree: the sizes of all left
 // siblings passed on the way up
@@ -482,19 +597,29 @@ inline uint32_t nblk(uint32_t n) { return (n + 255u) / 256u; }
 // Persistent topology kept for refit.
 struct BvhTopology {
   uint32_t n = 0, leaf_max = 0;
-  DevBuf left, right, first, last, node_parent, leaf_parent, keep, sorted_ids, tri_box, leaf_box, node_box, arrivals, scene_ord;
+  DevBuf left, right, first, last, node_parent, leaf_parent, keep, sorted_ids, tri_box, leaf_box, node_box, arrivals, scene_ord, block_ord;
   // 4-wide collapse: binary root of every 4-node (BFS order), the binary refs its slots were filled from, the 4-node
   // index of every binary root, per-level scratch
   DevBuf root_of, refs4, index4, cnt, off;
   bool collapsed = false;
+  bool fitted = false;               // node_box already holds the fitted boxes (PLOC writes them as it merges)
+  std::vector<uint32_t> level_base;  // first 4-node of every BFS level, then node_count: refit walks the levels bottom-up
 };
+
+// RENDER_SPEC 4.1b: leaf boxes are widened by 2^-19 of the scene's largest coordinate
+static float box_pad(const BvhBuffers& b) {
+  float amax = 0.0f;
+  for (int k = 0; k < 3; ++k) amax = std::max(amax, std::max(std::fabs(b.scene_min[k]), std::fabs(b.scene_max[k])));
+  return amax * 1.9073486328125e-06f;
+}
 
 static std::string flatten_and_bounds(BvhBuffers& b, BvhTopology& t, hipStream_t s) {
   const uint32_t n = b.tri_count;
-  static const uint32_t init_ord[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
-  HIP_TRY(hipMemcpyAsync(t.scene_ord.p, init_ord, sizeof(init_ord), hipMemcpyHostToDevice, s));
-  if (n) hipLaunchKernelGGL(k_flatten, dim3(nblk(n)), dim3(256), 0, s, b.primitives, b.inst_first_tri, b.instance_count, n, b.tris_by_id, b.shade_tris,
-                            b.tri_instance, t.tri_box.as<Box6>(), t.scene_ord.as<uint32_t>());
+  if (n) {
+    hipLaunchKernelGGL(k_flatten, dim3(nblk(n)), dim3(256), 0, s, b.primitives, b.inst_first_tri, b.instance_count, n, b.tris_by_id, b.shade_tris,
+                       b.tri_instance, t.tri_box.as<Box6>(), t.block_ord.as<uint32_t>());
+    hipLaunchKernelGGL(k_bounds_reduce, dim3(1), dim3(256), 0, s, t.block_ord.as<uint32_t>(), nblk(n), t.scene_ord.as<uint32_t>());
+  }
   uint32_t ord[6];
   HIP_TRY(hipMemcpyAsync(ord, t.scene_ord.p, sizeof(ord), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
@@ -507,10 +632,8 @@ static std::string flatten_and_bounds(BvhBuffers& b, BvhTopology& t, hipStream_t
 
 static std::string fit_and_emit(BvhBuffers& b, BvhTopology& t, hipStream_t s) {
   const uint32_t n = b.tri_count;
-  float amax = 0.0f;
-  for (int k = 0; k < 3; ++k) amax = std::max(amax, std::max(std::fabs(b.scene_min[k]), std::fabs(b.scene_max[k])));
   if (n) hipLaunchKernelGGL(k_leaf_boxes, dim3(nblk(n)), dim3(256), 0, s, t.tri_box.as<Box6>(), t.sorted_ids.as<uint32_t>(), n,
-                            t.leaf_box.as<Box6>(), b.tris_by_id, b.tris, amax * 1.9073486328125e-06f /* 2^-19 */);
+                            t.leaf_box.as<Box6>(), b.tris_by_id, b.tris, box_pad(b));
   if (n <= t.leaf_max || n < 2) {
     hipLaunchKernelGGL(k_emit_single4, dim3(1), dim3(64), 0, s, t.leaf_box.as<Box6>(), n, b.nodes);
     b.node_count = 1;
@@ -520,9 +643,24 @@ static std::string fit_and_emit(BvhBuffers& b, BvhTopology& t, hipStream_t s) {
     return "";
   }
   const uint32_t ni = n - 1;
-  HIP_TRY(hipMemsetAsync(t.arrivals.p, 0, (size_t)ni * 4, s));
-  hipLaunchKernelGGL(k_fit, dim3(nblk(n)), dim3(256), 0, s, t.left.as<uint32_t>(), t.right.as<uint32_t>(), t.node_parent.as<uint32_t>(),
-                     t.leaf_parent.as<uint32_t>(), t.leaf_box.as<Box6>(), t.node_box.as<Box6>(), t.arrivals.as<uint32_t>(), n);
+  if (t.collapsed) {
+    // refit: the 4-wide topology is kept; levels are contiguous in BFS order, so one launch per level from the deepest up
+    // re-derives every node from its children's boxes (leaf boxes, or the union a child node left in node_box[its index])
+    for (size_t l = t.level_base.size() - 1; l-- > 0;) {
+      const uint32_t base = t.level_base[l], size = t.level_base[l + 1] - base;
+      hipLaunchKernelGGL(k_refit_level, dim3(nblk(size)), dim3(256), 0, s, t.refs4.as<uint4>(), base, size, t.first.as<uint32_t>(),
+                         t.last.as<uint32_t>(), t.keep.as<uint32_t>(), t.index4.as<uint32_t>(), t.leaf_box.as<Box6>(), t.node_box.as<Box6>(),
+                         b.nodes);
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipGetLastError());
+    return "";
+  }
+  if (!t.fitted) {
+    HIP_TRY(hipMemsetAsync(t.arrivals.p, 0, (size_t)ni * 4, s));
+    hipLaunchKernelGGL(k_fit, dim3(nblk(n)), dim3(256), 0, s, t.left.as<uint32_t>(), t.right.as<uint32_t>(), t.node_parent.as<uint32_t>(),
+                       t.leaf_parent.as<uint32_t>(), t.leaf_box.as<Box6>(), t.node_box.as<Box6>(), t.arrivals.as<uint32_t>(), n);
+  }
   if (!t.collapsed) {  // first build: choose the 4-wide topology from the fitted boxes; refit keeps it
     static const uint32_t zero = 0;
     HIP_TRY(hipMemcpyAsync(t.root_of.p, &zero, 4, hipMemcpyHostToDevice, s));
@@ -533,7 +671,9 @@ static std::string fit_and_emit(BvhBuffers& b, BvhTopology& t, hipStream_t s) {
     std::string e = tmp.alloc(tmp_bytes);
     if (!e.empty()) return e;
     uint32_t base = 0, size = 1, levels = 0;
+    t.level_base.clear();
     while (size > 0) {
+      t.level_base.push_back(base);
       hipLaunchKernelGGL(k_collapse_level, dim3(nblk(size)), dim3(256), 0, s, t.root_of.as<uint32_t>(), base, size, t.left.as<uint32_t>(),
                          t.right.as<uint32_t>(), t.keep.as<uint32_t>(), t.node_box.as<Box6>(), t.refs4.as<uint4>(), t.cnt.as<uint32_t>());
       size_t tb = tmp_bytes;
@@ -548,6 +688,7 @@ static std::string fit_and_emit(BvhBuffers& b, BvhTopology& t, hipStream_t s) {
       size = last_off + last_cnt;
       ++levels;
     }
+    t.level_base.push_back(base);
     b.node_count = base;
     b.max_depth = levels;
     b.stack_need = 3u * levels;  // a 4-node visit defers at most three siblings
@@ -592,7 +733,7 @@ static std::string ploc_hierarchy(BvhBuffers& b, BvhTopology& t, hipStream_t s) 
     hipLaunchKernelGGL(k_ploc_apply, dim3(nblk(m)), dim3(256), 0, s, nn.as<uint32_t>(), merge.as<uint32_t>(), keepc.as<uint32_t>(),
                        merge_scan.as<uint32_t>(), keep_scan.as<uint32_t>(), m, (ni - 1u) - created, ref[cur].as<uint32_t>(), box[cur].as<Box6>(),
                        ref[cur ^ 1].as<uint32_t>(), box[cur ^ 1].as<Box6>(), t.left.as<uint32_t>(), t.right.as<uint32_t>(),
-                       t.node_parent.as<uint32_t>(), t.leaf_parent.as<uint32_t>(), subtree.as<uint32_t>());
+                       t.node_parent.as<uint32_t>(), t.leaf_parent.as<uint32_t>(), subtree.as<uint32_t>(), t.node_box.as<Box6>(), box_pad(b));
     uint32_t last_scan = 0, last_flag = 0;
     HIP_TRY(hipMemcpyAsync(&last_scan, merge_scan.as<uint32_t>() + (m - 1), 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(&last_flag, merge.as<uint32_t>() + (m - 1), 4, hipMemcpyDeviceToHost, s));
@@ -633,7 +774,7 @@ std::string bvh_build(BvhBuffers& b, uint32_t leaf_max, hipStream_t s) {
   ALLOC(left, ni * 4); ALLOC(right, ni * 4); ALLOC(first, ni * 4); ALLOC(last, ni * 4); ALLOC(node_parent, ni * 4);
   ALLOC(leaf_parent, (size_t)n * 4); ALLOC(keep, ni * 4); ALLOC(sorted_ids, (size_t)n * 4);
   ALLOC(tri_box, (size_t)n * sizeof(Box6)); ALLOC(leaf_box, (size_t)n * sizeof(Box6)); ALLOC(node_box, ni * sizeof(Box6));
-  ALLOC(arrivals, ni * 4); ALLOC(scene_ord, 6 * 4);
+  ALLOC(arrivals, ni * 4); ALLOC(scene_ord, 6 * 4); ALLOC(block_ord, (size_t)(nblk(n) + 1u) * 24);
   ALLOC(root_of, ni * 4); ALLOC(refs4, ni * 16); ALLOC(index4, ni * 4); ALLOC(cnt, ni * 4); ALLOC(off, ni * 4);
 #undef ALLOC
   if (leaf_max > 8u || n >= (1u << 28)) return "bvh_build: the 4-wide node format holds leaves of <= 8 triangles and < 2^28 triangles";
@@ -659,6 +800,7 @@ std::string bvh_build(BvhBuffers& b, uint32_t leaf_max, hipStream_t s) {
     const bool ploc = builder ? !strcmp(builder, "ploc") : n >= 4096u;
     if (ploc) {
       if (!(e = ploc_hierarchy(b, t, s)).empty()) return e;
+      t.fitted = true;
     } else
       hipLaunchKernelGGL(k_hierarchy, dim3(nblk(n - 1)), dim3(256), 0, s, keys_out.as<unsigned long long>(), (int)n, t.left.as<uint32_t>(),
                          t.right.as<uint32_t>(), t.first.as<uint32_t>(), t.last.as<uint32_t>(), t.node_parent.as<uint32_t>(),

@@ -125,12 +125,15 @@ constexpr uint32_t kMaxDepth = 64;
 // ~88 dequeues/us on MI355X (guide: "dequeue" row), which a 2 M-ray launch of 64-ray batches would hit.  The ray range
 // is therefore cut into kWorkShards contiguous shards, each with its own counter on its own 128-B line; a wave starts
 // on shard (blockIdx & 15) — blocks b and b+8 share an XCD — and moves on to the next shard when its own is dry.
-constexpr uint32_t kWorkShards = 16;
+#ifndef RT_WORK_SHARDS
+#define RT_WORK_SHARDS 16
+#endif
+constexpr uint32_t kWorkShards = RT_WORK_SHARDS;  // power of two, <= 64 (the dry mask is one 64-bit word)
 constexpr uint32_t kWorkStride = 32;  // uint32 words between shard counters (128 B)
 constexpr uint32_t kWorkBatch = 128;  // rays handed out per dequeue (two 64-lane passes)
 struct WorkCounters {
   uint32_t c[kWorkShards * kWorkStride];
-  uint32_t dry[kWorkStride];  // dry[0]: bit s set once shard s has handed out all of its batches (own 128-B line)
+  unsigned long long dry[kWorkStride / 2];  // dry[0]: bit s set once shard s has handed out all of its batches (own 128-B line)
 };
 struct Control {
   uint32_t n_active[kMaxDepth + 1];  // ray-queue size entering bounce d

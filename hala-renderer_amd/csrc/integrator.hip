@@ -69,17 +69,21 @@ RT_DI void block_compact3(BlockCompact& sm, const bool keep[3], uint32_t* const 
 // contiguous shards, each with its own counter; a wave works on one shard until it is dry.  Wave-uniform.
 struct WorkCursor {
   uint32_t shard, per;
+  unsigned long long dead;  // shards that lie wholly beyond the queue's end: never probed
 };
 RT_DI WorkCursor work_begin(uint32_t n) {
   WorkCursor c;
-  c.shard = blockIdx.x & (kWorkShards - 1u);
   const uint32_t batches = (n + kWorkBatch - 1u) / kWorkBatch;
   c.per = ((batches + kWorkShards - 1u) / kWorkShards) * kWorkBatch;  // rays per shard, a multiple of the batch
+  const uint32_t live = c.per ? min(kWorkShards, (n + c.per - 1u) / c.per) : 0u;
+  c.dead = live >= 64u ? 0ull : ~((1ull << live) - 1ull);
+  c.shard = live ? blockIdx.x % live : 0u;
   return c;
 }
 // Variable-size dequeue for the refill loop: asks for `want` rays, is granted 1..want of them from one shard.
 RT_DI uint32_t work_take(WorkCounters* wc, WorkCursor& c, uint32_t n, uint32_t want, uint32_t* got) {
-  constexpr uint32_t kAll = (1u << kWorkShards) - 1u;
+  constexpr unsigned long long kAll = kWorkShards >= 64u ? ~0ull : (1ull << (kWorkShards & 63u)) - 1ull;
+  if ((c.dead & kAll) == kAll) { *got = 0; return kAbsent; }
   for (;;) {
     uint32_t v = 0;
     if (lane_id() == 0u) v = atomicAdd(&wc->c[c.shard * kWorkStride], want);
@@ -93,17 +97,17 @@ RT_DI uint32_t work_take(WorkCounters* wc, WorkCursor& c, uint32_t n, uint32_t w
     // this shard is dry: publish that (once) and move to a shard nobody has reported dry yet.  The mask only ever
     // gains bits and a bit is set only after the shard's last ray was handed out, so a stale read costs at most an
     // extra probe and "all dry" is never reported early.
-    uint32_t m = 0;
+    unsigned long long m = 0;
     if (lane_id() == 0u) {
       m = __hip_atomic_load(&wc->dry[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (!(m & (1u << c.shard))) { atomicOr(&wc->dry[0], 1u << c.shard); m |= 1u << c.shard; }
+      if (!(m & (1ull << c.shard))) { atomicOr(&wc->dry[0], 1ull << c.shard); m |= 1ull << c.shard; }
     }
-    m = (uint32_t)__shfl((int)m, 0);
+    m = (unsigned long long)__shfl((long long)m, 0) | c.dead;
     if ((m & kAll) == kAll) { *got = 0; return kAbsent; }
-    const uint32_t avail = ~m & kAll;
+    const unsigned long long avail = ~m & kAll;
     const uint32_t rot = (c.shard + 1u) & (kWorkShards - 1u);
-    const uint32_t r = ((avail >> rot) | (avail << (kWorkShards - rot))) & kAll;
-    c.shard = (rot + (uint32_t)__ffs((int)r) - 1u) & (kWorkShards - 1u);
+    const unsigned long long r = rot ? (((avail >> rot) | (avail << (kWorkShards - rot))) & kAll) : avail;
+    c.shard = (rot + (uint32_t)__ffsll((long long)r) - 1u) & (kWorkShards - 1u);
   }
 }
 
@@ -324,7 +328,7 @@ __global__ void __launch_bounds__(kShadeThreads, RT_SHADE_WAVES) k_shade(FrameCo
     ctl->work_closest.c[threadIdx.x * kWorkStride] = 0u;
     ctl->work_shadow[0].c[threadIdx.x * kWorkStride] = 0u;
     ctl->work_shadow[1].c[threadIdx.x * kWorkStride] = 0u;
-    if (threadIdx.x == 0u) { ctl->work_closest.dry[0] = 0u; ctl->work_shadow[0].dry[0] = 0u; ctl->work_shadow[1].dry[0] = 0u; }
+    if (threadIdx.x == 0u) { ctl->work_closest.dry[0] = 0ull; ctl->work_shadow[0].dry[0] = 0ull; ctl->work_shadow[1].dry[0] = 0ull; }
   }
   if (blockIdx.x * blockDim.x >= n) return;  // whole workgroup beyond the queue (uniform exit: barriers below)
   const bool active = i < n;

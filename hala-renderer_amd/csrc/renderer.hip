@@ -317,8 +317,11 @@ int alloc_frame_buffers(hala_rt_renderer* r) {
   return HALA_OK;
 }
 
-int upload_packed(hala_rt_renderer* r) {
+// geometry = false re-publishes only the small records (cameras, lights, materials, instances): what a refit needs, since
+// node transforms move instances, cameras and lights but leave the vertex / index arenas untouched.
+int upload_packed(hala_rt_renderer* r, bool geometry = true) {
   HostScene& hs = r->hs;
+  if (geometry) {
   // one arena each for all vertex / index buffers (the reference creates one buffer pair per primitive,
   // gpu_uploader.rs:421-456; device addresses per primitive are what matters to the shaders, :869-870)
   size_t nv = 0, ni = 0;
@@ -333,6 +336,7 @@ int upload_packed(hala_rt_renderer* r) {
     const auto& p = hs.prims[k];
     if (!p.vertices.empty()) RT_HIP(hipMemcpyAsync(r->d_vertices.ptr + r->prim_vertex_offset[k], p.vertices.data(), p.vertices.size() * sizeof(hala_vertex), hipMemcpyHostToDevice, r->stream));
     if (!p.indices.empty()) RT_HIP(hipMemcpyAsync(r->d_indices.ptr + r->prim_index_offset[k], p.indices.data(), p.indices.size() * 4, hipMemcpyHostToDevice, r->stream));
+  }
   }
   for (size_t i = 0; i < hs.instances.size(); ++i) {
     const uint32_t p = hs.instance_prim[i];
@@ -945,7 +949,7 @@ int hala_rt_refit(hala_rt_renderer* r) {
   r->hs.update_node_hierarchies();
   const std::string e = r->hs.pack();
   if (!e.empty()) RT_FAIL(e);
-  if (upload_packed(r) != HALA_OK) return HALA_ERR;
+  if (upload_packed(r, false) != HALA_OK) return HALA_ERR;
   r->bvh.primitives = r->d_instances.ptr; r->bvh.inst_first_tri = r->d_inst_first_tri.ptr;
   const std::string e2 = bvh_refit(r->bvh, r->stream);
   if (!e2.empty()) RT_FAIL(e2);

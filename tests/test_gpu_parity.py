@@ -297,6 +297,22 @@ def test_refit_after_node_transform(halart, oracle):
     r.close()
 
 
+def test_refit_without_change_reproduces_the_build(halart, oracle):
+    """refit re-derives the 4-wide nodes level by level (k_refit_level) instead of fit + pack: with nothing moved the nodes, the
+    triangle order and every box must come out byte for byte as the build (PLOC boxes for the large scene, k_fit for the small)"""
+    for s in (scenes.sponza_class(target_triangles=20_000), scenes.cornell_box()):
+        r = make_renderer(halart, s, 16, 16)
+        n0, t0 = r.download_bvh()
+        info0 = r.bvh_info()
+        r.refit()
+        n1, t1 = r.download_bvh()
+        info1 = r.bvh_info()
+        assert n0.tobytes() == n1.tobytes() and t0.tobytes() == t1.tobytes()
+        assert (info0.node_count, info0.max_depth) == (info1.node_count, info1.max_depth)
+        assert list(info0.scene_min) == list(info1.scene_min) and list(info0.scene_max) == list(info1.scene_max)
+        r.close()
+
+
 # ---- K5-K7: the integrator -----------------------------------------------------------------------------------------------
 def assert_images_equal(r, imgs):
     for which, name in ((0, "accum"), (1, "albedo"), (2, "normal"), (3, "final")):
