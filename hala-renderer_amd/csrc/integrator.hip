@@ -223,26 +223,34 @@ struct CameraSource {
                                                : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(kAbsent));
   }
 };
+template <bool PREFETCH>
 struct ShadowSource {
-  struct Payload { float4 cs; };  // contribution.xyz | pixel slot, fetched with the ray (one coalesced 48-B record)
+  // contribution.xyz | pixel slot, fetched with the ray (one coalesced 48-B record), and the path's radiance as it stands
+  struct Payload { float4 cs; float lx, ly, lz; };
   const ShadowEntry* entries;
   float4* radiance;
+  // A path owns at most one connection per queue and the two queues are traced by separate launches, so nothing else touches this
+  // path's radiance during the launch: it is fetched here, behind the entry (the load is in flight while the ray is traced), and
+  // an unoccluded ray stores radiance + contribution — one IEEE add per component, no ordering freedom.  (Three memory-side float
+  // atomics per unoccluded ray did the same and cost 57 of the launch's 160 us on the headline config: profiles/r01_h_experiments.txt.)
+  // PREFETCH = false (the 6-waves-per-SIMD kernels of large scenes, where three more live registers spill): the add is done by
+  // fire-and-forget float atomics instead — at most one per radiance word per launch, so exactly the same single IEEE add.
   RT_DI bool load(uint32_t i, f3* o, f3* d, float* tmin, float* tmax, Payload* p) const {
     const float4* e = reinterpret_cast<const float4*>(entries + i);
     const float4 ro = e[0], rd = e[1];
     p->cs = e[2];
+    if (PREFETCH) {
+      const float* l = reinterpret_cast<const float*>(radiance + __float_as_uint(p->cs.w));
+      p->lx = l[0]; p->ly = l[1]; p->lz = l[2];
+    }
     *o = mk3(ro.x, ro.y, ro.z); *d = mk3(rd.x, rd.y, rd.z); *tmin = ro.w; *tmax = rd.w;
     return true;
   }
-  // A path owns at most one connection per queue and the two queues are traced by separate launches, so each radiance
-  // word receives at most ONE add per launch: a fire-and-forget float atomic is then exactly `L = L + c` (one IEEE add,
-  // no ordering freedom) and the lane does not stall on a read-modify-write round trip.
   RT_DI void done(uint32_t, const Trav& t, const Payload& p) const {
     if (t.best.prim != kAbsent) return;  // occluded
     float* l = reinterpret_cast<float*>(radiance + __float_as_uint(p.cs.w));
-    atomicAdd(l + 0, p.cs.x);
-    atomicAdd(l + 1, p.cs.y);
-    atomicAdd(l + 2, p.cs.z);
+    if (PREFETCH) { l[0] = p.lx + p.cs.x; l[1] = p.ly + p.cs.y; l[2] = p.lz + p.cs.z; }
+    else { atomicAdd(l + 0, p.cs.x); atomicAdd(l + 1, p.cs.y); atomicAdd(l + 2, p.cs.z); }
   }
 };
 
@@ -304,7 +312,7 @@ k_trace_shadow(SceneView sv, Queues q, PathState ps, Control* __restrict__ ctl, 
   const uint32_t n = ctl->n_shadow[kind][depth];
   uint2* spill = spill_base ? spill_base + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * kStackSpill : nullptr;
   StepCounters sc;
-  ShadowSource src{q.shadow[kind], ps.radiance};
+  ShadowSource<STAGED> src{q.shadow[kind], ps.radiance};
   persistent_trace<true, COUNT, STAGED>(sv, lds, spill, &ctl->work_shadow[kind], n, refill, src, sc);
   if (COUNT) flush_counters(ctl, 1, sc);
 }
