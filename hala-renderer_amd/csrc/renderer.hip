@@ -942,6 +942,21 @@ int hala_rt_update_node_transform(hala_rt_renderer* r, uint32_t node_index, cons
   memcpy(r->hs.nodes[node_index].local.m, local_transform, 64);
   return HALA_OK;
 }
+int hala_rt_update_vertices(hala_rt_renderer* r, uint32_t mesh_index, uint32_t primitive_index, const hala_vertex* vertices, uint32_t vertex_count) {
+  if (!r || !vertices) RT_FAIL("Invalid argument.");
+  if (ensure_device(r) != HALA_OK) return HALA_ERR;
+  if (!r->committed) RT_FAIL("The top level acceleration structure is none!");
+  if (mesh_index + 1u >= r->hs.mesh_first_prim.size()) RT_FAIL("The mesh does not exist.");
+  const uint32_t first = r->hs.mesh_first_prim[mesh_index], end = r->hs.mesh_first_prim[mesh_index + 1u];
+  if (primitive_index >= end - first) RT_FAIL("The primitive does not exist.");
+  HostPrimitive& p = r->hs.prims[first + primitive_index];
+  if (vertex_count != p.vertices.size()) RT_FAIL("The vertex count differs from the primitive's (" + std::to_string(p.vertices.size()) + "): refit keeps the topology, use set_scene + commit.");
+  memcpy(p.vertices.data(), vertices, (size_t)vertex_count * sizeof(hala_vertex));
+  // the copy below reads the renderer's own host copy, which outlives it; earlier frames still read the arena: wait for them
+  RT_HIP(hipStreamSynchronize(r->stream));
+  if (vertex_count) RT_HIP(hipMemcpyAsync(r->d_vertices.ptr + r->prim_vertex_offset[first + primitive_index], p.vertices.data(), (size_t)vertex_count * sizeof(hala_vertex), hipMemcpyHostToDevice, r->stream));
+  return HALA_OK;
+}
 int hala_rt_refit(hala_rt_renderer* r) {
   if (ensure_device(r) != HALA_OK) return HALA_ERR;
   if (!r->committed) RT_FAIL("The top level acceleration structure is none!");

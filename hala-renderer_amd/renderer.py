@@ -241,6 +241,11 @@ class HalaRenderer:
         m = np.asarray(local_transform, dtype=np.float32)
         self._check(self._lib.hala_rt_update_node_transform(self._h, C.c_uint32(node_index), (C.c_float * 16)(*m.T.reshape(-1).tolist())))
 
+    def update_vertices(self, mesh_index, primitive_index, vertices):
+        """deforming geometry: new vertices (VERTEX_DTYPE records, same count) for one primitive; applied by the next refit()"""
+        v = np.ascontiguousarray(vertices, dtype=A.VERTEX_DTYPE)
+        self._check(self._lib.hala_rt_update_vertices(self._h, C.c_uint32(mesh_index), C.c_uint32(primitive_index), C.c_void_p(v.ctypes.data), C.c_uint32(v.shape[0])))
+
     def refit(self):
         self._check(self._lib.hala_rt_refit(self._h))
 

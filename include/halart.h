@@ -471,6 +471,11 @@ int hala_rt_download_bvh(hala_rt_renderer* r, void* nodes_64B, void* triangles_4
 /* Refit after vertex/transform edits (north_star "BVH build/refit"; the reference rebuilds only):
  * re-flattens instances with the given node local transforms and refits AABBs bottom-up on the GPU. */
 int hala_rt_update_node_transform(hala_rt_renderer* r, uint32_t node_index, const float local_transform[16]);
+/* Deforming geometry: replaces the vertices of primitive `primitive_index` of mesh `mesh_index` (indices into the scene handed
+ * to hala_rt_set_scene, cpu/mesh.rs: HalaMesh::primitives).  The vertex count must be the primitive's own (the topology, i.e. the
+ * index buffer, stays); host pointer, copied before the call returns.  Takes effect at the next hala_rt_refit. */
+int hala_rt_update_vertices(hala_rt_renderer* r, uint32_t mesh_index, uint32_t primitive_index, const hala_vertex* vertices,
+                            uint32_t vertex_count);
 int hala_rt_refit(hala_rt_renderer* r);
 
 /* ------------------------------------------------------------------------------------------------

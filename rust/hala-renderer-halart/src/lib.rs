@@ -84,6 +84,7 @@ pub mod sys {
     pub fn hala_rt_trace_rays_indirect(r: *mut hala_rt_renderer, d_rays: *const hala_ray, d_hits: *mut hala_hit, d_indirect: *const u32,
                                        mode: c_int, hip_stream: *mut c_void) -> c_int;
     pub fn hala_rt_update_node_transform(r: *mut hala_rt_renderer, node_index: u32, local_transform: *const f32) -> c_int;
+    pub fn hala_rt_update_vertices(r: *mut hala_rt_renderer, mesh_index: u32, primitive_index: u32, vertices: *const hala_vertex, vertex_count: u32) -> c_int;
     pub fn hala_rt_refit(r: *mut hala_rt_renderer) -> c_int;
     pub fn hala_rt_set_tile_shard(r: *mut hala_rt_renderer, rank: u32, world: u32, tile_size: u32) -> c_int;
     pub fn hala_rt_tile_buffer(r: *mut hala_rt_renderer, which: c_int, d_ptr: *mut *mut c_void, bytes: *mut usize) -> c_int;
@@ -191,6 +192,9 @@ impl HalaRenderer {
   // beyond the reference: refit + tile sharding (BASELINE.json north_star)
   pub fn update_node_transform(&mut self, node_index: u32, local: glam::Mat4) -> Result<(), HalaRendererError> {
     check(unsafe { sys::hala_rt_update_node_transform(self.h, node_index, local.to_cols_array().as_ptr()) })
+  }
+  pub fn update_vertices(&mut self, mesh_index: u32, primitive_index: u32, vertices: &[sys::hala_vertex]) -> Result<(), HalaRendererError> {
+    check(unsafe { sys::hala_rt_update_vertices(self.h, mesh_index, primitive_index, vertices.as_ptr(), vertices.len() as u32) })
   }
   pub fn refit(&mut self) -> Result<(), HalaRendererError> { check(unsafe { sys::hala_rt_refit(self.h) }) }
   pub fn set_tile_shard(&mut self, rank: u32, world: u32, tile_size: u32) -> Result<(), HalaRendererError> { check(unsafe { sys::hala_rt_set_tile_shard(self.h, rank, world, tile_size) }) }

@@ -297,6 +297,35 @@ def test_refit_after_node_transform(halart, oracle):
     r.close()
 
 
+def test_refit_after_vertex_deformation(halart, oracle):
+    """hala_rt_update_vertices + refit: a sheet of the atrium is rippled in place; the refitted tree must
+    bound the new triangles, and rays / a small render must match the oracle built from the deformed scene"""
+    s = scenes.sponza_class(target_triangles=20_000)
+    r = make_renderer(halart, s, 24, 16)
+    mesh = 3  # the first drape (scenes.sponza_class: columns 0-1, arch 2, drapes 3..)
+    v = s.meshes[mesh].primitives[0].vertices.copy()
+    pos = v["position"]
+    pos[:, 2] += (0.35 * np.sin(3.0 * pos[:, 0] + 1.7 * pos[:, 1])).astype(f32)
+    pos[:, 0] *= f32(1.1)
+    with pytest.raises(Exception):
+        r.update_vertices(mesh, 0, v[:-1])          # topology is kept: the count must match
+    with pytest.raises(Exception):
+        r.update_vertices(len(s.meshes), 0, v)
+    r.update_vertices(mesh, 0, v)
+    r.refit()
+    s.meshes[mesh].primitives[0].vertices = v
+    osc = oracle.OracleScene(s)
+    nodes, tris = r.download_bvh()
+    rc, _ = oracle.validate_bvh(nodes, tris, osc.triangles())
+    assert rc == 0
+    rays = osc.camera_rays(160, 96, 0)
+    assert r.trace_rays_host(rays, 0).tobytes() == osc.trace(rays, 0).tobytes()
+    r.update(); r.update(); r.render()
+    img, _ = osc.render(24, 16, frames=2)
+    assert r.read_image(0).tobytes() == img[0].tobytes()
+    r.close()
+
+
 def test_refit_without_change_reproduces_the_build(halart, oracle):
     """refit re-derives the 4-wide nodes level by level (k_refit_level) instead of fit + pack: with nothing moved the nodes, the
     triangle order and every box must come out byte for byte as the build (PLOC boxes for the large scene, k_fit for the small)"""
