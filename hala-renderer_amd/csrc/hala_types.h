@@ -29,6 +29,7 @@ namespace rt {
 
 constexpr uint32_t kAbsent = 0xffffffffu;
 constexpr float kTMax = 3.402823466e+38f;
+constexpr float kNoNeePdf = 1e18f;  // RENDER_SPEC 7.1f: power_heuristic(kNoNeePdf, b) == 1 for every pdf b a light or the env map reports
 
 // 64-B compressed BVH4 node (RENDER_SPEC §4.1b): up to four children in the bytes a plain BVH2 node would take.  Child boxes are
 // 8-bit quantised against the node's own box: lo = pmin + qlo * 2^e, hi = pmin + qhi * 2^e per axis (lo rounded down,

@@ -418,12 +418,33 @@ __global__ void __launch_bounds__(kShadeThreads, RT_SHADE_WAVES) k_shade(FrameCo
         }
       }
       T = T * sf.absorb;
-      bool through = false;
-      if (sf.mat.opacity < 1.0f) {  // §7.1d: the surface is skipped with probability 1 - opacity (one extra random number)
+      bool through = false, scattered = false;
+      if (sf.sigma > 0.0f) {  // §7.1f: free flight through a scattering medium; the surface is only reached if the flight outlasts the segment
+        const float rs = rng_next(rng);
+        const float dist = -log_poly(1.0f - rs) / sf.sigma;
+        if (dist < hv.x) {
+          const float r1 = rng_next(rng), r2 = rng_next(rng);
+          const f3 wi = hg_sample(d, sf.hg, r1, r2);
+          T = T * sf.scol;
+          prev_pdf = kNoNeePdf;  // no next-event estimation at a scattering vertex: an emitter reached next counts in full
+          bool alive = true;
+          if (depth >= fc.u.rr_depth) {
+            const float qq = minf(max3f(T), 0.95f);
+            const float rr = rng_next(rng);
+            if (!(rr < qq)) alive = false; else T = T * (1.0f / qq);
+          }
+          if (depth + 1u >= fc.u.max_depth) alive = false;
+          keep[0] = alive;
+          if (alive) { no = madd3(d, dist, o); nd = wi; }
+          scattered = true;
+        }
+      }
+      if (!scattered && sf.mat.opacity < 1.0f) {  // §7.1d: the surface is skipped with probability 1 - opacity (one extra random number)
         const float ro = rng_next(rng);
         through = !(ro < sf.mat.opacity);
       }
-      if (through) {
+      if (scattered) {
+      } else if (through) {
         const bool alive = depth + 1u < fc.u.max_depth;
         keep[0] = alive;
         if (alive) {

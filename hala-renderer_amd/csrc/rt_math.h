@@ -101,6 +101,22 @@ RT_DI float exp_neg_poly(float x) {
   p = __fmaf_rn(p, g, 1.0f);
   return p * __uint_as_float((uint32_t)((int)n + 127) << 23);
 }
+// ln x for a positive normal float (RENDER_SPEC §7.1f): x = m 2^e with m in [sqrt(1/2), sqrt 2); z = (m-1)/(m+1);
+// ln m = 2z (1 + z^2/3 + z^4/5 + z^6/7 + z^8/9) (|z| <= 0.172: truncation < 2e-9); ln x = fma(e, ln 2, ln m).
+RT_DI float log_poly(float x) {
+  const uint32_t b = __float_as_uint(x);
+  int e = (int)(b >> 23) - 127;
+  float m = __uint_as_float((b & 0x007fffffu) | 0x3f800000u);
+  if (m > 1.41421356237f) { m = m * 0.5f; e += 1; }
+  const float z = (m - 1.0f) / (m + 1.0f);
+  const float z2 = z * z;
+  float p = 0.11111111111111111f;
+  p = __fmaf_rn(p, z2, 0.14285714285714285f);
+  p = __fmaf_rn(p, z2, 0.2f);
+  p = __fmaf_rn(p, z2, 0.33333333333333333f);
+  p = __fmaf_rn(p, z2, 1.0f);
+  return __fmaf_rn((float)e, 0.69314718055994530942f, (2.0f * z) * p);
+}
 RT_DI float acos_poly(float x) {
   float ax = fabsf(x);
   if (ax > 1.0f) ax = 1.0f;
@@ -170,6 +186,23 @@ RT_DI f3 cosine_hemisphere(float u1, float u2) {
   float s, c;
   sincos_2pi(u2, &s, &c);
   return f3{r * c, r * s, sqrtf(maxf(0.0f, 1.0f - u1))};
+}
+// Henyey-Greenstein direction around the unit vector d (RENDER_SPEC §7.1f)
+RT_DI f3 hg_sample(f3 d, float g, float u1, float u2) {
+  g = minf(maxf(g, -0.99f), 0.99f);
+  float ct;
+  if (fabsf(g) < 1e-3f) ct = 1.0f - 2.0f * u1;
+  else {
+    const float q = (1.0f - g * g) / ((1.0f - g) + (2.0f * g) * u1);
+    ct = ((1.0f + g * g) - q * q) / (2.0f * g);
+  }
+  ct = minf(maxf(ct, -1.0f), 1.0f);
+  const float st = sqrtf(maxf(0.0f, 1.0f - ct * ct));
+  float s, c;
+  sincos_2pi(u2, &s, &c);
+  f3 t, b;
+  onb(d, &t, &b);
+  return to_world(f3{st * c, st * s, ct}, t, b, d);
 }
 RT_DI float luminance(f3 c) { return 0.212671f * c.x + 0.715160f * c.y + 0.072169f * c.z; }
 RT_DI float power_heuristic(float a, float b) {

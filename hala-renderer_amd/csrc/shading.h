@@ -484,6 +484,8 @@ struct Surface {
   f3 P, ns, ng;
   MatView mat;
   f3 absorb, glow;  // §7.1e: transmittance / emitted radiance of the medium the segment that ends here ran through
+  float sigma, hg;  // §7.1f: scattering coefficient (0: none) and Henyey-Greenstein g of that medium
+  f3 scol;          //        its single-scattering albedo
 };
 RT_DI f3 transform_vector(const float* m, f3 p) {
   return mk3(__fmaf_rn(m[8], p.z, __fmaf_rn(m[4], p.y, m[0] * p.x)), __fmaf_rn(m[9], p.z, __fmaf_rn(m[5], p.y, m[1] * p.x)),
@@ -573,6 +575,7 @@ RT_DI Surface make_surface(const SceneView& sv, float pixel_spread, f3 o, f3 d, 
   if (m.type == 1u) sf.mat.trans = m.specular_transmission * (1.0f - sf.mat.metallic);  // after the metallic map
   if (dot3(sf.ns, sf.ng) < 0.0f) sf.ng = -sf.ng;
   sf.absorb = splat3(1.0f); sf.glow = splat3(0.0f);
+  sf.sigma = 0.0f; sf.hg = 0.0f; sf.scol = splat3(1.0f);
   if (dot3(sf.ng, d) > 0.0f) {  // the path arrives from behind the surface: it is leaving the object
     sf.ns = -sf.ns; sf.ng = -sf.ng;
     sf.mat.eta = 1.0f / sf.mat.ior;
@@ -583,6 +586,9 @@ RT_DI Surface make_surface(const SceneView& sv, float pixel_spread, f3 o, f3 d, 
                       exp_neg_poly(-(dt * (1.0f - m.medium_color[2]))));
     else if (m.medium_type == 3u)  // EMISSIVE: colour * density per unit length
       sf.glow = mk3(m.medium_color[0] * dt, m.medium_color[1] * dt, m.medium_color[2] * dt);
+    else if (m.medium_type == 2u) {  // SCATTER (§7.1f): decided by the caller, which owns the random numbers
+      sf.sigma = m.medium_density; sf.hg = m.medium_anisotropy; sf.scol = mk3(m.medium_color[0], m.medium_color[1], m.medium_color[2]);
+    }
   }
   return sf;
 }

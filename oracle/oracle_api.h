@@ -192,6 +192,8 @@ void orc_scene_sample_texture(const orc_scene* s, uint32_t tex, const float* uvl
 void orc_probe_sincos_2pi(const float* u, float* s, float* c, size_t n);
 void orc_probe_acos(const float* x, float* out, size_t n);
 void orc_probe_exp_neg(const float* x, float* out, size_t n);
+void orc_probe_log(const float* x, float* out, size_t n);
+void orc_probe_hg(const float* d3, float g, const float* u1, const float* u2, float* out3, size_t n);
 void orc_probe_atan2(const float* y, const float* x, float* out, size_t n);
 void orc_probe_rng(uint32_t pixel_id, uint32_t frame_index, float* out, size_t n);
 

@@ -366,6 +366,10 @@ extern "C" size_t orc_pfm_bytes(const float* rgba, uint32_t width, uint32_t heig
 extern "C" void orc_probe_sincos_2pi(const float* u, float* s, float* c, size_t n) { for (size_t i = 0; i < n; ++i) sincos_2pi(u[i], &s[i], &c[i]); }
 extern "C" void orc_probe_acos(const float* x, float* out, size_t n) { for (size_t i = 0; i < n; ++i) out[i] = acos_poly(x[i]); }
 extern "C" void orc_probe_exp_neg(const float* x, float* out, size_t n) { for (size_t i = 0; i < n; ++i) out[i] = exp_neg_poly(x[i]); }
+extern "C" void orc_probe_log(const float* x, float* out, size_t n) { for (size_t i = 0; i < n; ++i) out[i] = log_poly(x[i]); }
+extern "C" void orc_probe_hg(const float* d3, float g, const float* u1, const float* u2, float* out3, size_t n) {
+  for (size_t i = 0; i < n; ++i) { V3 w = hg_sample(V3{d3[0], d3[1], d3[2]}, g, u1[i], u2[i]); out3[3 * i] = w.x; out3[3 * i + 1] = w.y; out3[3 * i + 2] = w.z; }
+}
 extern "C" void orc_probe_atan2(const float* y, const float* x, float* out, size_t n) { for (size_t i = 0; i < n; ++i) out[i] = atan2_poly(y[i], x[i]); }
 extern "C" void orc_probe_rng(uint32_t pixel_id, uint32_t frame_index, float* out, size_t n) {
   uint32_t s = rng_init(pixel_id, frame_index);

@@ -421,7 +421,7 @@ static float intersect_light(const orc_gpu_light& l, V3 o, V3 d, float* pdf) {
 }
 
 // ---- RENDER_SPEC §6 surface reconstruction ----------------------------------------------------------------------
-struct Surface { V3 P, ns, ng; orc_gpu_material m; V3 base; Trans tr; float opacity; V3 absorb, glow; };  // absorb / glow: §7.1e  // opacity: §7.1d, material x base-colour-map alpha  // m: the packed material after texture modulation
+struct Surface { V3 P, ns, ng; orc_gpu_material m; V3 base; Trans tr; float opacity; V3 absorb, glow; float sigma, hg; V3 scol; };  // sigma / hg / scol: §7.1f  // absorb / glow: §7.1e  // opacity: §7.1d, material x base-colour-map alpha  // m: the packed material after texture modulation
 
 static inline V3 transform_normal(const float* m, V3 n) {
   // inverse-transpose of the upper 3x3 = cofactor matrix / det; columns c0,c1,c2 of M
@@ -557,6 +557,7 @@ static Surface make_surface(const orc_scene* s, float pixel_spread, V3 o, V3 d, 
   if (sf.m.type == 1u) sf.tr.trans = sf.m.specular_transmission * (1.0f - sf.m.metallic);  // after the metallic map
   if (dot3(sf.ns, sf.ng) < 0.0f) sf.ng = -sf.ng;
   sf.absorb = v3s(1.0f); sf.glow = v3s(0.0f);
+  sf.sigma = 0.0f; sf.hg = 0.0f; sf.scol = v3s(1.0f);
   if (dot3(sf.ng, d) > 0.0f) {  // the path arrives from behind the surface: it is leaving the object
     sf.ns = -sf.ns; sf.ng = -sf.ng;
     sf.tr.eta = 1.0f / sf.m.ior;
@@ -567,12 +568,17 @@ static Surface make_surface(const orc_scene* s, float pixel_spread, V3 o, V3 d, 
                      exp_neg_poly(-(dt * (1.0f - pm.medium_color[2]))));
     else if (pm.medium_type == 3u)
       sf.glow = v3(pm.medium_color[0] * dt, pm.medium_color[1] * dt, pm.medium_color[2] * dt);
+    else if (pm.medium_type == 2u) {  // §7.1f SCATTER
+      sf.sigma = pm.medium_density; sf.hg = pm.medium_anisotropy; sf.scol = ld3(pm.medium_color);
+    }
   }
   return sf;
 }
 
 // ---- RENDER_SPEC §6 the path loop ----------------------------------------------------------------------------------
 struct PixelOut { V3 L, albedo, normal; };
+
+static const float kNoNeePdf = 1e18f;  // §7.1f: power_heuristic(kNoNeePdf, b) == 1 for every pdf b a light or the env map can report
 
 static PixelOut trace_path(const Frame& f, uint32_t px, uint32_t py, uint32_t frame_index, orc_render_stats* st, Counters* ctr) {
   const orc_scene* s = f.s;
@@ -616,6 +622,25 @@ static PixelOut trace_path(const Frame& f, uint32_t px, uint32_t py, uint32_t fr
     if (depth == 0) { out.albedo = sf.base; out.normal = sf.ns; }
     if (sf.glow.x > 0.0f || sf.glow.y > 0.0f || sf.glow.z > 0.0f) L = L + T * sf.glow;  // §7.1e, before the absorption of the same segment... (only one of the two is ever set)
     T = T * sf.absorb;
+    if (sf.sigma > 0.0f) {  // §7.1f: free flight through a scattering medium; the surface is only reached if the flight outlasts the segment
+      float rs = rng_next(&rng);
+      float dist = -log_poly(1.0f - rs) / sf.sigma;
+      if (dist < h.t) {
+        float r1 = rng_next(&rng), r2 = rng_next(&rng);
+        V3 wi = hg_sample(d, sf.hg, r1, r2);
+        T = T * sf.scol;
+        prev_pdf = kNoNeePdf;  // no next-event estimation at a scattering vertex: an emitter reached next counts in full
+        if (depth >= f.p.rr_depth) {
+          float q = minf(max3f(T), 0.95f);
+          float rr = rng_next(&rng);
+          if (!(rr < q)) break;
+          T = T * (1.0f / q);
+        }
+        o = madd3(d, dist, o);
+        d = wi;
+        continue;
+      }
+    }
     if (sf.opacity < 1.0f) {  // §7.1d: the surface is skipped with probability 1 - opacity (one extra random number, drawn only here)
       float ro = rng_next(&rng);
       if (!(ro < sf.opacity)) { o = madd3(sf.ng, -s->ray_eps, sf.P); continue; }

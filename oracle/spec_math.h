@@ -116,6 +116,25 @@ static inline float exp_neg_poly(float x) {
   memcpy(&scale, &bits, 4);
   return p * scale;
 }
+// ln x for a positive normal float (RENDER_SPEC 7.1f): x = m 2^e with m in [sqrt(1/2), sqrt 2); z = (m-1)/(m+1);
+// ln m = 2z (1 + z^2/3 + z^4/5 + z^6/7 + z^8/9); ln x = fma(e, ln 2, ln m).
+static inline float log_poly(float x) {
+  uint32_t b;
+  memcpy(&b, &x, 4);
+  int e = (int)(b >> 23) - 127;
+  uint32_t mb = (b & 0x007fffffu) | 0x3f800000u;
+  float m;
+  memcpy(&m, &mb, 4);
+  if (m > 1.41421356237f) { m = m * 0.5f; e += 1; }
+  const float z = (m - 1.0f) / (m + 1.0f);
+  const float z2 = z * z;
+  float p = 0.11111111111111111f;
+  p = fmaf(p, z2, 0.14285714285714285f);
+  p = fmaf(p, z2, 0.2f);
+  p = fmaf(p, z2, 0.33333333333333333f);
+  p = fmaf(p, z2, 1.0f);
+  return fmaf((float)e, 0.69314718055994530942f, (2.0f * z) * p);
+}
 // acos on [-1,1], Abramowitz & Stegun 4.4.46 (|err| <= 2e-8 before rounding)
 static inline float acos_poly(float x) {
   float ax = fabsf(x);
@@ -190,6 +209,23 @@ static inline V3 cosine_hemisphere(float u1, float u2) {
   float s, c;
   sincos_2pi(u2, &s, &c);
   return V3{r * c, r * s, sqrtf(maxf(0.0f, 1.0f - u1))};
+}
+// Henyey-Greenstein direction around the unit vector d (RENDER_SPEC 7.1f)
+static inline V3 hg_sample(V3 d, float g, float u1, float u2) {
+  g = minf(maxf(g, -0.99f), 0.99f);
+  float ct;
+  if (fabsf(g) < 1e-3f) ct = 1.0f - 2.0f * u1;
+  else {
+    const float q = (1.0f - g * g) / ((1.0f - g) + (2.0f * g) * u1);
+    ct = ((1.0f + g * g) - q * q) / (2.0f * g);
+  }
+  ct = minf(maxf(ct, -1.0f), 1.0f);
+  const float st = sqrtf(maxf(0.0f, 1.0f - ct * ct));
+  float sn, cs;
+  sincos_2pi(u2, &sn, &cs);
+  V3 t, b;
+  onb(d, &t, &b);
+  return to_world(V3{st * cs, st * sn, ct}, t, b, d);
 }
 static inline float luminance(V3 c) {
   // src/envmap.rs:249-251 and src/rt_renderer.rs:1257-1259: (0.212671*r + 0.715160*g) + 0.072169*b, no fma

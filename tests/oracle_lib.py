@@ -300,6 +300,20 @@ def probe_rng(pixel_id, frame_index, n):
     return o
 
 
+def probe_log(x):
+    x = np.ascontiguousarray(x, dtype=np.float32); o = np.empty_like(x)
+    lib().orc_probe_log(fptr(x), fptr(o), C.c_size_t(x.size))
+    return o
+
+
+def probe_hg(d, g, u1, u2):
+    d = np.ascontiguousarray(d, dtype=np.float32)
+    u1 = np.ascontiguousarray(u1, dtype=np.float32); u2 = np.ascontiguousarray(u2, dtype=np.float32)
+    o = np.empty((u1.size, 3), dtype=np.float32)
+    lib().orc_probe_hg(fptr(d), C.c_float(g), fptr(u1), fptr(u2), fptr(o), C.c_size_t(u1.size))
+    return o
+
+
 def probe_exp_neg(x):
     x = np.ascontiguousarray(x, dtype=np.float32); o = np.empty_like(x)
     lib().orc_probe_exp_neg(fptr(x), fptr(o), C.c_size_t(x.size))

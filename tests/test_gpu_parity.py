@@ -765,6 +765,29 @@ def test_render_media_bit_exact(halart, oracle, medium):
     r.close()
 
 
+@pytest.mark.parametrize("boundary", ["glass", "invisible"])
+def test_render_scattering_medium_bit_exact(halart, oracle, boundary):
+    """RENDER_SPEC 7.1f: free-flight sampling (polynomial log), Henyey-Greenstein scattering, no NEE at scattering vertices (the
+    next emitter hit counts in full) - inside a glass blob and inside an invisible (opacity 0) one, lights + env map, batched"""
+    env = scenes.sky_sun_envmap(64, 32, sun_gain=100.0)
+    s = scenes.bunny_class(subdivisions=3, aspect=80 / 48, disney=True)
+    med = H.HalaMedium(2, (0.95, 0.7, 0.4), 3.0, 0.6)
+    if boundary == "glass":
+        s.materials[0] = H.HalaMaterial(type=1, base_color=(1.0, 1.0, 1.0), metallic=0.0, roughness=0.15, specular_transmission=1.0, ior=1.45, medium=med)
+    else:
+        s.materials[0] = H.HalaMaterial(type=0, base_color=(1.0, 1.0, 1.0), roughness=0.5, opacity=0.0, medium=med)
+    r = make_renderer(halart, s, 80, 48, max_depth=24, rr_depth=3, env=env)
+    r.update(); r.update_batch(3); r.render()
+    imgs, st = oracle.OracleScene(s, envmap=env).render(80, 48, frames=4, max_depth=24, rr_depth=3)
+    assert_images_equal(r, imgs)
+    stg = r.statistics()
+    assert (stg.rays_closest_total, stg.rays_shadow_total) == (st.rays_closest, st.rays_shadow)
+    s.materials[0].medium = H.HalaMedium()
+    plain, _ = oracle.OracleScene(s, envmap=env).render(80, 48, frames=4, max_depth=24, rr_depth=3)
+    assert np.abs(plain[0][16:32, 30:50, :3] - imgs[0][16:32, 30:50, :3]).mean() > 0.005
+    r.close()
+
+
 @pytest.mark.parametrize("config", [3, 4])
 def test_large_configs_full_resolution_bit_exact(halart, oracle, config):
     """BASELINE configs[2] (82 k-triangle Disney blob under a 2048x1024 sun/sky map, MIS) and configs[3] (1 M-triangle atrium:

@@ -334,3 +334,63 @@ def test_absorbing_glass_tints_with_thickness(oracle):
     c, t = clear[12:20, 12:20, :3].mean(axis=(0, 1)), tinted[12:20, 12:20, :3].mean(axis=(0, 1))
     assert abs(t[0] - c[0]) < 0.03 * c[0]          # red passes untouched (sigma_r = 0)
     assert t[1] < 0.6 * c[1] and t[2] < 0.6 * c[2]  # green and blue are absorbed over ~2 radii
+
+
+def test_log_poly_accuracy(oracle):
+    """RENDER_SPEC §7.1f: the logarithm the free-flight sampling uses — no libm, same bits on CPU and GPU by construction"""
+    x = np.concatenate([np.linspace(2.0 ** -24, 1.0, 200001), np.logspace(-7.2, 0, 4001), np.logspace(0, 6, 1001)]).astype(f32)
+    got = oracle.probe_log(x).astype(np.float64)
+    want = np.log(x.astype(np.float64))
+    assert np.max(np.abs(got - want) / np.maximum(np.abs(want), 1e-6)) < 4e-7 or np.max(np.abs(got - want)) < 2e-7
+    assert np.max(np.abs(got - want)) < 2e-6  # absolute, over |ln x| <= 17
+    assert oracle.probe_log(np.array([1.0], dtype=f32))[0] == 0.0
+    k = np.arange(1, 2 ** 12, dtype=np.float64) * 2.0 ** -24  # the smallest arguments 1 - xi can take
+    assert np.all(np.isfinite(oracle.probe_log(k.astype(f32))))
+
+
+def test_hg_sample_statistics(oracle):
+    """unit vectors, mean cosine = g (the defining property of Henyey-Greenstein), isotropic at g = 0"""
+    rng = np.random.RandomState(3)
+    u1, u2 = rng.rand(200000).astype(f32), rng.rand(200000).astype(f32)
+    d = np.array([0.3, -0.5, 0.81], dtype=f32); d /= np.linalg.norm(d)
+    for g in (0.0, 0.6, -0.4, 0.95):
+        w = oracle.probe_hg(d, g, u1, u2).astype(np.float64)
+        assert np.max(np.abs(np.linalg.norm(w, axis=1) - 1.0)) < 1e-5
+        assert abs((w @ d.astype(np.float64)).mean() - g) < 5e-3
+
+
+def scatter_scene(density, colour=(1.0, 1.0, 1.0), g=0.0):
+    """a ball of scattering medium behind an invisible boundary (opacity 0, 7.1d: always passed straight through; the medium of
+    7.1e/f acts before the opacity test) - the glass model of 7.1c is kept out of these tests: it is not TIR-aware and loses
+    energy for light that reaches the boundary from inside at steep angles, which is what a scattering interior produces"""
+    s = furnace_scene()
+    s.materials = [H.HalaMaterial(type=0, base_color=(1.0, 1.0, 1.0), roughness=0.5, opacity=0.0, medium=H.HalaMedium(2, colour, density, g))]
+    return s
+
+
+FURNACE = dict(frames=64, max_depth=64, rr_depth=255, ground=(0.7,) * 3 + (1,), sky=(0.7,) * 3 + (1,))
+
+
+def test_scattering_medium_white_furnace(oracle):
+    """7.1f: a non-absorbing scattering medium only redirects light: in a uniform environment every pixel still sees the environment
+    radiance - thin and thick media, isotropic and forward-peaked phase functions; what is lost is the max_depth cut-off"""
+    for density, g in ((0.5, 0.0), (2.0, 0.0), (2.0, 0.7), (3.0, -0.3)):
+        img = oracle.OracleScene(scatter_scene(density, g=g)).render(32, 32, **FURNACE)[0][0]
+        assert abs(img[10:22, 10:22, :3].mean() - 0.7) < 0.01, (density, g, img[10:22, 10:22, :3].mean())
+
+
+def test_scattering_medium_albedo_darkens(oracle):
+    """single-scattering albedo < 1 in one channel: that channel loses energy at every scattering event, the others do not;
+    a denser ball scatters more often and gets darker in that channel"""
+    c1 = oracle.OracleScene(scatter_scene(1.0, colour=(1.0, 0.5, 1.0))).render(32, 32, **FURNACE)[0][0][10:22, 10:22, :3].mean(axis=(0, 1))
+    c3 = oracle.OracleScene(scatter_scene(3.0, colour=(1.0, 0.5, 1.0))).render(32, 32, **FURNACE)[0][0][10:22, 10:22, :3].mean(axis=(0, 1))
+    for c in (c1, c3):
+        assert abs(c[0] - 0.7) < 0.01 and abs(c[2] - 0.7) < 0.01
+    assert c3[1] < c1[1] < 0.62
+
+
+def test_scattering_medium_blurs_the_horizon(oracle):
+    """a dense ball in front of a black ground / white sky: the pixels through the ball see a mix instead of the sharp horizon"""
+    img = oracle.OracleScene(scatter_scene(6.0)).render(32, 32, frames=64, max_depth=64, rr_depth=255, ground=(0, 0, 0, 1), sky=(1, 1, 1, 1))[0][0]
+    centre = img[12:20, 12:20, 0]
+    assert 0.1 < centre.mean() < 0.9 and centre.std() < 0.3
