@@ -211,7 +211,12 @@ RT_DI DisneyLobes disney_lobes(const MatView& m, float nv) {
   float wd = (1.0f - m.metallic) * lb * (1.0f - m.trans);
   float ws = luminance(mix3(d.cspec0, splat3(1.0f), fv));
   float wc = 0.25f * m.clearcoat * mixf(0.04f, 1.0f, fv);
-  float wt = m.trans * (1.0f - mixf(f0, 1.0f, fv));
+  float wt = 0.0f;
+  if (m.trans > 0.0f) {  // §7.1c: the transmissive share reflects by the exact dielectric Fresnel term (1 beyond the critical angle)
+    const float fe = fresnel_dielectric(nv, m.eta);
+    ws = mixf(ws, fe, m.trans);
+    wt = m.trans * (1.0f - fe);
+  }
   float sum = wd + ws + wc + wt;
   if (!(sum > 0.0f)) { d.pd = d.ps = d.pc = d.pt = 0.0f; return d; }
   float inv = 1.0f / sum;
@@ -254,6 +259,7 @@ RT_DI void disney_eval(const MatView& m, f3 wo, f3 wi, f3 n, f3* f, float* pdf) 
   float fd = mixf(1.0f, fd90, fl) * mixf(1.0f, fd90, fv);
   float dw = (1.0f - m.metallic) * (1.0f - m.trans);
   f3 fs = mix3(d.cspec0, splat3(1.0f), fh);
+  if (m.trans > 0.0f) fs = mix3(fs, splat3(fresnel_dielectric(ldh, m.eta)), m.trans);  // §7.1c: pairs with the (1 - F) of the refraction lobe
   f3 fr = m.base * (splat3(1.0f) - fs) * (kInvPi * fd * dw) + d.csheen * (m.sheen * fh * dw);
   float ds = ggx_d(h, m.ax, m.ay);
   float g1o = ggx_g1(lo, m.ax, m.ay), g1i = ggx_g1(li, m.ax, m.ay);

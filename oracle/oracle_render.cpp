@@ -201,7 +201,12 @@ static inline DisneyLobes disney_lobes(const orc_gpu_material& m, V3 base, Trans
   float wd = (1.0f - m.metallic) * lb * (1.0f - tr.trans);
   float ws = luminance(mix3(d.cspec0, v3s(1.0f), fv));
   float wc = 0.25f * m.clearcoat * mixf(0.04f, 1.0f, fv);
-  float wt = tr.trans * (1.0f - mixf(f0, 1.0f, fv));
+  float wt = 0.0f;
+  if (tr.trans > 0.0f) {  // §7.1c: the transmissive share reflects by the exact dielectric Fresnel term (1 beyond the critical angle)
+    float fe = fresnel_dielectric(nv, tr.eta);
+    ws = mixf(ws, fe, tr.trans);
+    wt = tr.trans * (1.0f - fe);
+  }
   float sum = wd + ws + wc + wt;
   if (!(sum > 0.0f)) { d.pd = d.ps = d.pc = d.pt = 0.0f; return d; }
   float inv = 1.0f / sum;
@@ -245,6 +250,7 @@ static inline void disney_eval(const orc_gpu_material& m, V3 base, Trans tr, V3 
   float fd = mixf(1.0f, fd90, fl) * mixf(1.0f, fd90, fv);
   float dw = (1.0f - m.metallic) * (1.0f - tr.trans);
   V3 fs = mix3(d.cspec0, v3s(1.0f), fh);  // specular Fresnel; the diffuse lobe only gets what it lets through
+  if (tr.trans > 0.0f) fs = mix3(fs, v3s(fresnel_dielectric(ldh, tr.eta)), tr.trans);  // §7.1c: pairs with the (1 - F) of the refraction lobe
   V3 fr = base * (v3s(1.0f) - fs) * (kInvPi * fd * dw) + d.csheen * (m.sheen * fh * dw);
   // specular
   float ds = ggx_d(h, m.ax, m.ay);

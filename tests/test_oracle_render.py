@@ -361,8 +361,7 @@ def test_hg_sample_statistics(oracle):
 
 def scatter_scene(density, colour=(1.0, 1.0, 1.0), g=0.0):
     """a ball of scattering medium behind an invisible boundary (opacity 0, 7.1d: always passed straight through; the medium of
-    7.1e/f acts before the opacity test) - the glass model of 7.1c is kept out of these tests: it is not TIR-aware and loses
-    energy for light that reaches the boundary from inside at steep angles, which is what a scattering interior produces"""
+    7.1e/f acts before the opacity test): a bare participating medium"""
     s = furnace_scene()
     s.materials = [H.HalaMaterial(type=0, base_color=(1.0, 1.0, 1.0), roughness=0.5, opacity=0.0, medium=H.HalaMedium(2, colour, density, g))]
     return s
@@ -394,3 +393,15 @@ def test_scattering_medium_blurs_the_horizon(oracle):
     img = oracle.OracleScene(scatter_scene(6.0)).render(32, 32, frames=64, max_depth=64, rr_depth=255, ground=(0, 0, 0, 1), sky=(1, 1, 1, 1))[0][0]
     centre = img[12:20, 12:20, 0]
     assert 0.1 < centre.mean() < 0.9 and centre.std() < 0.3
+
+
+def test_glass_is_energy_conserving_from_inside(oracle):
+    """§7.1c: the transmissive share of the specular lobe reflects by the exact dielectric Fresnel term, so light that reaches a glass
+    boundary from inside beyond the critical angle is totally reflected instead of lost: a glass ball stays a white furnace even
+    when a scattering interior sends light at the boundary from every direction (a Schlick-weighted lobe gave 0.63 / 0.47 here)"""
+    for density in (0.0, 0.5, 3.0):
+        s = furnace_scene()
+        kw = dict(type=1, base_color=(1.0, 1.0, 1.0), metallic=0.0, roughness=0.05, specular_transmission=1.0, ior=1.3)
+        s.materials = [H.HalaMaterial(medium=H.HalaMedium(2, (1.0, 1.0, 1.0), density, 0.0), **kw)]
+        img = oracle.OracleScene(s).render(32, 32, **FURNACE)[0][0]
+        assert abs(img[10:22, 10:22, :3].mean() - 0.7) < 0.01, density
