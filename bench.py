@@ -24,6 +24,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 BASE_W, BASE_H, SPP, MAX_DEPTH, RR_DEPTH, TILE = 1920, 1080, 4, 5, 3, 32
+TIMING_PERIOD = 4  # per-launch HIP events on every 4th frame of the timed region (see main())
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -107,6 +108,12 @@ def main():
         r.set_tile_shard(rank, world, TILE)
     r.set_scene(scene)
     r.commit()
+    # Per-launch HIP events (the roofline's avg_launch_ms) cost ~22 barrier packets = 70 us of the 2.25 ms frame: they are recorded
+    # on every TIMING_PERIOD-th frame of the timed region (still live, still inside it), not on all of them.
+    timing_period = TIMING_PERIOD if args.steps >= 2 * TIMING_PERIOD else 1
+    if os.environ.get("BENCH_TIMING_PERIOD"):  # A/B knob
+        timing_period = int(os.environ["BENCH_TIMING_PERIOD"])
+    r.set_launch_timing_period(timing_period)
 
     gather = None
     sync_gather = bool(os.environ.get("BENCH_SYNC_GATHER"))
@@ -173,9 +180,11 @@ def main():
     primary_launches = s1.traverse_primary_launches - s0.traverse_primary_launches
     shadow_ms = s1.traverse_shadow_ms_total - s0.traverse_shadow_ms_total
     shadow_launches = s1.traverse_shadow_launches - s0.traverse_shadow_launches
-    rays_closest = s1.rays_closest_total - s0.rays_closest_total
-    rays_primary = s1.rays_primary_total - s0.rays_primary_total
-    rays_shadow = s1.rays_shadow_total - s0.rays_shadow_total
+    # rays of the frames whose launches were timed (all of them when timing_period == 1)
+    rays_closest = s1.rays_closest_timed - s0.rays_closest_timed
+    rays_primary = s1.rays_primary_timed - s0.rays_primary_timed
+    rays_shadow = s1.rays_shadow_timed - s0.rays_shadow_timed
+    r.set_launch_timing_period(1)
     r.set_counting(True)
     c0 = r.statistics()
     step()
@@ -229,7 +238,8 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_GBps": (round(traffic / (avg_launch_ms * 1e-3) / 1e9, 1) if traffic and avg_launch_ms > 0 else None),
                          "note": "achieved = ALGORITHMIC bytes (SURVEY 8d formula, 64 B per 4-wide node) / launch time, both per launch of this "
-                                 "kernel symbol; avg_launch_ms is measured with HIP events on the renderer's stream and agrees with the "
+                                 "kernel symbol; avg_launch_ms is measured with HIP events on the renderer's stream, inside the timed region, "
+                                 "on every `timing_period`-th frame (`launches` = the launches so measured) and agrees with the "
                                  "rocprofv3 --kernel-trace --stats average in profiles/. For this 32-triangle scene the whole BVH (6 nodes + "
                                  "32 triangles = 1.9 KB) is staged in LDS, so node/triangle bytes never reach HBM: `traffic` (PMC FETCH_SIZE*2 "
                                  "+ WRITE_SIZE per launch, profiles/traffic_closest.json) is just the ray-queue read + hit write, and frac can "
@@ -238,7 +248,7 @@ def main():
                                  "for the 82 k and 1 M triangle scenes, where the nodes do come from L2 / Infinity Cache / HBM.",
                          "bytes_per_ray": round(bytes_per_ray, 1), "nodes_per_ray": round(nodes_per_ray, 3),
                          "tris_per_ray": round(tris_per_ray, 3), "avg_launch_ms": round(avg_launch_ms, 5),
-                         "launches": int(batch_launches), "rays_per_launch": round(rays_per_launch, 1),
+                         "launches": int(batch_launches), "timing_period": timing_period, "rays_per_launch": round(rays_per_launch, 1),
                          "grays_per_s_in_kernel": round(rays_bounce / max(batch_ms, 1e-9) / 1e6, 3),
                          "simt": simt, "valu": valu,
                          "primary_kernel": {"kernel": "rt::k_trace_primary<false, true> (depth 0: camera rays generated in the lanes that trace them, 16 B hit write per ray)",

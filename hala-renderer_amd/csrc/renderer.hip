@@ -158,6 +158,8 @@ struct hala_rt_renderer {
   hala_global_uniform last_uniform{};
   TraceEvents ring[kStatRing];
   int ring_pos = 0;
+  uint32_t launch_event_period = 1;  // per-launch timing events on every n-th update (hala_rt_set_launch_timing_period)
+  unsigned long long update_counter = 0;
   hala_rt_statistics stats{};
 
   ~hala_rt_renderer() {
@@ -242,6 +244,10 @@ struct hala_rt_renderer {
     stats.rays_closest_total += rc;
     stats.rays_primary_total += (unsigned long long)real_pixels * t.samples;
     stats.rays_shadow_total += rs;
+    if (t.used > 0) {
+      stats.rays_closest_timed += rc; stats.rays_shadow_timed += rs;
+      stats.rays_primary_timed += (unsigned long long)real_pixels * t.samples;
+    }
     if (t.counted) {
       stats.nodes_closest_total += t.host_counts[2]; stats.tris_closest_total += t.host_counts[3];
       stats.nodes_shadow_total += t.host_counts[4]; stats.tris_shadow_total += t.host_counts[5];
@@ -492,6 +498,7 @@ int hala_rt_create(const char* name, uint32_t width, uint32_t height, int device
   if (device_ordinal < 0 || device_ordinal >= count) RT_FAIL("The requested device ordinal does not exist.");
   RT_HIP(hipSetDevice(device_ordinal));
   std::unique_ptr<hala_rt_renderer> r(new hala_rt_renderer());
+  if (const char* ev = getenv("HALART_EVENT_PERIOD")) r->launch_event_period = (uint32_t)std::max(0, atoi(ev));  // tuning knob
   r->name = name ? name : "";
   r->width = width; r->height = height; r->device = device_ordinal;
   r->max_depth = max_depth; r->rr_depth = rr_depth;
@@ -656,23 +663,25 @@ static int update_impl(hala_rt_renderer* r, uint32_t frames) {
   hipStream_t s = r->stream;
   RT_HIP(hipEventRecord(te.frame_begin, s));
   RT_HIP(hipMemsetAsync(ctl, 0, sizeof(Control), s));
+  // per-launch HIP events (statistics: traverse_*_ms_total) on every launch_event_period-th update; each record is a barrier
+  // packet on the stream, i.e. a few microseconds between two launches
+  const bool timed = r->launch_event_period == 1u || (r->launch_event_period > 1u && (r->update_counter % r->launch_event_period) == 0u);
+  r->update_counter++;
   for (uint32_t depth = 0; depth < r->max_depth; ++depth) {
-    hipEvent_t a = r->next_event(te), b = r->next_event(te);
-    RT_HIP(hipEventRecord(a, s));
+    if (timed) { hipEvent_t a = r->next_event(te); RT_HIP(hipEventRecord(a, s)); }
     // depth 0: the camera rays are generated inside the traversal kernel, there is no ray-generation pass
     if (depth == 0) {
       launch_trace_primary(r->lcfg, sv, fc, q.hits, &ctl->work_closest, ctl, r->real_pixels * samples, r->counting, s);
       if (r->counting) RT_HIP(hipMemcpyAsync(ctl->primary_steps, ctl->steps[0], 16, hipMemcpyDeviceToDevice, s));
     }
     else launch_trace_batch(r->lcfg, sv, q.rays[depth & 1u], q.hits, &ctl->n_active[depth], 0, &ctl->work_closest, ctl, false, r->counting, true, s);
-    RT_HIP(hipEventRecord(b, s));
+    if (timed) { hipEvent_t b = r->next_event(te); RT_HIP(hipEventRecord(b, s)); }
     launch_shade(fc, sv, q, ps, ctl, depth, s);
-    hipEvent_t c = r->next_event(te), d = r->next_event(te);
-    RT_HIP(hipEventRecord(c, s));
+    if (timed) { hipEvent_t c = r->next_event(te); RT_HIP(hipEventRecord(c, s)); }
     // light connections first, environment connections second: contributions land in spec order (RENDER_SPEC §6)
     if (u.num_of_lights > 0) launch_trace_shadow(r->lcfg, sv, q, ps, ctl, depth, 0, r->counting, s);
     if (u.env_type == 1u) launch_trace_shadow(r->lcfg, sv, q, ps, ctl, depth, 1, r->counting, s);
-    RT_HIP(hipEventRecord(d, s));
+    if (timed) { hipEvent_t d = r->next_event(te); RT_HIP(hipEventRecord(d, s)); }
   }
   launch_resolve(fc, ps, r->img_local[0].ptr, r->img_local[1].ptr, r->img_local[2].ptr, r->img_local[3].ptr, s);
   RT_HIP(hipMemcpyAsync(te.host_counts, &ctl->rays_closest, 14 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
@@ -753,6 +762,12 @@ int hala_rt_get_statistics(hala_rt_renderer* r, hala_rt_statistics* out) {
 int hala_rt_reset_accumulation(hala_rt_renderer* r) {
   if (!r) RT_FAIL("The renderer handle is null!");
   r->reset_accumulation();
+  return HALA_OK;
+}
+int hala_rt_set_launch_timing_period(hala_rt_renderer* r, uint32_t period) {
+  if (!r) RT_FAIL("The renderer handle is null!");
+  r->launch_event_period = period;
+  r->update_counter = 0;
   return HALA_OK;
 }
 int hala_rt_set_counting(hala_rt_renderer* r, int enable) {

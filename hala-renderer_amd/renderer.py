@@ -154,6 +154,10 @@ class HalaRenderer:
         """count BVH nodes visited / triangles tested in update() (inputs of the algorithmic-bytes figure)"""
         self._check(self._lib.hala_rt_set_counting(self._h, C.c_int(bool(enable))))
 
+    def set_launch_timing_period(self, period):
+        """per-launch HIP events on every `period`-th update (1: all, the default; 0: none) — see include/halart.h"""
+        self._check(self._lib.hala_rt_set_launch_timing_period(self._h, C.c_uint32(period)))
+
     # -- read-back used by tests and bench (what save_images downloads, :1239-1254) -------------------------------
     ACCUM, ALBEDO, NORMAL, FINAL = 0, 1, 2, 3
 

@@ -383,6 +383,9 @@ typedef struct hala_rt_statistics {
   uint64_t traverse_primary_launches;
   uint64_t nodes_primary_total, tris_primary_total, rays_primary_counted; /* counting launches, camera rays only */
   uint64_t rays_primary_total; /* camera rays of all updates (part of rays_closest_total) */
+  /* rays of the updates whose launches carried timing events (hala_rt_set_launch_timing_period): the rays the
+   * traverse_*_ms_total / *_launches figures belong to.  Equal to the *_total fields while every update is timed. */
+  uint64_t rays_closest_timed, rays_primary_timed, rays_shadow_timed;
 } hala_rt_statistics;
 int hala_rt_get_info(hala_rt_renderer* r, hala_rt_info* out);
 int hala_rt_get_statistics(hala_rt_renderer* r, hala_rt_statistics* out);
@@ -393,6 +396,10 @@ int hala_rt_reset_accumulation(hala_rt_renderer* r);
 /* enable = 1: update() launches the counting variants of the traversal kernels (BVH nodes visited and
  * triangles tested per ray — the inputs of the algorithmic-bytes figure). Slower; off by default. */
 int hala_rt_set_counting(hala_rt_renderer* r, int enable);
+/* Per-launch timing (the traverse_*_ms_total statistics) brackets every traversal launch with two HIP events, i.e. ~22 barrier
+ * packets per update (70 us of a 2.25 ms frame on MI355X).  period = 1 (default): every update is timed; n > 1: every n-th;
+ * 0: none.  The frame-level figures (last_gpu_ms, gpu_ms_total, ray counts) are always collected. */
+int hala_rt_set_launch_timing_period(hala_rt_renderer* r, uint32_t period);
 /* the 112-B record the last update uploaded (src/rt_renderer.rs:408-427) */
 int hala_rt_get_global_uniform(hala_rt_renderer* r, hala_global_uniform* out);
 
