@@ -558,7 +558,9 @@ __global__ void __launch_bounds__(256) k_resolve(FrameConst fc, PathState ps, fl
                                                   float4* __restrict__ normal, float4* __restrict__ final_img) {
   const uint32_t pslot = blockIdx.x * blockDim.x + threadIdx.x;
   if (pslot >= fc.pixel_slots) return;
-  float4 a = accum[pslot], b = albedo[pslot], n = normal[pslot];
+  // the running means; a batch that starts an accumulation (frame_index 0) never looks at them (fold_mean)
+  float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f), b = a, n = a;
+  if (fc.u.frame_index != 0u) { a = accum[pslot]; b = albedo[pslot]; n = normal[pslot]; }
   for (uint32_t k = 0; k < fc.samples; ++k) {  // the batch's samples, folded in frame order
     const uint32_t slot = k * fc.pixel_slots + pslot;
     const float4 lr = ps.radiance[slot];
