@@ -153,11 +153,12 @@ struct Control {
 };
 
 // per-path records indexed by path slot (everything a live path needs from bounce to bounce travels in its queue entry)
+struct P3 { float x, y, z; };  // 12-B per-path record: one dwordx3 load / store, no padding word to move
 struct PathState {
-  float4* radiance;        // L.xyz of the path: set by the depth-0 shade, added to by later shades (rarely: light hit,
+  P3* radiance;            // L of the path: set by the depth-0 shade, added to by later shades (rarely: light hit,
                            // environment, emission) and by the shadow passes
-  float4* albedo;          // first-hit AOVs of this sample
-  float4* normal;
+  P3* albedo;              // first-hit AOVs of this sample
+  P3* normal;
 };
 
 struct ShadowEntry {  // 48 B: one NEE connection = shadow ray + the contribution it carries if unoccluded

@@ -228,7 +228,7 @@ struct ShadowSource {
   // contribution.xyz | pixel slot, fetched with the ray (one coalesced 48-B record), and the path's radiance as it stands
   struct Payload { float4 cs; float lx, ly, lz; };
   const ShadowEntry* entries;
-  float4* radiance;
+  P3* radiance;
   // A path owns at most one connection per queue and the two queues are traced by separate launches, so nothing else touches this
   // path's radiance during the launch: it is fetched here, behind the entry (the load is in flight while the ray is traced), and
   // an unoccluded ray stores radiance + contribution — one IEEE add per component, no ordering freedom.  (Three memory-side float
@@ -353,9 +353,9 @@ __global__ void __launch_bounds__(kShadeThreads, RT_SHADE_WAVES) k_shade(FrameCo
     slot = i;
     real = primary_ray(fc, sv, slot, &o, &d, &rng);
     if (!real) {  // resolve reads every slot of the rank's tile buffer
-      ps.radiance[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      ps.albedo[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      ps.normal[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      ps.radiance[slot] = P3{0.0f, 0.0f, 0.0f};
+      ps.albedo[slot] = P3{0.0f, 0.0f, 0.0f};
+      ps.normal[slot] = P3{0.0f, 0.0f, 0.0f};
     }
   }
   if (real) {
@@ -387,8 +387,8 @@ __global__ void __launch_bounds__(kShadeThreads, RT_SHADE_WAVES) k_shade(FrameCo
       if (!PRIMARY) w = power_heuristic(prev_pdf, light_pdf * (1.0f / (float)nl));
       L = L + T * le * w;
       if (PRIMARY) {
-        ps.albedo[slot] = make_float4(minf(le.x, 1.0f), minf(le.y, 1.0f), minf(le.z, 1.0f), 1.0f);
-        ps.normal[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        ps.albedo[slot] = P3{minf(le.x, 1.0f), minf(le.y, 1.0f), minf(le.z, 1.0f)};
+        ps.normal[slot] = P3{0.0f, 0.0f, 0.0f};
       }
     } else if (hit_prim == kAbsent) {
       f3 env;
@@ -399,22 +399,22 @@ __global__ void __launch_bounds__(kShadeThreads, RT_SHADE_WAVES) k_shade(FrameCo
       } else env = sky_eval(fc, d);
       L = L + T * env * w;
       if (PRIMARY) {
-        ps.albedo[slot] = make_float4(minf(env.x, 1.0f), minf(env.y, 1.0f), minf(env.z, 1.0f), 1.0f);
-        ps.normal[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        ps.albedo[slot] = P3{minf(env.x, 1.0f), minf(env.y, 1.0f), minf(env.z, 1.0f)};
+        ps.normal[slot] = P3{0.0f, 0.0f, 0.0f};
       }
     } else {
       const Surface sf = make_surface(sv, fc.pixel_spread, o, d, hv.x, hv.y, hv.z, hit_prim);
       if (PRIMARY) {
-        ps.albedo[slot] = make_float4(sf.mat.base.x, sf.mat.base.y, sf.mat.base.z, 1.0f);
-        ps.normal[slot] = make_float4(sf.ns.x, sf.ns.y, sf.ns.z, 1.0f);
+        ps.albedo[slot] = P3{sf.mat.base.x, sf.mat.base.y, sf.mat.base.z};
+        ps.normal[slot] = P3{sf.ns.x, sf.ns.y, sf.ns.z};
       }
       // §7.1e: what the medium of an object just crossed did to the segment that ends here (identity for every other hit)
       if (sf.glow.x > 0.0f || sf.glow.y > 0.0f || sf.glow.z > 0.0f) {
         const f3 g = T * sf.glow;
         if (PRIMARY) L = L + g;
         else {  // a second term may follow in this bounce (emission): this one goes to the path's radiance right away, in order
-          const float4 l = ps.radiance[slot];
-          ps.radiance[slot] = make_float4(l.x + g.x, l.y + g.y, l.z + g.z, 0.0f);
+          const P3 l = ps.radiance[slot];
+          ps.radiance[slot] = P3{l.x + g.x, l.y + g.y, l.z + g.z};
         }
       }
       T = T * sf.absorb;
@@ -524,10 +524,10 @@ __global__ void __launch_bounds__(kShadeThreads, RT_SHADE_WAVES) k_shade(FrameCo
       }
       }  // !through
     }
-    if (PRIMARY) ps.radiance[slot] = make_float4(L.x, L.y, L.z, 0.0f);
+    if (PRIMARY) ps.radiance[slot] = P3{L.x, L.y, L.z};
     else if (L.x != 0.0f || L.y != 0.0f || L.z != 0.0f) {  // radiance += term (this launch touches the word once: a plain update)
-      const float4 l = ps.radiance[slot];
-      ps.radiance[slot] = make_float4(l.x + L.x, l.y + L.y, l.z + L.z, 0.0f);
+      const P3 l = ps.radiance[slot];
+      ps.radiance[slot] = P3{l.x + L.x, l.y + L.y, l.z + L.z};
     }
     rng_out = rng;
     state_out = make_float4(T.x, T.y, T.z, prev_pdf);
@@ -563,11 +563,11 @@ __global__ void __launch_bounds__(256) k_resolve(FrameConst fc, PathState ps, fl
   if (fc.u.frame_index != 0u) { a = accum[pslot]; b = albedo[pslot]; n = normal[pslot]; }
   for (uint32_t k = 0; k < fc.samples; ++k) {  // the batch's samples, folded in frame order
     const uint32_t slot = k * fc.pixel_slots + pslot;
-    const float4 lr = ps.radiance[slot];
+    const P3 lr = ps.radiance[slot];
     f3 L = mk3(lr.x, lr.y, lr.z);
     if (!(isfinite(L.x) && isfinite(L.y) && isfinite(L.z))) L = splat3(0.0f);
     const uint32_t fi = fc.u.frame_index + k;
-    const float4 sa = ps.albedo[slot], sn = ps.normal[slot];
+    const P3 sa = ps.albedo[slot], sn = ps.normal[slot];
     a = make_float4(fold_mean(a.x, L.x, fi), fold_mean(a.y, L.y, fi), fold_mean(a.z, L.z, fi), 1.0f);
     b = make_float4(fold_mean(b.x, sa.x, fi), fold_mean(b.y, sa.y, fi), fold_mean(b.z, sa.z, fi), 1.0f);
     n = make_float4(fold_mean(n.x, sn.x, fi), fold_mean(n.y, sn.y, fi), fold_mean(n.z, sn.z, fi), 1.0f);

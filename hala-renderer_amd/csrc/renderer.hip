@@ -145,7 +145,7 @@ struct hala_rt_renderer {
   DeviceArray<float4> img_local[4];  // accum, albedo, normal, final (slot order)
   DeviceArray<float4> img_full[4];   // row-major, only after scatter_gathered_tiles (world > 1)
   bool full_valid[4] = {false, false, false, false};
-  DeviceArray<float4> ps_lr, ps_alb, ps_nrm;
+  DeviceArray<P3> ps_lr, ps_alb, ps_nrm;
   DeviceArray<hala_ray> q_rays[2];
   DeviceArray<float4> q_state[2];
   DeviceArray<hala_hit> q_hits;
