@@ -707,7 +707,12 @@ int hala_rt_update_batch(hala_rt_renderer* r, uint32_t frames) {
 int hala_rt_render(hala_rt_renderer* r) {  // src/rt_renderer.rs:475-502: nothing to present; make the frame's work visible
   if (ensure_device(r) != HALA_OK) return HALA_ERR;
   if (r->total_frames > r->max_frames) return HALA_OK;  // :484-486
-  RT_HIP(hipStreamSynchronize(r->stream));
+  // submit_and_present_frame hands the frame to the queue and only blocks on the fence of the swapchain image it reuses: with no
+  // swapchain here, render() bounds the updates in flight to two (it waits for the update before the latest), so the host can
+  // enqueue the next frame while this one runs.  Everything that reads results (read_image, save_images, statistics, wait_idle,
+  // tile_buffer users via wait_idle) synchronises on its own.
+  const TraceEvents& before_last = r->ring[(r->ring_pos + kStatRing - 2) % kStatRing];
+  if (before_last.pending && before_last.frame_end) RT_HIP(hipEventSynchronize(before_last.frame_end));
   return HALA_OK;
 }
 int hala_rt_wait_idle(hala_rt_renderer* r) {
@@ -877,6 +882,12 @@ int hala_rt_tile_buffer(hala_rt_renderer* r, int which, void** d_ptr, size_t* by
   *bytes = (size_t)r->slot_count * sizeof(float4);
   return HALA_OK;
 }
+int hala_rt_get_stream(hala_rt_renderer* r, void** hip_stream) {
+  if (!hip_stream) RT_FAIL("Invalid argument.");
+  if (ensure_device(r) != HALA_OK) return HALA_ERR;
+  *hip_stream = static_cast<void*>(r->stream);
+  return HALA_OK;
+}
 int hala_rt_scatter_gathered_tiles(hala_rt_renderer* r, int which, const void* d_gathered, size_t bytes) {
   if (ensure_device(r) != HALA_OK) return HALA_ERR;
   if (which < 0 || which > 3 || !d_gathered) RT_FAIL("Invalid argument.");
@@ -885,8 +896,8 @@ int hala_rt_scatter_gathered_tiles(hala_rt_renderer* r, int which, const void* d
   RT_HIP(r->img_full[which].resize((size_t)r->width * r->height));
   hala_global_uniform u = r->last_uniform;
   const FrameConst fc = r->frame_const(u);
-  launch_scatter_tiles(fc, static_cast<const float4*>(d_gathered), r->img_full[which].ptr, r->stream);
-  RT_HIP(hipStreamSynchronize(r->stream));
+  launch_scatter_tiles(fc, static_cast<const float4*>(d_gathered), r->img_full[which].ptr, r->stream);  // stream ordered: readers wait themselves
+  RT_HIP(hipGetLastError());
   r->full_valid[which] = true;
   return HALA_OK;
 }

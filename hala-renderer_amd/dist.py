@@ -102,21 +102,41 @@ class TileGather:
     # ---- pipelined form: the all-gather of frame k runs while frame k + 1 is rendered -------------------------------
     # xGMI is point-to-point: a ring all-gather of N x 33 MB (1080p RGBA32F per rank) is bound by ONE link per hop, i.e.
     # it can take as long as rendering the frame.  begin() snapshots the rank's tile buffer (the next frame overwrites
-    # it) and starts the collective on a side stream; finish() — called by the next begin(), or explicitly — waits for it
-    # and de-interleaves.  Every frame is still gathered and de-interleaved in full; only the waiting is overlapped.
-    def begin(self):
+    # it) and starts the collective on a side stream; finish() — called by the next begin(), or explicitly — makes the
+    # renderer's stream wait for it and de-interleaves.  Every frame is still gathered and de-interleaved in full.
+    # With RCCL nothing here blocks the host: the hand-overs are stream dependencies between the renderer's HIP stream R
+    # (hala_rt_get_stream) and the side stream S,
+    #   finish(k-1): S waits for the collective; R waits for S; R: de-interleave(k-1)
+    #   begin(k):    S waits for R (frame k rendered, receive buffer read out); S: staging <- tiles; R waits for that copy
+    #                (frame k+1 may overwrite the tiles); S: all-gather(receive <- staging)
+    # so the host can keep enqueueing frames (hala_rt_render bounds them to two in flight).  gloo (CPU collectives; the
+    # 1-GPU rehearsal) synchronises instead.
+    def _streams(self):
         torch = self.torch
-        self.r.wait_idle()  # frame k is complete in the rank's tile buffer (the renderer works on its own HIP stream)
-        self.finish()       # frame k - 1 must have left the staging / receive buffers
         if not hasattr(self, "_side"):
             self._side = torch.cuda.Stream()
             self._stage = [torch.empty_like(src) for _, src, _, _ in self.bufs]
+            self._rstream = torch.cuda.ExternalStream(self.r.stream_handle())
+            self._gloo = self.dist.get_backend(self.group) == "gloo"
+        return self._side, self._rstream
+
+    def begin(self):
+        torch = self.torch
+        side, rstream = self._streams()
+        self.finish()  # frame k - 1 must have left the staging / receive buffers
+        if self._gloo:
+            self.r.wait_idle()
+        side.wait_stream(rstream)  # frame k is complete in the rank's tile buffer, de-interleave k - 1 has read the receive buffer
         self._works = []
-        with torch.cuda.stream(self._side):
+        with torch.cuda.stream(side):
             for (_, src, dst, _), stage in zip(self.bufs, self._stage):
                 stage.copy_(src, non_blocking=True)
-                if self.dist.get_backend(self.group) == "gloo":  # rehearsal on a 1-GPU box; same buffer layout
-                    self._side.synchronize()
+            copied = torch.cuda.Event()
+            copied.record(side)
+            rstream.wait_event(copied)  # the next frame overwrites the tile buffer
+            for (_, src, dst, _), stage in zip(self.bufs, self._stage):
+                if self._gloo:
+                    side.synchronize()
                     self._works.append(self.dist.all_gather(list(dst.view(self.world, -1).unbind(0)), stage, group=self.group, async_op=True))
                 else:
                     self._works.append(self.dist.all_gather_into_tensor(dst, stage, group=self.group, async_op=True))
@@ -125,15 +145,18 @@ class TileGather:
     def finish(self):
         if not getattr(self, "_pending", False):
             return
-        with self.torch.cuda.stream(self._side):
+        side, rstream = self._streams()
+        with self.torch.cuda.stream(side):
             for w in self._works:
-                w.wait()
-        self._side.synchronize()
+                w.wait()  # RCCL: the side stream waits for the collective; gloo: the host does
+        if self._gloo:
+            side.synchronize()
+        rstream.wait_stream(side)
         self._pending = False
         if self.world == 1:
             return
         for which, _, dst, nbytes in self.bufs:
-            self.r.scatter_gathered_tiles(which, dst.data_ptr(), nbytes * self.world)
+            self.r.scatter_gathered_tiles(which, dst.data_ptr(), nbytes * self.world)  # on the renderer's stream, not waited for
 
     def gather(self):
         self.finish()

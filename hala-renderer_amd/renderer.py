@@ -257,6 +257,12 @@ class HalaRenderer:
     def set_tile_shard(self, rank, world, tile_size=32):
         self._check(self._lib.hala_rt_set_tile_shard(self._h, C.c_uint32(rank), C.c_uint32(world), C.c_uint32(tile_size)))
 
+    def stream_handle(self):
+        """the renderer's hipStream_t as an integer (torch.cuda.ExternalStream(handle) wraps it)"""
+        p = C.c_void_p()
+        self._check(self._lib.hala_rt_get_stream(self._h, C.byref(p)))
+        return p.value or 0
+
     def tile_buffer(self, which=0):
         p = C.c_void_p(); n = C.c_size_t()
         self._check(self._lib.hala_rt_tile_buffer(self._h, C.c_int(which), C.byref(p), C.byref(n)))

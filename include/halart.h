@@ -335,7 +335,9 @@ int hala_rt_update(hala_rt_renderer* r, double delta_time, uint32_t width, uint3
  * hala_rt_update `frames` times; what changes is the launch count and the size of each launch (288 GB of HBM hold
  * the extra path state; the per-launch tail of the longest ray is amortised over `frames` times more rays). */
 int hala_rt_update_batch(hala_rt_renderer* r, uint32_t frames);
-/* render (src/rt_renderer.rs:475-502): no swapchain to present to; flushes the stream. */
+/* render (src/rt_renderer.rs:475-502): no swapchain to present to.  Like submit_and_present_frame, which blocks only on the fence of
+ * the swapchain image it is about to reuse, it bounds the updates in flight to two: it returns once the update BEFORE the latest has
+ * finished.  Readers (read_image, save_images, get_statistics, wait_idle) wait for everything themselves. */
 int hala_rt_render(hala_rt_renderer* r);
 /* wait_idle (src/renderer.rs:251-256) */
 int hala_rt_wait_idle(hala_rt_renderer* r);
@@ -425,9 +427,12 @@ int hala_rt_sample_texture_host(hala_rt_renderer* r, uint32_t texture, const flo
  * scramble).  After this call update() renders only this rank's tiles into a tile-major buffer;
  * hala_rt_tile_buffer gives its device address + byte size (per AOV) for the RCCL all-gather, and
  * hala_rt_scatter_gathered_tiles de-interleaves the gathered [world][tiles_per_rank][ts][ts][4] buffer
- * into the row-major images of this renderer. */
+ * into the row-major images of this renderer.  The renderer works on its own HIP stream: wait (hala_rt_wait_idle, or a stream
+ * dependency on hala_rt_get_stream) before another stream reads the tile buffer — hala_rt_render does not flush. */
 int hala_rt_set_tile_shard(hala_rt_renderer* r, uint32_t rank, uint32_t world, uint32_t tile_size);
 int hala_rt_tile_buffer(hala_rt_renderer* r, int which, void** d_ptr, size_t* bytes);
+/* the hipStream_t every launch of this renderer goes to (for stream-ordered hand-overs: hipStreamWaitEvent both ways) */
+int hala_rt_get_stream(hala_rt_renderer* r, void** hip_stream);
 int hala_rt_scatter_gathered_tiles(hala_rt_renderer* r, int which, const void* d_gathered, size_t bytes);
 
 /* ------------------------------------------------------------------------------------------------

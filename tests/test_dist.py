@@ -99,6 +99,44 @@ def test_rccl_all_gather_aliases_library_memory(halart):
         dist.destroy_process_group()
 
 
+@pytest.mark.gpu
+def test_rccl_pipelined_gather_is_stream_ordered(halart):
+    """the RCCL form of begin()/finish() never blocks the host: frame k + 1 is enqueued on the renderer's stream before frame k's
+    gather is finished; the receive buffer must still hold frame k (snapshot taken before the tiles are overwritten) — one rank,
+    which is what this box has"""
+    import torch
+    import torch.distributed as dist
+    from hala_renderer_amd.dist import TileGather
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        w, h = 480, 270
+        scene = scenes.cornell_box(aspect=w / h)
+        r = halart.HalaRenderer("rccl-pipe", w, h, 5, 3, False, False, False, 0)
+        ref = halart.HalaRenderer("ref", w, h, 5, 3, False, False, False, 0)
+        for x in (r, ref):
+            x.set_scene(scene); x.commit()
+        g = TileGather(r, 0, aovs=(r.ACCUM,))
+        want = []
+        for spp in (1, 3, 2, 4):
+            ref.reset_accumulation(); ref.update_batch(spp)
+            want.append(ref.read_image(ref.ACCUM))
+        spps = (1, 3, 2, 4)
+        r.reset_accumulation(); r.update_batch(spps[0])
+        for k in range(4):
+            g.begin()                      # (finishes gather k - 1,) snapshots frame k, starts its gather; the host is not blocked
+            r.render()
+            if k + 1 < 4:                  # frame k + 1 goes to the renderer's stream while gather k may still be running
+                r.reset_accumulation(); r.update_batch(spps[k + 1])
+            g.finish()
+            torch.cuda.synchronize()
+            assert np.array_equal(g.bufs[0][2].cpu().numpy().reshape(h, w, 4), want[k]), k
+        r.close(); ref.close()
+    finally:
+        dist.destroy_process_group()
+
+
 def _pipelined_worker(rank, world, port, q):
     """two real processes (gloo: RCCL refuses two ranks on one device) sharing cuda:0: sharded renders of three different
     frames through the pipelined begin()/finish() gather; every frame's gathered image must equal the unsharded render"""
@@ -169,6 +207,7 @@ def test_sharded_render_equals_unsharded(halart, world):
         for _ in range(spp):
             r.update()
         r.render()
+        r.wait_idle()  # torch reads the tile buffer on its own stream below; render() bounds the frames in flight, it does not flush
         return r
 
     ref = render(0, 1)
