@@ -89,6 +89,8 @@ pub mod sys {
     pub fn hala_rt_set_tile_shard(r: *mut hala_rt_renderer, rank: u32, world: u32, tile_size: u32) -> c_int;
     pub fn hala_rt_tile_buffer(r: *mut hala_rt_renderer, which: c_int, d_ptr: *mut *mut c_void, bytes: *mut usize) -> c_int;
     pub fn hala_rt_scatter_gathered_tiles(r: *mut hala_rt_renderer, which: c_int, d_gathered: *const c_void, bytes: usize) -> c_int;
+    pub fn hala_rt_get_stream(r: *mut hala_rt_renderer, hip_stream: *mut *mut c_void) -> c_int;
+    pub fn hala_rt_set_launch_timing_period(r: *mut hala_rt_renderer, period: u32) -> c_int;
     // cpu::HalaScene::new inside the library (for hosts without the Rust `src/scene` module)
     pub fn hala_scene_load_gltf(path: *const c_char, out: *mut *mut hala_scene) -> c_int;
     pub fn hala_scene_get_desc(scene: *const hala_scene) -> *const hala_scene_desc;
@@ -197,6 +199,14 @@ impl HalaRenderer {
     check(unsafe { sys::hala_rt_update_vertices(self.h, mesh_index, primitive_index, vertices.as_ptr(), vertices.len() as u32) })
   }
   pub fn refit(&mut self) -> Result<(), HalaRendererError> { check(unsafe { sys::hala_rt_refit(self.h) }) }
+  /// the hipStream_t of this renderer, for stream-ordered hand-overs of the tile buffer (multi-GPU gather)
+  pub fn stream(&self) -> Result<*mut c_void, HalaRendererError> {
+    let mut s: *mut c_void = std::ptr::null_mut();
+    check(unsafe { sys::hala_rt_get_stream(self.h, &mut s) })?;
+    Ok(s)
+  }
+  /// per-launch timing events on every `period`-th update (1: all, 0: none)
+  pub fn set_launch_timing_period(&mut self, period: u32) -> Result<(), HalaRendererError> { check(unsafe { sys::hala_rt_set_launch_timing_period(self.h, period) }) }
   pub fn set_tile_shard(&mut self, rank: u32, world: u32, tile_size: u32) -> Result<(), HalaRendererError> { check(unsafe { sys::hala_rt_set_tile_shard(self.h, rank, world, tile_size) }) }
 }
 impl Drop for HalaRenderer { fn drop(&mut self) { unsafe { sys::hala_rt_destroy(self.h) } } }
