@@ -541,6 +541,82 @@ __global__ void __launch_bounds__(256) k_ploc_apply(const uint32_t* __restrict__
   for (int c = 0; c < 3; ++c) { w.mn[c] = u.mn[c] - pad; w.mx[c] = u.mx[c] + pad; }
   node_box[id] = w;
 }
+// The last rounds in ONE workgroup: once kPlocTail or fewer clusters are left (27 of the ~60 rounds of a million-triangle build)
+// a round is far shorter than its six launches and two host round trips.  Same nearest-neighbour rule, same flags, same ids
+// (next_id - exclusive scan of the merge flags) as k_ploc_nearest / k_ploc_flags / k_ploc_apply: the tree is bit for bit the same.
+constexpr uint32_t kPlocTail = 512;
+__global__ void __launch_bounds__(kPlocTail) k_ploc_tail(uint32_t m, uint32_t radius, uint32_t next_id, const uint32_t* __restrict__ cl_ref_in,
+                                                          const Box6* __restrict__ cl_box_in, uint32_t* __restrict__ left, uint32_t* __restrict__ right,
+                                                          uint32_t* __restrict__ node_parent, uint32_t* __restrict__ leaf_parent, uint32_t* subtree,
+                                                          Box6* __restrict__ node_box, float pad) {
+  __shared__ uint32_t s_ref[2][kPlocTail], s_size[2][kPlocTail];  // s_size: triangles below the cluster (subtree[] of this kernel's own
+  __shared__ Box6 s_box[2][kPlocTail];                            // nodes is only written, never read back through the caches)
+  __shared__ uint32_t s_nn[kPlocTail];
+  __shared__ uint32_t s_wave[kPlocTail / 64];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  int cur = 0;
+  if (tid < m) { const uint32_t r = cl_ref_in[tid]; s_ref[0][tid] = r; s_size[0][tid] = ploc_size(r, subtree); s_box[0][tid] = cl_box_in[tid]; }
+  __syncthreads();
+  while (m > 1u) {
+    if (tid < m) {
+      const Box6 bi = s_box[cur][tid];
+      const uint32_t lo = tid > radius ? tid - radius : 0u, hi = min(m - 1u, tid + radius);
+      float best = 3.402823466e+38f;
+      uint32_t bj = tid;
+      for (uint32_t j = lo; j <= hi; ++j) {
+        if (j == tid) continue;
+        const float a = half_area(box_union(bi, s_box[cur][j]));
+        if (a < best || bj == tid) { best = a; bj = j; }
+      }
+      s_nn[tid] = bj;
+    }
+    __syncthreads();
+    uint32_t merge = 0, keepc = 0, j = tid;
+    if (tid < m) {
+      j = s_nn[tid];
+      const bool mutual = j != tid && s_nn[j] == tid;
+      merge = (mutual && tid < j) ? 1u : 0u;
+      keepc = (mutual && tid > j) ? 0u : 1u;
+    }
+    // one block-wide scan for both flags: merge count in the high half, keep count in the low half (<= 512 each)
+    const uint32_t packed = (merge << 16) | keepc;
+    uint32_t incl = packed;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);
+      if (lane >= (uint32_t)d) incl += up;
+    }
+    if (lane == 63u) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+    for (uint32_t w = 0; w < kPlocTail / 64; ++w) { const uint32_t v = s_wave[w]; if (w < wave) before += v; total += v; }
+    const uint32_t excl = before + incl - packed;
+    const uint32_t merge_scan = excl >> 16, keep_scan = excl & 0xffffu;
+    if (tid < m && keepc) {
+      if (!merge) { s_ref[cur ^ 1][keep_scan] = s_ref[cur][tid]; s_size[cur ^ 1][keep_scan] = s_size[cur][tid]; s_box[cur ^ 1][keep_scan] = s_box[cur][tid]; }
+      else {
+        const uint32_t id = next_id - merge_scan;
+        const uint32_t ra = s_ref[cur][tid], rb = s_ref[cur][j];
+        left[id] = ra; right[id] = rb;
+        if (ra & kLeafBit) leaf_parent[ra & ~kLeafBit] = id; else node_parent[ra] = id;
+        if (rb & kLeafBit) leaf_parent[rb & ~kLeafBit] = id; else node_parent[rb] = id;
+        const uint32_t size = s_size[cur][tid] + s_size[cur][j];
+        subtree[id] = size;
+        s_ref[cur ^ 1][keep_scan] = id; s_size[cur ^ 1][keep_scan] = size;
+        const Box6 u = box_union(s_box[cur][tid], s_box[cur][j]);
+        s_box[cur ^ 1][keep_scan] = u;
+        Box6 w;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { w.mn[c] = u.mn[c] - pad; w.mx[c] = u.mx[c] + pad; }
+        node_box[id] = w;
+      }
+    }
+    __syncthreads();
+    next_id -= total >> 16;
+    m = total & 0xffffu;
+    cur ^= 1;
+  }
+}
 // position of leaf k / first position of node i in the depth-first order of the finished tree: the sizes of all left
 // siblings passed on the way up
 RT_DI uint32_t ploc_offset(uint32_t ref, uint32_t p, const uint32_t* __restrict__ left, const uint32_t* __restrict__ right,
@@ -755,7 +831,15 @@ static std::string ploc_hierarchy(BvhBuffers& b, BvhTopology& t, hipStream_t s) 
   int cur = 0;
   uint32_t radius = kPlocRadius;
   if (const char* ev = getenv("HALART_PLOC_RADIUS")) radius = (uint32_t)std::max(1, atoi(ev));  // tuning knob
+  bool tail = true;
+  if (const char* ev = getenv("HALART_PLOC_TAIL")) tail = atoi(ev) != 0;  // A/B knob: 0 = every round as separate launches
   while (m > 1) {
+    if (tail && m <= kPlocTail) {
+      hipLaunchKernelGGL(k_ploc_tail, dim3(1), dim3(kPlocTail), 0, s, m, radius, (ni - 1u) - created, ref[cur].as<uint32_t>(), box[cur].as<Box6>(),
+                         t.left.as<uint32_t>(), t.right.as<uint32_t>(), t.node_parent.as<uint32_t>(), t.leaf_parent.as<uint32_t>(),
+                         subtree.as<uint32_t>(), t.node_box.as<Box6>(), box_pad(b));
+      break;
+    }
     hipLaunchKernelGGL(k_ploc_nearest, dim3(nblk(m)), dim3(256), 0, s, box[cur].as<Box6>(), m, radius, nn.as<uint32_t>());
     hipLaunchKernelGGL(k_ploc_flags, dim3(nblk(m)), dim3(256), 0, s, nn.as<uint32_t>(), m, merge.as<uint32_t>(), keepc.as<uint32_t>());
     size_t tb = tmp_bytes;

@@ -326,6 +326,24 @@ def test_refit_after_vertex_deformation(halart, oracle):
     r.close()
 
 
+def test_ploc_single_workgroup_tail_builds_the_same_tree(halart, oracle, monkeypatch):
+    """the last PLOC rounds (<= 512 clusters) run inside one workgroup (k_ploc_tail); with HALART_PLOC_TAIL=0 every round is its own set
+    of launches: the two builders must emit byte-identical nodes and triangle orders"""
+    s = scenes.sponza_class(target_triangles=60_000)
+    trees = []
+    for tail in ("1", "0"):
+        monkeypatch.setenv("HALART_PLOC_TAIL", tail)
+        r = make_renderer(halart, s, 16, 16)
+        trees.append(r.download_bvh())
+        info = r.bvh_info()
+        r.close()
+    assert info.triangle_count >= 4096  # PLOC is the builder at this size
+    assert trees[0][0].tobytes() == trees[1][0].tobytes() and trees[0][1].tobytes() == trees[1][1].tobytes()
+    osc = oracle.OracleScene(s)
+    rc, _ = oracle.validate_bvh(trees[0][0], trees[0][1], osc.triangles())
+    assert rc == 0
+
+
 def test_refit_without_change_reproduces_the_build(halart, oracle):
     """refit re-derives the 4-wide nodes level by level (k_refit_level) instead of fit + pack: with nothing moved the nodes, the
     triangle order and every box must come out byte for byte as the build (PLOC boxes for the large scene, k_fit for the small)"""
