@@ -24,6 +24,7 @@ using namespace rt;
 namespace {
 
 constexpr uint32_t kLeafMax = 2;  // triangles per leaf: a triangle test costs ~2x a child box test, profiles/r01_h_experiments.txt
+constexpr uint32_t kLeafMaxStaged = 4;  // ... unless the whole tree sits in LDS: leaves of two packed pairs, fewer node steps (+2 % on Cornell)
 constexpr size_t kLdsStageBudget = 40 * 1024;  // a BVH up to this size is staged whole in LDS (next to the 24-KB stack)
 constexpr uint32_t kRefillThreshold = 32;      // idle lanes that trigger a refill of the wave (persistent_trace)
 constexpr int kStatRing = 16;
@@ -431,7 +432,8 @@ int build_bvh(hala_rt_renderer* r) {
   r->bvh.primitives = r->d_instances.ptr; r->bvh.inst_first_tri = r->d_inst_first_tri.ptr;
   r->bvh.instance_count = (uint32_t)r->hs.instances.size(); r->bvh.tri_count = n;
   r->bvh.tris_by_id = r->d_tris_by_id.ptr; r->bvh.shade_tris = r->d_shade_tris.ptr; r->bvh.tris = r->d_tris.ptr; r->bvh.tri_instance = r->d_tri_instance.ptr; r->bvh.nodes = r->d_nodes.ptr;
-  uint32_t leaf_max = kLeafMax;
+  // a scene this small will be staged in LDS (configure_traversal: 48 B per triangle + at most ~32 B of nodes per triangle)
+  uint32_t leaf_max = (size_t)n * 80 <= kLdsStageBudget ? kLeafMaxStaged : kLeafMax;
   if (const char* ev = getenv("HALART_LEAF_MAX")) leaf_max = std::min(8u, std::max(1u, (uint32_t)atoi(ev)));  // tuning knob
   const std::string e = bvh_build(r->bvh, leaf_max, r->stream);
   if (!e.empty()) RT_FAIL(e);
