@@ -237,13 +237,14 @@ def main():
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_GBps": (round(traffic / (avg_launch_ms * 1e-3) / 1e9, 1) if traffic and avg_launch_ms > 0 else None),
+                         "traffic_frac_of_peak": (round(traffic / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and avg_launch_ms > 0 else None),
                          "note": "achieved = ALGORITHMIC bytes (SURVEY 8d formula, 64 B per 4-wide node) / launch time, both per launch of this "
                                  "kernel symbol; avg_launch_ms is measured with HIP events on the renderer's stream, inside the timed region, "
                                  "on every `timing_period`-th frame (`launches` = the launches so measured) and agrees with the "
                                  "rocprofv3 --kernel-trace --stats average in profiles/. For this 32-triangle scene the whole BVH (6 nodes + "
                                  "32 triangles = 1.9 KB) is staged in LDS, so node/triangle bytes never reach HBM: `traffic` (PMC FETCH_SIZE*2 "
-                                 "+ WRITE_SIZE per launch, profiles/traffic_closest.json) is just the ray-queue read + hit write, and frac can "
-                                 "exceed 1. The kernel is VALU-issue bound (profiles/r01_k_pmc_config2.txt: ~0.8 of the issue slots; `simt` "
+                                 "+ WRITE_SIZE per launch, profiles/traffic_closest.json) is just the ray-queue read + hit write (`traffic_frac_of_peak` is what HBM actually carries), and frac — a rate of "
+                                 "useful work priced in bytes, not a bandwidth — can exceed 1. The kernel is VALU-issue bound (profiles/r01_l_pmc_config2.txt: ~0.8 of the issue slots; `simt` "
                                  "gives the active lanes per wave on its two code paths). scripts/bench_scenes.py reports the same figures "
                                  "for the 82 k and 1 M triangle scenes, where the nodes do come from L2 / Infinity Cache / HBM.",
                          "bytes_per_ray": round(bytes_per_ray, 1), "nodes_per_ray": round(nodes_per_ray, 3),
