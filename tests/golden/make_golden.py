@@ -21,7 +21,42 @@ from hala_renderer_amd import scenes  # noqa: E402
 from test_oracle_host import kat_images  # noqa: E402
 
 
+def media_scene():
+    """RENDER_SPEC 7.1c-f in one frame: a glass blob (TIR-aware transmission) filled with an absorbing medium, a second, invisible
+    (opacity 0) ball of forward-scattering fog, a cut-out (opacity 0.5) ground, one quad light, env map"""
+    import hala_renderer_amd as H
+    s = scenes.bunny_class(subdivisions=2, aspect=48 / 32, disney=True)
+    s.materials[0] = H.HalaMaterial(type=1, base_color=(1.0, 1.0, 1.0), metallic=0.0, roughness=0.1, specular_transmission=1.0, ior=1.45,
+                                    medium=H.HalaMedium(1, (0.9, 0.5, 0.3), 1.5, 0.0))
+    fog = scenes.blob_mesh(subdivisions=2, amplitude=0.0)
+    fog.material_index = len(s.materials)
+    s.materials.append(H.HalaMaterial(type=0, base_color=(1.0, 1.0, 1.0), roughness=0.5, opacity=0.0, medium=H.HalaMedium(2, (0.95, 0.9, 0.8), 2.5, 0.6)))
+    s.meshes.append(H.HalaMesh([fog]))
+    m = np.eye(4, dtype=np.float32)
+    m[:3, :3] *= 0.6
+    m[:3, 3] = (1.4, 0.2, 0.4)
+    s.nodes.append(H.HalaNode(name="fog", mesh_index=len(s.meshes) - 1, local_transform=m))
+    for mat in s.materials[1:2]:
+        mat.opacity = 0.5
+    return s
+
+
+def media(write=True):
+    env = scenes.sky_sun_envmap(64, 32, sun_gain=100.0)
+    sc = O.OracleScene(media_scene(), envmap=env)
+    imgs, st = sc.render(48, 32, frames=2, max_depth=12, rr_depth=3, env_rotation=15.0)
+    if write:
+        np.savez_compressed(os.path.join(HERE, "media_glass_48x32_2spp.npz"), accum=imgs[0], albedo=imgs[1], normal=imgs[2], env=env,
+                            rays=np.array([st.rays_closest, st.rays_shadow], dtype=np.uint64))
+    return imgs, st
+
+
 def main():
+    if "--only-media" in sys.argv:  # added later than the others: written alone so that their files keep their bytes
+        media()
+        print("media fixture written to", HERE)
+        return
+    media()
     # (i) env-map KATs
     out = {}
     for name, img in kat_images().items():

@@ -783,6 +783,23 @@ def test_render_media_bit_exact(halart, oracle, medium):
     r.close()
 
 
+def test_media_glass_fixture_scene_bit_exact(halart, oracle):
+    """the frozen media / glass frame (tests/golden/media_glass_48x32_2spp.npz): GPU == oracle bit for bit on this box's scene
+    arrays, and both within the fixture's tolerance"""
+    import sys
+    sys.path.insert(0, GOLDEN)
+    from make_golden import media_scene
+    g = np.load(os.path.join(GOLDEN, "media_glass_48x32_2spp.npz"))
+    s = media_scene()
+    r = make_renderer(halart, s, 48, 32, max_depth=12, rr_depth=3, env=g["env"], env_rot=15.0)
+    r.update_batch(2); r.render()
+    imgs, st = oracle.OracleScene(s, envmap=g["env"]).render(48, 32, frames=2, max_depth=12, rr_depth=3, env_rotation=15.0)
+    assert_images_equal(r, imgs)
+    d = np.abs(r.read_image(0) - g["accum"])
+    assert np.mean(d.max(axis=-1) > 1e-3) < 0.02
+    r.close()
+
+
 @pytest.mark.parametrize("boundary", ["glass", "invisible"])
 def test_render_scattering_medium_bit_exact(halart, oracle, boundary):
     """RENDER_SPEC 7.1f: free-flight sampling (polynomial log), Henyey-Greenstein scattering, no NEE at scattering vertices (the

@@ -3,6 +3,7 @@
 brute-force intersector, analytic renders, frozen regression fixtures — so that the oracle can act as the spec the HIP
 kernels are held to in tests/test_gpu_parity.py."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -112,6 +113,20 @@ def test_rect_render_is_position_independent(oracle):
     part, _ = osc.render(48, 40, frames=2, rect=(16, 8, 40, 24))
     assert full[0][8:24, 16:40].tobytes() == part[0][8:24, 16:40].tobytes()
     assert np.all(part[0][:8] == 0)
+
+
+def test_media_glass_render_fixture(oracle):
+    """RENDER_SPEC 7.1c-f frozen: TIR-aware glass with an absorbing interior, an invisible ball of forward-scattering fog, a cut-out
+    ground, quad light + env map (tests/golden/make_golden.py::media_scene)"""
+    sys.path.insert(0, GOLDEN)
+    from make_golden import media_scene
+    g = np.load(os.path.join(GOLDEN, "media_glass_48x32_2spp.npz"))
+    osc = oracle.OracleScene(media_scene(), envmap=g["env"])
+    imgs, st = osc.render(48, 32, frames=2, max_depth=12, rr_depth=3, env_rotation=15.0)
+    for k, name in enumerate(["accum", "albedo", "normal"]):  # tolerance: the scene generator uses libm (see the blob fixture)
+        d = np.abs(imgs[k] - g[name])
+        assert np.mean(d.max(axis=-1) > 1e-3) < 0.02, name
+    assert abs(int(st.rays_closest) - int(g["rays"][0])) <= 0.01 * int(g["rays"][0])
 
 
 def furnace_scene():
