@@ -181,7 +181,7 @@ EXPORTS = [
     "hala_last_error_message", "hala_rt_create", "hala_rt_destroy",
     "hala_rt_push_general_shader", "hala_rt_push_general_shader_with_file",
     "hala_rt_push_hit_shaders", "hala_rt_push_hit_shaders_with_file",
-    "hala_rt_load_blue_noise_pixels", "hala_rt_set_scene", "hala_rt_set_envmap_pixels",
+    "hala_rt_load_blue_noise_texture", "hala_rt_load_blue_noise_pixels", "hala_rt_set_scene", "hala_rt_set_envmap_pixels",
     "hala_rt_set_envmap_file", "hala_rt_set_ground_color", "hala_rt_set_sky_color",
     "hala_rt_set_env_intensity", "hala_rt_set_exposure_value", "hala_rt_commit", "hala_rt_update", "hala_rt_update_batch",
     "hala_rt_render", "hala_rt_wait_idle", "hala_rt_save_images", "hala_rt_read_image",

@@ -475,6 +475,24 @@ void load(const std::string& path, hala_scene* s) {
 
 }  // namespace
 
+// 8-bit image file -> RGBA8 for callers outside the glTF loader (cpu::HalaImageData::new_with_file, src/scene/cpu/image_data.rs:26-29: PNG
+// and baseline JPEG here); the error text is the reference's.
+namespace rt {
+std::string decode_image_file_rgba8(const char* path, uint32_t* w, uint32_t* h, std::vector<uint8_t>* rgba) {
+  const std::string msg = std::string("Failed to open image \"") + (path ? path : "") + "\".";
+  if (!path) return msg;
+  FILE* f = fopen(path, "rb");
+  if (!f) return msg;
+  std::vector<uint8_t> raw;
+  uint8_t buf[65536];
+  size_t got;
+  while ((got = fread(buf, 1, sizeof(buf), f)) > 0) raw.insert(raw.end(), buf, buf + got);
+  fclose(f);
+  if (!decode_png(raw, w, h, rgba) && !decode_jpeg(raw, w, h, rgba)) return msg;
+  return "";
+}
+}  // namespace rt
+
 extern "C" {
 
 int hala_scene_load_gltf(const char* path, hala_scene** out) {

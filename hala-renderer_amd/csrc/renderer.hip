@@ -19,6 +19,8 @@
 #include "host_util.h"
 #include "kernels.h"
 
+namespace rt { std::string decode_image_file_rgba8(const char* path, uint32_t* w, uint32_t* h, std::vector<uint8_t>* rgba); }  // gltf_loader.cpp
+
 using namespace rt;
 
 namespace {
@@ -548,6 +550,16 @@ int hala_rt_push_hit_shaders_with_file(hala_rt_renderer* r, const char* ch, cons
   return HALA_OK;
 }
 
+int hala_rt_load_blue_noise_pixels(hala_rt_renderer* r, const uint8_t* rgba8, uint32_t width, uint32_t height);
+int hala_rt_load_blue_noise_texture(hala_rt_renderer* r, const char* path) {
+  if (!r) RT_FAIL("The renderer handle is null!");
+  if (!path || !*path || file_stem(path).empty()) RT_FAIL("The file name is none!");  // src/rt_renderer.rs:1120
+  uint32_t w = 0, h = 0;
+  std::vector<uint8_t> px;
+  const std::string e = rt::decode_image_file_rgba8(path, &w, &h, &px);
+  if (!e.empty()) RT_FAIL(e);
+  return hala_rt_load_blue_noise_pixels(r, px.data(), w, h);
+}
 int hala_rt_load_blue_noise_pixels(hala_rt_renderer* r, const uint8_t* rgba8, uint32_t width, uint32_t height) {
   if (ensure_device(r) != HALA_OK) return HALA_ERR;
   if (!rgba8 || !width || !height) RT_FAIL("The blue noise texture is empty!");

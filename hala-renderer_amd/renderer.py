@@ -69,9 +69,12 @@ class HalaRenderer:
         enc = lambda p: os.fsencode(p) if p else None  # noqa: E731
         self._check(self._lib.hala_rt_push_hit_shaders_with_file(self._h, enc(closest_hit_path), enc(any_hit_path), enc(intersection_path), debug_name.encode()))
 
-    def load_blue_noise_texture(self, rgba8: np.ndarray):
-        """src/rt_renderer.rs:1117-1156 (takes decoded RGBA8 pixels [H,W,4]; optional in this integrator)"""
-        px = np.ascontiguousarray(rgba8, dtype=np.uint8)
+    def load_blue_noise_texture(self, path_or_rgba8):
+        """src/rt_renderer.rs:1117-1156: a PNG / JPEG path like the reference, or decoded RGBA8 pixels [H,W,4]; optional in this integrator"""
+        if isinstance(path_or_rgba8, (str, bytes, os.PathLike)):
+            self._check(self._lib.hala_rt_load_blue_noise_texture(self._h, os.fsencode(path_or_rgba8)))
+            return
+        px = np.ascontiguousarray(path_or_rgba8, dtype=np.uint8)
         self._check(self._lib.hala_rt_load_blue_noise_pixels(self._h, px.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_uint32(px.shape[1]), C.c_uint32(px.shape[0])))
 
     # -- scene / environment ------------------------------------------------------------------------------

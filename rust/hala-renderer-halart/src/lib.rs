@@ -86,6 +86,7 @@ pub mod sys {
     pub fn hala_rt_update_node_transform(r: *mut hala_rt_renderer, node_index: u32, local_transform: *const f32) -> c_int;
     pub fn hala_rt_update_vertices(r: *mut hala_rt_renderer, mesh_index: u32, primitive_index: u32, vertices: *const hala_vertex, vertex_count: u32) -> c_int;
     pub fn hala_rt_refit(r: *mut hala_rt_renderer) -> c_int;
+    pub fn hala_rt_load_blue_noise_texture(r: *mut hala_rt_renderer, path: *const c_char) -> c_int;
     pub fn hala_rt_set_tile_shard(r: *mut hala_rt_renderer, rank: u32, world: u32, tile_size: u32) -> c_int;
     pub fn hala_rt_tile_buffer(r: *mut hala_rt_renderer, which: c_int, d_ptr: *mut *mut c_void, bytes: *mut usize) -> c_int;
     pub fn hala_rt_scatter_gathered_tiles(r: *mut hala_rt_renderer, which: c_int, d_gathered: *const c_void, bytes: usize) -> c_int;
@@ -171,6 +172,10 @@ impl HalaRenderer {
       cameras: scene.cameras.as_ptr(), camera_count: scene.cameras.len() as u32, texture2image_mapping: t2i.as_ptr(), texture_count: t2i.len() as u32,
       image2data_mapping: i2d.as_ptr(), image_count: i2d.len() as u32, image_data: images.as_ptr(), image_data_count: images.len() as u32 };
     check(unsafe { sys::hala_rt_set_scene(self.h, &desc) })
+  }
+  /// src/rt_renderer.rs:1117-1156
+  pub fn load_blue_noise_texture<P: AsRef<Path>>(&mut self, path: P) -> Result<(), HalaRendererError> {
+    check(unsafe { sys::hala_rt_load_blue_noise_texture(self.h, cpath(path).as_ptr()) })
   }
   /// src/rt_renderer.rs:1184-1195
   pub fn set_envmap<P: AsRef<Path>>(&mut self, path: P, rotation: f32) -> Result<(), HalaRendererError> {

@@ -274,6 +274,26 @@ def test_rtprog_trace_rays_and_indirect(halart, oracle):
     r.close()
 
 
+def test_load_blue_noise_texture_from_file(halart, tmp_path):
+    """load_blue_noise_texture(path) (src/rt_renderer.rs:1117-1156): PNG decoded by the library itself; the reference's messages for a
+    missing file / an empty name; the texture is accepted and unused (RENDER_SPEC 2.3), so the render does not change"""
+    from PIL import Image
+    rng = np.random.RandomState(5)
+    Image.fromarray(rng.randint(0, 256, (32, 32, 4), dtype=np.uint8), "RGBA").save(tmp_path / "blue.png")
+    s = scenes.cornell_box()
+    r = make_renderer(halart, s, 24, 24)
+    r.update(); r.render()
+    before = r.read_image(0)
+    r.load_blue_noise_texture(str(tmp_path / "blue.png"))
+    r.reset_accumulation(); r.update(); r.render()
+    assert r.read_image(0).tobytes() == before.tobytes()
+    with pytest.raises(Exception, match="Failed to open image"):
+        r.load_blue_noise_texture(str(tmp_path / "missing.png"))
+    with pytest.raises(Exception, match="The file name is none!"):
+        r.load_blue_noise_texture("")
+    r.close()
+
+
 # ---- K4: refit -------------------------------------------------------------------------------------------------------
 def test_refit_after_node_transform(halart, oracle):
     s = scenes.cornell_box()
