@@ -902,7 +902,7 @@ int hala_rt_get_stream(hala_rt_renderer* r, void** hip_stream) {
   *hip_stream = static_cast<void*>(r->stream);
   return HALA_OK;
 }
-int hala_rt_scatter_gathered_tiles(hala_rt_renderer* r, int which, const void* d_gathered, size_t bytes) {
+int hala_rt_scatter_gathered_tiles_on_stream(hala_rt_renderer* r, int which, const void* d_gathered, size_t bytes, void* hip_stream) {
   if (ensure_device(r) != HALA_OK) return HALA_ERR;
   if (which < 0 || which > 3 || !d_gathered) RT_FAIL("Invalid argument.");
   if (r->world <= 1) RT_FAIL("The renderer is not sharded.");
@@ -910,10 +910,13 @@ int hala_rt_scatter_gathered_tiles(hala_rt_renderer* r, int which, const void* d
   RT_HIP(r->img_full[which].resize((size_t)r->width * r->height));
   hala_global_uniform u = r->last_uniform;
   const FrameConst fc = r->frame_const(u);
-  launch_scatter_tiles(fc, static_cast<const float4*>(d_gathered), r->img_full[which].ptr, r->stream);  // stream ordered: readers wait themselves
+  launch_scatter_tiles(fc, static_cast<const float4*>(d_gathered), r->img_full[which].ptr, hip_stream ? static_cast<hipStream_t>(hip_stream) : r->stream);  // stream ordered: readers wait themselves
   RT_HIP(hipGetLastError());
   r->full_valid[which] = true;
   return HALA_OK;
+}
+int hala_rt_scatter_gathered_tiles(hala_rt_renderer* r, int which, const void* d_gathered, size_t bytes) {
+  return hala_rt_scatter_gathered_tiles_on_stream(r, which, d_gathered, bytes, nullptr);
 }
 
 // ---- ray-batch operator ------------------------------------------------------------------------------------------------

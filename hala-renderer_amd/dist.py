@@ -106,7 +106,7 @@ class TileGather:
     # renderer's stream wait for it and de-interleaves.  Every frame is still gathered and de-interleaved in full.
     # With RCCL nothing here blocks the host: the hand-overs are stream dependencies between the renderer's HIP stream R
     # (hala_rt_get_stream) and the side stream S,
-    #   finish(k-1): S waits for the collective; R waits for S; R: de-interleave(k-1)
+    #   finish(k-1): S waits for the collective; S: de-interleave(k-1), beside frame k on R; R's later work waits for S
     #   begin(k):    S waits for R (frame k rendered, receive buffer read out); S: staging <- tiles; R waits for that copy
     #                (frame k+1 may overwrite the tiles); S: all-gather(receive <- staging)
     # so the host can keep enqueueing frames (hala_rt_render bounds them to two in flight).  gloo (CPU collectives; the
@@ -151,12 +151,11 @@ class TileGather:
                 w.wait()  # RCCL: the side stream waits for the collective; gloo: the host does
         if self._gloo:
             side.synchronize()
-        rstream.wait_stream(side)
         self._pending = False
-        if self.world == 1:
-            return
-        for which, _, dst, nbytes in self.bufs:
-            self.r.scatter_gathered_tiles(which, dst.data_ptr(), nbytes * self.world)  # on the renderer's stream, not waited for
+        if self.world > 1:
+            for which, _, dst, nbytes in self.bufs:  # on the side stream: the de-interleave of frame k runs beside the rendering of k + 1
+                self.r.scatter_gathered_tiles(which, dst.data_ptr(), nbytes * self.world, stream=side.cuda_stream)
+        rstream.wait_stream(side)  # whatever the renderer's stream does next (and whoever waits for it) sees the images complete
 
     def gather(self):
         self.finish()

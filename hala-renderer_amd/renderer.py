@@ -271,5 +271,6 @@ class HalaRenderer:
         self._check(self._lib.hala_rt_tile_buffer(self._h, C.c_int(which), C.byref(p), C.byref(n)))
         return p.value, n.value
 
-    def scatter_gathered_tiles(self, which, d_gathered: int, nbytes: int):
-        self._check(self._lib.hala_rt_scatter_gathered_tiles(self._h, C.c_int(which), C.c_void_p(d_gathered), C.c_size_t(nbytes)))
+    def scatter_gathered_tiles(self, which, d_gathered: int, nbytes: int, stream: int = 0):
+        """de-interleave a gathered buffer into this renderer's row-major image; stream = a hipStream_t of the caller's (0: the renderer's)"""
+        self._check(self._lib.hala_rt_scatter_gathered_tiles_on_stream(self._h, C.c_int(which), C.c_void_p(d_gathered), C.c_size_t(nbytes), C.c_void_p(stream or None)))

@@ -435,6 +435,9 @@ int hala_rt_tile_buffer(hala_rt_renderer* r, int which, void** d_ptr, size_t* by
 /* the hipStream_t every launch of this renderer goes to (for stream-ordered hand-overs: hipStreamWaitEvent both ways) */
 int hala_rt_get_stream(hala_rt_renderer* r, void** hip_stream);
 int hala_rt_scatter_gathered_tiles(hala_rt_renderer* r, int which, const void* d_gathered, size_t bytes);
+/* the same launched on a stream of the caller's (NULL: the renderer's): the de-interleave of frame k can then run beside the rendering
+ * of frame k + 1.  The caller orders it against the renderer's stream (hala_rt_get_stream) before anything reads the images. */
+int hala_rt_scatter_gathered_tiles_on_stream(hala_rt_renderer* r, int which, const void* d_gathered, size_t bytes, void* hip_stream);
 
 /* ------------------------------------------------------------------------------------------------
  * The ray-batch operator under the renderer: what vkCmdTraceRaysKHR + the closest-hit stage do for
