@@ -90,6 +90,7 @@ pub mod sys {
     pub fn hala_rt_set_tile_shard(r: *mut hala_rt_renderer, rank: u32, world: u32, tile_size: u32) -> c_int;
     pub fn hala_rt_tile_buffer(r: *mut hala_rt_renderer, which: c_int, d_ptr: *mut *mut c_void, bytes: *mut usize) -> c_int;
     pub fn hala_rt_scatter_gathered_tiles(r: *mut hala_rt_renderer, which: c_int, d_gathered: *const c_void, bytes: usize) -> c_int;
+    pub fn hala_rt_scatter_gathered_tiles_on_stream(r: *mut hala_rt_renderer, which: c_int, d_gathered: *const c_void, bytes: usize, hip_stream: *mut c_void) -> c_int;
     pub fn hala_rt_get_stream(r: *mut hala_rt_renderer, hip_stream: *mut *mut c_void) -> c_int;
     pub fn hala_rt_set_launch_timing_period(r: *mut hala_rt_renderer, period: u32) -> c_int;
     // cpu::HalaScene::new inside the library (for hosts without the Rust `src/scene` module)
