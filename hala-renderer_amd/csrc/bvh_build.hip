@@ -490,8 +490,12 @@ __global__ void __launch_bounds__(256) k_ploc_init(const Box6* __restrict__ tri_
   cl_ref[k] = kLeafBit | k;
   cl_box[k] = tri_box[sorted_ids[k]];
 }
-__global__ void __launch_bounds__(256) k_ploc_nearest(const Box6* __restrict__ cl_box, uint32_t m, uint32_t radius, uint32_t* __restrict__ nn) {
+// The round kernels take the live cluster count m (and the nodes created so far) from device memory: the host only knows an upper
+// bound of m (the grid), refreshed every few rounds, so that a round does not cost a host round trip (k_ploc_advance).
+__global__ void __launch_bounds__(256) k_ploc_nearest(const Box6* __restrict__ cl_box, const uint32_t* __restrict__ state, uint32_t radius,
+                                                       uint32_t* __restrict__ nn) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t m = state[0];
   if (i >= m) return;
   const Box6 bi = cl_box[i];
   const uint32_t lo = i > radius ? i - radius : 0u, hi = min(m - 1u, i + radius);
@@ -504,10 +508,12 @@ __global__ void __launch_bounds__(256) k_ploc_nearest(const Box6* __restrict__ c
   }
   nn[i] = bj;
 }
-__global__ void __launch_bounds__(256) k_ploc_flags(const uint32_t* __restrict__ nn, uint32_t m, uint32_t* __restrict__ merge,
-                                                     uint32_t* __restrict__ keepc) {
+__global__ void __launch_bounds__(256) k_ploc_flags(const uint32_t* __restrict__ nn, const uint32_t* __restrict__ state, uint32_t bound,
+                                                     uint32_t* __restrict__ merge, uint32_t* __restrict__ keepc) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= m) return;
+  if (i >= bound) return;
+  const uint32_t m = state[0];
+  if (i >= m) { merge[i] = 0u; keepc[i] = 0u; return; }  // the scans run over the host's bound
   const uint32_t j = nn[i];
   const bool mutual = j != i && nn[j] == i;
   merge[i] = (mutual && i < j) ? 1u : 0u;
@@ -515,13 +521,14 @@ __global__ void __launch_bounds__(256) k_ploc_flags(const uint32_t* __restrict__
 }
 __global__ void __launch_bounds__(256) k_ploc_apply(const uint32_t* __restrict__ nn, const uint32_t* __restrict__ merge,
                                                      const uint32_t* __restrict__ keepc, const uint32_t* __restrict__ merge_scan,
-                                                     const uint32_t* __restrict__ keep_scan, uint32_t m, uint32_t next_id,
+                                                     const uint32_t* __restrict__ keep_scan, const uint32_t* __restrict__ state, uint32_t last_id,
                                                      const uint32_t* __restrict__ cl_ref, const Box6* __restrict__ cl_box,
                                                      uint32_t* __restrict__ cl_ref_out, Box6* __restrict__ cl_box_out,
                                                      uint32_t* __restrict__ left, uint32_t* __restrict__ right, uint32_t* __restrict__ node_parent,
                                                      uint32_t* __restrict__ leaf_parent, uint32_t* __restrict__ subtree,
                                                      Box6* __restrict__ node_box, float pad) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t m = state[0], next_id = last_id - state[1];  // last_id = n - 2: ids count down from it as nodes are created
   if (i >= m || !keepc[i]) return;
   const uint32_t pos = keep_scan[i];
   if (!merge[i]) { cl_ref_out[pos] = cl_ref[i]; cl_box_out[pos] = cl_box[i]; return; }
@@ -540,6 +547,15 @@ __global__ void __launch_bounds__(256) k_ploc_apply(const uint32_t* __restrict__
 #pragma unroll
   for (int c = 0; c < 3; ++c) { w.mn[c] = u.mn[c] - pad; w.mx[c] = u.mx[c] + pad; }
   node_box[id] = w;
+}
+// closes a round: state = {m - merged, created + merged}
+__global__ void k_ploc_advance(const uint32_t* __restrict__ merge, const uint32_t* __restrict__ merge_scan, uint32_t* __restrict__ state) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  const uint32_t m = state[0];
+  if (m == 0u) return;
+  const uint32_t merged = merge_scan[m - 1u] + merge[m - 1u];
+  state[0] = m - merged;
+  state[1] += merged;
 }
 // The last rounds in ONE workgroup: once kPlocTail or fewer clusters are left (27 of the ~60 rounds of a million-triangle build)
 // a round is far shorter than its six launches and two host round trips.  Same nearest-neighbour rule, same flags, same ids
@@ -833,6 +849,14 @@ static std::string ploc_hierarchy(BvhBuffers& b, BvhTopology& t, hipStream_t s) 
   if (const char* ev = getenv("HALART_PLOC_RADIUS")) radius = (uint32_t)std::max(1, atoi(ev));  // tuning knob
   bool tail = true;
   if (const char* ev = getenv("HALART_PLOC_TAIL")) tail = atoi(ev) != 0;  // A/B knob: 0 = every round as separate launches
+  // rounds between two looks at the device's counters: a look is a host round trip (~50 us, as long as a late round itself); the
+  // grid of the rounds in between is sized for the count of the last look (clusters only get fewer).  Same tree for any value.
+  uint32_t look_every = 6;
+  if (const char* ev = getenv("HALART_PLOC_LOOK_EVERY")) look_every = (uint32_t)std::max(1, atoi(ev));  // A/B knob
+  DevBuf state;
+  if (!(e = state.alloc(8)).empty()) return e;
+  const uint32_t init_state[2] = {n, 0u};
+  HIP_TRY(hipMemcpyAsync(state.p, init_state, 8, hipMemcpyHostToDevice, s));
   while (m > 1) {
     if (tail && m <= kPlocTail) {
       hipLaunchKernelGGL(k_ploc_tail, dim3(1), dim3(kPlocTail), 0, s, m, radius, (ni - 1u) - created, ref[cur].as<uint32_t>(), box[cur].as<Box6>(),
@@ -840,25 +864,28 @@ static std::string ploc_hierarchy(BvhBuffers& b, BvhTopology& t, hipStream_t s) 
                          subtree.as<uint32_t>(), t.node_box.as<Box6>(), box_pad(b));
       break;
     }
-    hipLaunchKernelGGL(k_ploc_nearest, dim3(nblk(m)), dim3(256), 0, s, box[cur].as<Box6>(), m, radius, nn.as<uint32_t>());
-    hipLaunchKernelGGL(k_ploc_flags, dim3(nblk(m)), dim3(256), 0, s, nn.as<uint32_t>(), m, merge.as<uint32_t>(), keepc.as<uint32_t>());
-    size_t tb = tmp_bytes;
-    HIP_TRY(rocprim::exclusive_scan(tmp.p, tb, merge.as<uint32_t>(), merge_scan.as<uint32_t>(), 0u, m, rocprim::plus<uint32_t>(), s));
-    tb = tmp_bytes;
-    HIP_TRY(rocprim::exclusive_scan(tmp.p, tb, keepc.as<uint32_t>(), keep_scan.as<uint32_t>(), 0u, m, rocprim::plus<uint32_t>(), s));
-    hipLaunchKernelGGL(k_ploc_apply, dim3(nblk(m)), dim3(256), 0, s, nn.as<uint32_t>(), merge.as<uint32_t>(), keepc.as<uint32_t>(),
-                       merge_scan.as<uint32_t>(), keep_scan.as<uint32_t>(), m, (ni - 1u) - created, ref[cur].as<uint32_t>(), box[cur].as<Box6>(),
-                       ref[cur ^ 1].as<uint32_t>(), box[cur ^ 1].as<Box6>(), t.left.as<uint32_t>(), t.right.as<uint32_t>(),
-                       t.node_parent.as<uint32_t>(), t.leaf_parent.as<uint32_t>(), subtree.as<uint32_t>(), t.node_box.as<Box6>(), box_pad(b));
-    uint32_t last_scan = 0, last_flag = 0;
-    HIP_TRY(hipMemcpyAsync(&last_scan, merge_scan.as<uint32_t>() + (m - 1), 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(&last_flag, merge.as<uint32_t>() + (m - 1), 4, hipMemcpyDeviceToHost, s));
+    const uint32_t bound = m;
+    for (uint32_t round = 0; round < look_every; ++round) {
+      hipLaunchKernelGGL(k_ploc_nearest, dim3(nblk(bound)), dim3(256), 0, s, box[cur].as<Box6>(), state.as<uint32_t>(), radius, nn.as<uint32_t>());
+      hipLaunchKernelGGL(k_ploc_flags, dim3(nblk(bound)), dim3(256), 0, s, nn.as<uint32_t>(), state.as<uint32_t>(), bound, merge.as<uint32_t>(),
+                         keepc.as<uint32_t>());
+      size_t tb = tmp_bytes;
+      HIP_TRY(rocprim::exclusive_scan(tmp.p, tb, merge.as<uint32_t>(), merge_scan.as<uint32_t>(), 0u, bound, rocprim::plus<uint32_t>(), s));
+      tb = tmp_bytes;
+      HIP_TRY(rocprim::exclusive_scan(tmp.p, tb, keepc.as<uint32_t>(), keep_scan.as<uint32_t>(), 0u, bound, rocprim::plus<uint32_t>(), s));
+      hipLaunchKernelGGL(k_ploc_apply, dim3(nblk(bound)), dim3(256), 0, s, nn.as<uint32_t>(), merge.as<uint32_t>(), keepc.as<uint32_t>(),
+                         merge_scan.as<uint32_t>(), keep_scan.as<uint32_t>(), state.as<uint32_t>(), ni - 1u, ref[cur].as<uint32_t>(), box[cur].as<Box6>(),
+                         ref[cur ^ 1].as<uint32_t>(), box[cur ^ 1].as<Box6>(), t.left.as<uint32_t>(), t.right.as<uint32_t>(),
+                         t.node_parent.as<uint32_t>(), t.leaf_parent.as<uint32_t>(), subtree.as<uint32_t>(), t.node_box.as<Box6>(), box_pad(b));
+      hipLaunchKernelGGL(k_ploc_advance, dim3(1), dim3(64), 0, s, merge.as<uint32_t>(), merge_scan.as<uint32_t>(), state.as<uint32_t>());
+      cur ^= 1;
+    }
+    uint32_t now[2] = {0u, 0u};
+    HIP_TRY(hipMemcpyAsync(now, state.p, 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    const uint32_t merged = last_scan + last_flag;
-    if (merged == 0) return "bvh_build: PLOC made no progress";  // cannot happen: the closest pair is always mutual
-    created += merged;
-    m -= merged;
-    cur ^= 1;
+    if (now[0] >= m) return "bvh_build: PLOC made no progress";  // cannot happen: the closest pair is always mutual
+    m = now[0];
+    created = now[1];
   }
   static const uint32_t absent = kAbsent;
   HIP_TRY(hipMemcpyAsync(t.node_parent.p, &absent, 4, hipMemcpyHostToDevice, s));  // node 0 is the root

@@ -346,19 +346,22 @@ def test_refit_after_vertex_deformation(halart, oracle):
     r.close()
 
 
-def test_ploc_single_workgroup_tail_builds_the_same_tree(halart, oracle, monkeypatch):
-    """the last PLOC rounds (<= 512 clusters) run inside one workgroup (k_ploc_tail); with HALART_PLOC_TAIL=0 every round is its own set
-    of launches: the two builders must emit byte-identical nodes and triangle orders"""
+def test_ploc_drivers_build_the_same_tree(halart, oracle, monkeypatch):
+    """PLOC's rounds are driven three ways — every round looked at by the host (HALART_PLOC_LOOK_EVERY=1), several rounds between two
+    looks with the counters on the device (the default, and an odd value), the last rounds (<= 512 clusters) inside one workgroup
+    (k_ploc_tail) or not (HALART_PLOC_TAIL=0): all of them must emit byte-identical nodes and triangle orders"""
     s = scenes.sponza_class(target_triangles=60_000)
     trees = []
-    for tail in ("1", "0"):
+    for tail, look in (("1", "4"), ("0", "1"), ("1", "1"), ("0", "7")):
         monkeypatch.setenv("HALART_PLOC_TAIL", tail)
+        monkeypatch.setenv("HALART_PLOC_LOOK_EVERY", look)
         r = make_renderer(halart, s, 16, 16)
         trees.append(r.download_bvh())
         info = r.bvh_info()
         r.close()
     assert info.triangle_count >= 4096  # PLOC is the builder at this size
-    assert trees[0][0].tobytes() == trees[1][0].tobytes() and trees[0][1].tobytes() == trees[1][1].tobytes()
+    for nodes, tris in trees[1:]:
+        assert nodes.tobytes() == trees[0][0].tobytes() and tris.tobytes() == trees[0][1].tobytes()
     osc = oracle.OracleScene(s)
     rc, _ = oracle.validate_bvh(trees[0][0], trees[0][1], osc.triangles())
     assert rc == 0
