@@ -360,12 +360,16 @@ RT_DI float half_area(const Box6& b) {
   const float dx = b.mx[0] - b.mn[0], dy = b.mx[1] - b.mn[1], dz = b.mx[2] - b.mn[2];
   return dx * dy + dy * dz + dz * dx;
 }
-__global__ void __launch_bounds__(256) k_collapse_level(const uint32_t* __restrict__ root_of, uint32_t base, uint32_t size,
+// The level kernels take the level's first node and size from device memory (level[0], level[1]; k_level_advance closes a level):
+// the host only knows an upper bound of the size — the grid — and looks at the counters every few levels.
+__global__ void __launch_bounds__(256) k_collapse_level(const uint32_t* __restrict__ root_of, const uint32_t* __restrict__ level, uint32_t bound,
                                                          const uint32_t* __restrict__ left, const uint32_t* __restrict__ right,
                                                          const uint32_t* __restrict__ keep, const Box6* __restrict__ node_box,
                                                          uint4* __restrict__ refs4, uint32_t* __restrict__ cnt) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= size) return;
+  if (j >= bound) return;
+  const uint32_t base = level[0], size = level[1];
+  if (j >= size) { cnt[j] = 0u; return; }  // the scan runs over the host's bound
   const uint32_t i = root_of[base + j];
   uint32_t c[4] = {left[i], right[i], kAbsent, kAbsent};
   int n = 2;
@@ -392,10 +396,11 @@ __global__ void __launch_bounds__(256) k_collapse_level(const uint32_t* __restri
   for (int k = 0; k < n; ++k) inner += (!(c[k] & kLeafBit) && keep[c[k]]) ? 1u : 0u;
   cnt[j] = inner;
 }
-__global__ void __launch_bounds__(256) k_scatter_level(uint32_t* __restrict__ root_of, uint32_t base, uint32_t size, const uint4* __restrict__ refs4,
+__global__ void __launch_bounds__(256) k_scatter_level(uint32_t* __restrict__ root_of, const uint32_t* __restrict__ level, const uint4* __restrict__ refs4,
                                                         const uint32_t* __restrict__ keep, const uint32_t* __restrict__ off,
                                                         uint32_t* __restrict__ index4) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t base = level[0], size = level[1];
   if (j >= size) return;
   const uint4 q = refs4[base + j];
   const uint32_t c[4] = {q.x, q.y, q.z, q.w};
@@ -407,6 +412,17 @@ __global__ void __launch_bounds__(256) k_scatter_level(uint32_t* __restrict__ ro
     index4[r] = pos;
     ++pos;
   }
+}
+// closes a level: level = {base + size, inner children found, levels so far + 1}; bases[l] = first node of level l
+__global__ void k_level_advance(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off, uint32_t* __restrict__ level,
+                                uint32_t* __restrict__ bases, uint32_t max_levels) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  const uint32_t base = level[0], size = level[1], l = level[2];
+  if (size == 0u) return;
+  if (l < max_levels) bases[l] = base;
+  level[0] = base + size;
+  level[1] = off[size - 1u] + cnt[size - 1u];
+  level[2] = l + 1u;
 }
 __global__ void __launch_bounds__(256) k_pack4(const uint4* __restrict__ refs4, uint32_t node_count, const uint32_t* __restrict__ first,
                                                 const uint32_t* __restrict__ last, const uint32_t* __restrict__ keep,
@@ -794,24 +810,38 @@ static std::string fit_and_emit(BvhBuffers& b, BvhTopology& t, hipStream_t s) {
     HIP_TRY(rocprim::exclusive_scan(nullptr, tmp_bytes, t.cnt.as<uint32_t>(), t.off.as<uint32_t>(), 0u, ni, rocprim::plus<uint32_t>(), s));
     std::string e = tmp.alloc(tmp_bytes);
     if (!e.empty()) return e;
-    uint32_t base = 0, size = 1, levels = 0;
-    t.level_base.clear();
-    while (size > 0) {
-      t.level_base.push_back(base);
-      hipLaunchKernelGGL(k_collapse_level, dim3(nblk(size)), dim3(256), 0, s, t.root_of.as<uint32_t>(), base, size, t.left.as<uint32_t>(),
-                         t.right.as<uint32_t>(), t.keep.as<uint32_t>(), t.node_box.as<Box6>(), t.refs4.as<uint4>(), t.cnt.as<uint32_t>());
-      size_t tb = tmp_bytes;
-      HIP_TRY(rocprim::exclusive_scan(tmp.p, tb, t.cnt.as<uint32_t>(), t.off.as<uint32_t>(), 0u, size, rocprim::plus<uint32_t>(), s));
-      hipLaunchKernelGGL(k_scatter_level, dim3(nblk(size)), dim3(256), 0, s, t.root_of.as<uint32_t>(), base, size, t.refs4.as<uint4>(),
-                         t.keep.as<uint32_t>(), t.off.as<uint32_t>(), t.index4.as<uint32_t>());
-      uint32_t last_off = 0, last_cnt = 0;
-      HIP_TRY(hipMemcpyAsync(&last_off, t.off.as<uint32_t>() + (size - 1), 4, hipMemcpyDeviceToHost, s));
-      HIP_TRY(hipMemcpyAsync(&last_cnt, t.cnt.as<uint32_t>() + (size - 1), 4, hipMemcpyDeviceToHost, s));
+    // levels are driven like PLOC's rounds: {first node, size, level} on the device, the host looks every few levels; between two
+    // looks the grid covers the largest size the level can have reached (a level is at most 4 times the one above, and < n)
+    constexpr uint32_t kMaxLevels = 96;
+    uint32_t look_every = 8;
+    if (const char* ev = getenv("HALART_COLLAPSE_LOOK_EVERY")) look_every = (uint32_t)std::max(1, atoi(ev));  // A/B knob
+    DevBuf level, bases;
+    if (!(e = level.alloc(16)).empty()) return e;
+    if (!(e = bases.alloc(kMaxLevels * 4)).empty()) return e;
+    const uint32_t init_level[3] = {0u, 1u, 0u};
+    HIP_TRY(hipMemcpyAsync(level.p, init_level, 12, hipMemcpyHostToDevice, s));
+    uint32_t now[3] = {0u, 1u, 0u};
+    while (now[1] > 0u) {
+      unsigned long long bound = now[1];
+      for (uint32_t k = 0; k < look_every; ++k) {
+        const uint32_t bd = (uint32_t)std::min<unsigned long long>(bound, ni);
+        hipLaunchKernelGGL(k_collapse_level, dim3(nblk(bd)), dim3(256), 0, s, t.root_of.as<uint32_t>(), level.as<uint32_t>(), bd, t.left.as<uint32_t>(),
+                           t.right.as<uint32_t>(), t.keep.as<uint32_t>(), t.node_box.as<Box6>(), t.refs4.as<uint4>(), t.cnt.as<uint32_t>());
+        size_t tb = tmp_bytes;
+        HIP_TRY(rocprim::exclusive_scan(tmp.p, tb, t.cnt.as<uint32_t>(), t.off.as<uint32_t>(), 0u, bd, rocprim::plus<uint32_t>(), s));
+        hipLaunchKernelGGL(k_scatter_level, dim3(nblk(bd)), dim3(256), 0, s, t.root_of.as<uint32_t>(), level.as<uint32_t>(), t.refs4.as<uint4>(),
+                           t.keep.as<uint32_t>(), t.off.as<uint32_t>(), t.index4.as<uint32_t>());
+        hipLaunchKernelGGL(k_level_advance, dim3(1), dim3(64), 0, s, t.cnt.as<uint32_t>(), t.off.as<uint32_t>(), level.as<uint32_t>(), bases.as<uint32_t>(),
+                           kMaxLevels);
+        bound *= 4ull;
+      }
+      HIP_TRY(hipMemcpyAsync(now, level.p, 12, hipMemcpyDeviceToHost, s));
       HIP_TRY(hipStreamSynchronize(s));
-      base += size;
-      size = last_off + last_cnt;
-      ++levels;
+      if (now[2] > kMaxLevels) return "bvh_build: the tree is deeper than " + std::to_string(kMaxLevels) + " 4-wide levels";
     }
+    const uint32_t base = now[0], levels = now[2];
+    t.level_base.assign(levels, 0u);
+    HIP_TRY(hipMemcpy(t.level_base.data(), bases.p, (size_t)levels * 4, hipMemcpyDeviceToHost));
     t.level_base.push_back(base);
     b.node_count = base;
     b.max_depth = levels;

@@ -352,9 +352,10 @@ def test_ploc_drivers_build_the_same_tree(halart, oracle, monkeypatch):
     (k_ploc_tail) or not (HALART_PLOC_TAIL=0): all of them must emit byte-identical nodes and triangle orders"""
     s = scenes.sponza_class(target_triangles=60_000)
     trees = []
-    for tail, look in (("1", "4"), ("0", "1"), ("1", "1"), ("0", "7")):
+    for tail, look, collapse_look in (("1", "6", "4"), ("0", "1", "1"), ("1", "1", "3"), ("0", "7", "9")):
         monkeypatch.setenv("HALART_PLOC_TAIL", tail)
         monkeypatch.setenv("HALART_PLOC_LOOK_EVERY", look)
+        monkeypatch.setenv("HALART_COLLAPSE_LOOK_EVERY", collapse_look)  # the 4-wide collapse walks its levels the same way
         r = make_renderer(halart, s, 16, 16)
         trees.append(r.download_bvh())
         info = r.bvh_info()
