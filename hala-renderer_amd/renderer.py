@@ -126,7 +126,8 @@ class HalaRenderer:
         self._check(self._lib.hala_rt_update_batch(self._h, C.c_uint32(frames)))
 
     def render(self):
-        """src/rt_renderer.rs:475-502"""
+        """src/rt_renderer.rs:475-502: nothing to present; bounds the updates in flight to two (it does not flush: read_image,
+        save_images, statistics and wait_idle wait for the stream themselves)"""
         self._check(self._lib.hala_rt_render(self._h))
 
     def wait_idle(self):
