@@ -274,6 +274,31 @@ def test_rtprog_trace_rays_and_indirect(halart, oracle):
     r.close()
 
 
+def test_launch_timing_period(halart):
+    """hala_rt_set_launch_timing_period: per-launch events on every n-th update only; ray totals and frame times are always
+    collected, the *_timed ray counters follow the timed updates, and the image does not depend on it"""
+    s = scenes.cornell_box()
+    imgs = []
+    for period, timed_updates in ((1, 6), (3, 2), (0, 0)):
+        r = make_renderer(halart, s, 64, 48)
+        r.set_launch_timing_period(period)
+        for _ in range(6):
+            r.update(); r.render()
+        st = r.statistics()
+        imgs.append(r.read_image(0))
+        assert st.total_frames == 6 and st.rays_total == st.rays_closest_total + st.rays_shadow_total and st.gpu_ms_total > 0.0
+        assert st.traverse_primary_launches == timed_updates
+        assert st.traverse_closest_launches == timed_updates * 5 and st.traverse_shadow_launches == timed_updates * 5  # max_depth 5
+        assert st.rays_primary_timed == timed_updates * 64 * 48
+        if period == 1:
+            assert (st.rays_closest_timed, st.rays_shadow_timed) == (st.rays_closest_total, st.rays_shadow_total)
+            assert st.traverse_closest_ms_total > 0.0
+        if period == 0:
+            assert st.traverse_closest_ms_total == 0.0 and st.rays_closest_timed == 0
+        r.close()
+    assert imgs[0].tobytes() == imgs[1].tobytes() == imgs[2].tobytes()
+
+
 def test_load_blue_noise_texture_from_file(halart, tmp_path):
     """load_blue_noise_texture(path) (src/rt_renderer.rs:1117-1156): PNG decoded by the library itself; the reference's messages for a
     missing file / an empty name; the texture is accepted and unused (RENDER_SPEC 2.3), so the render does not change"""
