@@ -161,6 +161,7 @@ struct hala_rt_renderer {
   hala_global_uniform last_uniform{};
   TraceEvents ring[kStatRing];
   int ring_pos = 0;
+  bool vertices_dirty = false;  // hala_rt_update_vertices since the last refit
   uint32_t launch_event_period = 1;  // per-launch timing events on every n-th update (hala_rt_set_launch_timing_period)
   unsigned long long update_counter = 0;
   hala_rt_statistics stats{};
@@ -997,6 +998,7 @@ int hala_rt_update_vertices(hala_rt_renderer* r, uint32_t mesh_index, uint32_t p
   memcpy(p.vertices.data(), vertices, (size_t)vertex_count * sizeof(hala_vertex));
   // the copy below reads the renderer's own host copy, which outlives it; earlier frames still read the arena: wait for them
   RT_HIP(hipStreamSynchronize(r->stream));
+  r->vertices_dirty = true;
   if (vertex_count) RT_HIP(hipMemcpyAsync(r->d_vertices.ptr + r->prim_vertex_offset[first + primitive_index], p.vertices.data(), (size_t)vertex_count * sizeof(hala_vertex), hipMemcpyHostToDevice, r->stream));
   return HALA_OK;
 }
@@ -1004,14 +1006,21 @@ int hala_rt_refit(hala_rt_renderer* r) {
   if (ensure_device(r) != HALA_OK) return HALA_ERR;
   if (!r->committed) RT_FAIL("The top level acceleration structure is none!");
   RT_HIP(hipStreamSynchronize(r->stream));
+  const std::vector<hala_gpu_mesh_data> before = r->hs.instances;  // object -> world of every instance as the tree was fitted to it
   r->hs.update_node_hierarchies();
   const std::string e = r->hs.pack();
   if (!e.empty()) RT_FAIL(e);
   if (upload_packed(r, false) != HALA_OK) return HALA_ERR;
   r->bvh.primitives = r->d_instances.ptr; r->bvh.inst_first_tri = r->d_inst_first_tri.ptr;
-  const std::string e2 = bvh_refit(r->bvh, r->stream);
-  if (!e2.empty()) RT_FAIL(e2);
-  if (configure_traversal(r) != HALA_OK) return HALA_ERR;
+  // only cameras / lights moved (the interactive case: a camera node): the geometry and its tree stand as they are
+  bool geometry_moved = r->vertices_dirty || before.size() != r->hs.instances.size();
+  for (size_t i = 0; i < before.size() && !geometry_moved; ++i) geometry_moved = memcmp(before[i].transform, r->hs.instances[i].transform, 64) != 0;
+  if (geometry_moved) {
+    const std::string e2 = bvh_refit(r->bvh, r->stream);
+    if (!e2.empty()) RT_FAIL(e2);
+    if (configure_traversal(r) != HALA_OK) return HALA_ERR;
+    r->vertices_dirty = false;
+  }
   r->reset_accumulation();  // like the device-lost path: accumulation restarts (src/rt_renderer.rs:557)
   return HALA_OK;
 }

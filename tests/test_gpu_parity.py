@@ -342,6 +342,27 @@ def test_refit_after_node_transform(halart, oracle):
     r.close()
 
 
+def test_refit_with_only_the_camera_moved(halart, oracle):
+    """the interactive case: update_node_transform on the camera node + refit re-publishes the camera record and restarts the
+    accumulation; the geometry did not move, so the tree is left alone (same bytes) and the new view matches the oracle"""
+    s = scenes.cornell_box()
+    cam = next(k for k, n in enumerate(s.nodes) if n.camera_index != 0xFFFFFFFF)
+    r = make_renderer(halart, s, 40, 30)
+    r.update(); r.render()
+    n0, t0 = r.download_bvh()
+    m = scenes.look_at_node_transform((150.0, 320.0, -650.0), (278.0, 250.0, 280.0))
+    r.update_node_transform(cam, m)
+    r.refit()
+    n1, t1 = r.download_bvh()
+    assert n0.tobytes() == n1.tobytes() and t0.tobytes() == t1.tobytes()
+    r.update(); r.update(); r.render()
+    s.nodes[cam].local_transform = m
+    img, _ = oracle.OracleScene(s).render(40, 30, frames=2)
+    assert r.read_image(0).tobytes() == img[0].tobytes()
+    assert r.statistics().total_frames == 2
+    r.close()
+
+
 def test_refit_after_vertex_deformation(halart, oracle):
     """hala_rt_update_vertices + refit: a sheet of the atrium is rippled in place; the refitted tree must
     bound the new triangles, and rays / a small render must match the oracle built from the deformed scene"""
