@@ -191,7 +191,7 @@ EXPORTS = [
     "hala_rt_read_texture_level", "hala_rt_sample_texture_host", "hala_rt_set_tile_shard",
     "hala_rt_tile_buffer", "hala_rt_get_stream", "hala_rt_scatter_gathered_tiles", "hala_rt_scatter_gathered_tiles_on_stream", "hala_rt_trace_rays",
     "hala_rt_trace_rays_host", "hala_rt_trace_rays_indirect", "hala_rt_get_bvh_info", "hala_rt_download_bvh",
-    "hala_rt_update_node_transform", "hala_rt_update_vertices", "hala_rt_refit", "hala_envmap_build_distribution",
+    "hala_rt_update_node_transform", "hala_rt_update_vertices", "hala_rt_update_material", "hala_rt_refit", "hala_envmap_build_distribution",
     "hala_tonemap_pixels", "hala_write_pfm", "hala_rtprog_parse_desc", "hala_version",
     "hala_scene_load_gltf", "hala_scene_get_desc", "hala_scene_free", "hala_load_float_image",
 ]

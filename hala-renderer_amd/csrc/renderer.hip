@@ -1002,6 +1002,13 @@ int hala_rt_update_vertices(hala_rt_renderer* r, uint32_t mesh_index, uint32_t p
   if (vertex_count) RT_HIP(hipMemcpyAsync(r->d_vertices.ptr + r->prim_vertex_offset[first + primitive_index], p.vertices.data(), (size_t)vertex_count * sizeof(hala_vertex), hipMemcpyHostToDevice, r->stream));
   return HALA_OK;
 }
+int hala_rt_update_material(hala_rt_renderer* r, uint32_t material_index, const hala_material_desc* material) {
+  if (!r || !material) RT_FAIL("Invalid argument.");
+  if (!r->has_scene || material_index >= r->hs.materials.size()) RT_FAIL("The material does not exist.");
+  if (material->type > 1u) RT_FAIL("Invalid material type.");  // cpu/material.rs:14
+  r->hs.materials[material_index] = *material;
+  return HALA_OK;
+}
 int hala_rt_refit(hala_rt_renderer* r) {
   if (ensure_device(r) != HALA_OK) return HALA_ERR;
   if (!r->committed) RT_FAIL("The top level acceleration structure is none!");

@@ -254,6 +254,13 @@ class HalaRenderer:
         v = np.ascontiguousarray(vertices, dtype=A.VERTEX_DTYPE)
         self._check(self._lib.hala_rt_update_vertices(self._h, C.c_uint32(mesh_index), C.c_uint32(primitive_index), C.c_void_p(v.ctypes.data), C.c_uint32(v.shape[0])))
 
+    def update_material(self, material_index, material):
+        """replace one cpu::HalaMaterial of the scene (interactive material edits); applied by the next refit()"""
+        from .scene import fill_material_desc
+        d = A.MaterialDesc()
+        fill_material_desc(d, material)
+        self._check(self._lib.hala_rt_update_material(self._h, C.c_uint32(material_index), C.byref(d)))
+
     def refit(self):
         self._check(self._lib.hala_rt_refit(self._h))
 

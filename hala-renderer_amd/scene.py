@@ -160,6 +160,35 @@ def _f3(t):
     return (C.c_float * 3)(*[float(x) for x in t])
 
 
+def fill_material_desc(d, m):
+    """cpu::HalaMaterial -> the C ABI record (src/scene/cpu/material.rs:24-50)"""
+    d.type = m.type
+    d.base_color = _f3(m.base_color)
+    d.opacity = m.opacity
+    d.emission = _f3(m.emission)
+    d.anisotropic = m.anisotropic
+    d.metallic = m.metallic
+    d.roughness = m.roughness
+    d.subsurface = m.subsurface
+    d.specular_tint = m.specular_tint
+    d.sheen = m.sheen
+    d.sheen_tint = m.sheen_tint
+    d.clearcoat = m.clearcoat
+    d.clearcoat_roughness = m.clearcoat_roughness
+    d.clearcoat_tint = _f3(m.clearcoat_tint)
+    d.specular_transmission = m.specular_transmission
+    d.ior = m.ior
+    d.medium_type = m.medium.type
+    d.medium_color = _f3(m.medium.color)
+    d.medium_density = m.medium.density
+    d.medium_anisotropy = m.medium.anisotropy
+    d.base_color_map_index = m.base_color_map_index
+    d.emission_map_index = m.emission_map_index
+    d.normal_map_index = m.normal_map_index
+    d.metallic_roughness_map_index = m.metallic_roughness_map_index
+
+
+
 class SceneDescHolder:
     """Owns the ctypes tree of a hala_scene_desc; keep it alive for the duration of the call."""
 
@@ -194,31 +223,7 @@ class SceneDescHolder:
             meshes[i].primitive_count = len(mesh.primitives)
         mats = (A.MaterialDesc * max(len(scene.materials), 1))()
         for i, m in enumerate(scene.materials):
-            d = mats[i]
-            d.type = m.type
-            d.base_color = _f3(m.base_color)
-            d.opacity = m.opacity
-            d.emission = _f3(m.emission)
-            d.anisotropic = m.anisotropic
-            d.metallic = m.metallic
-            d.roughness = m.roughness
-            d.subsurface = m.subsurface
-            d.specular_tint = m.specular_tint
-            d.sheen = m.sheen
-            d.sheen_tint = m.sheen_tint
-            d.clearcoat = m.clearcoat
-            d.clearcoat_roughness = m.clearcoat_roughness
-            d.clearcoat_tint = _f3(m.clearcoat_tint)
-            d.specular_transmission = m.specular_transmission
-            d.ior = m.ior
-            d.medium_type = m.medium.type
-            d.medium_color = _f3(m.medium.color)
-            d.medium_density = m.medium.density
-            d.medium_anisotropy = m.medium.anisotropy
-            d.base_color_map_index = m.base_color_map_index
-            d.emission_map_index = m.emission_map_index
-            d.normal_map_index = m.normal_map_index
-            d.metallic_roughness_map_index = m.metallic_roughness_map_index
+            fill_material_desc(mats[i], m)
         lights = (A.LightDesc * max(len(scene.lights), 1))()
         for i, l in enumerate(scene.lights):
             lights[i].color = _f3(l.color)

@@ -492,7 +492,11 @@ int hala_rt_update_node_transform(hala_rt_renderer* r, uint32_t node_index, cons
  * index buffer, stays); host pointer, copied before the call returns.  Takes effect at the next hala_rt_refit. */
 int hala_rt_update_vertices(hala_rt_renderer* r, uint32_t mesh_index, uint32_t primitive_index, const hala_vertex* vertices,
                             uint32_t vertex_count);
-/* Applies the edits: node hierarchies, camera / light / instance records, and — if an instance's transform or a primitive's vertices
+/* Replaces material `material_index` of the scene (cpu::HalaMaterial, the record hala_rt_set_scene took); texture indices must stay
+ * within the scene's textures.  Takes effect at the next hala_rt_refit (which re-publishes the packed 144-B records; the geometry
+ * is untouched, so is the tree). */
+int hala_rt_update_material(hala_rt_renderer* r, uint32_t material_index, const hala_material_desc* material);
+/* Applies the edits: node hierarchies, materials, camera / light / instance records, and — if an instance's transform or a primitive's vertices
  * changed — the tree (topology kept, boxes re-derived).  A move of camera or light nodes alone leaves the tree untouched.  The
  * accumulation restarts either way. */
 int hala_rt_refit(hala_rt_renderer* r);

@@ -84,6 +84,7 @@ pub mod sys {
     pub fn hala_rt_trace_rays_indirect(r: *mut hala_rt_renderer, d_rays: *const hala_ray, d_hits: *mut hala_hit, d_indirect: *const u32,
                                        mode: c_int, hip_stream: *mut c_void) -> c_int;
     pub fn hala_rt_update_node_transform(r: *mut hala_rt_renderer, node_index: u32, local_transform: *const f32) -> c_int;
+    pub fn hala_rt_update_material(r: *mut hala_rt_renderer, material_index: u32, material: *const hala_material_desc) -> c_int;
     pub fn hala_rt_update_vertices(r: *mut hala_rt_renderer, mesh_index: u32, primitive_index: u32, vertices: *const hala_vertex, vertex_count: u32) -> c_int;
     pub fn hala_rt_refit(r: *mut hala_rt_renderer) -> c_int;
     pub fn hala_rt_load_blue_noise_texture(r: *mut hala_rt_renderer, path: *const c_char) -> c_int;

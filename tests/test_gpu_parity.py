@@ -363,6 +363,31 @@ def test_refit_with_only_the_camera_moved(halart, oracle):
     r.close()
 
 
+def test_refit_after_material_edit(halart, oracle):
+    """hala_rt_update_material + refit: the packed material records are re-published (the tree is left alone), the accumulation
+    restarts and the frame matches the oracle of the edited scene — diffuse to Disney glass with an absorbing medium"""
+    s = scenes.cornell_box()
+    r = make_renderer(halart, s, 40, 30, max_depth=8)
+    r.update(); r.render()
+    n0, t0 = r.download_bvh()
+    before = r.read_image(0)
+    new = H.HalaMaterial(type=1, base_color=(0.9, 0.95, 1.0), metallic=0.0, roughness=0.08, specular_transmission=1.0, ior=1.5,
+                         medium=H.HalaMedium(1, (0.8, 0.9, 1.0), 0.004, 0.0))
+    target = s.meshes[s.nodes[2].mesh_index].primitives[0].material_index  # the tall block's material
+    with pytest.raises(Exception, match="The material does not exist"):
+        r.update_material(len(s.materials), new)
+    r.update_material(target, new)
+    r.refit()
+    n1, t1 = r.download_bvh()
+    assert n0.tobytes() == n1.tobytes() and t0.tobytes() == t1.tobytes()
+    r.update(); r.update(); r.render()
+    s.materials[target] = new
+    img, _ = oracle.OracleScene(s).render(40, 30, frames=2, max_depth=8)
+    assert r.read_image(0).tobytes() == img[0].tobytes()
+    assert np.abs(r.read_image(0) - before).max() > 0.05
+    r.close()
+
+
 def test_refit_after_vertex_deformation(halart, oracle):
     """hala_rt_update_vertices + refit: a sheet of the atrium is rippled in place; the refitted tree must
     bound the new triangles, and rays / a small render must match the oracle built from the deformed scene"""
