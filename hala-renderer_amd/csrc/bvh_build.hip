@@ -253,7 +253,9 @@ __global__ void __launch_bounds__(256) k_hierarchy(const unsigned long long* __r
 }
 
 __global__ void __launch_bounds__(256) k_leaf_boxes(const Box6* __restrict__ tri_box, const uint32_t* __restrict__ sorted_ids, uint32_t n,
-                                                     Box6* __restrict__ leaf_box, const Tri* __restrict__ tris_by_id, Tri* __restrict__ tris, float pad) {
+                                                     Box6* __restrict__ leaf_box, const Tri* __restrict__ tris_by_id, Tri* __restrict__ tris, float pad,
+                                                     Tri* __restrict__ tris_any, const ShadeTri* __restrict__ shade_tris,
+                                                     const hala_gpu_material* __restrict__ materials, uint32_t material_count) {
   const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
   const uint32_t id = sorted_ids[k];
@@ -267,6 +269,14 @@ __global__ void __launch_bounds__(256) k_leaf_boxes(const Box6* __restrict__ tri
   const float4* src = reinterpret_cast<const float4*>(tris_by_id + id);
   float4* dst = reinterpret_cast<float4*>(tris + k);
   dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+  if (tris_any) {  // RENDER_SPEC 7.1d: shadow rays do not see surfaces of opacity exactly 0 — their triangles are degenerate in this copy
+    const uint32_t mi = shade_tris[id].material;
+    const bool gone = mi < material_count && materials[mi].opacity == 0.0f;
+    float4* da = reinterpret_cast<float4*>(tris_any + k);
+    da[0] = src[0];
+    da[1] = gone ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : src[1];
+    da[2] = gone ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : src[2];
+  }
 }
 
 RT_DI Box6 box_union(const Box6& a, const Box6& b) {
@@ -773,7 +783,7 @@ static std::string flatten_and_bounds(BvhBuffers& b, BvhTopology& t, hipStream_t
 static std::string fit_and_emit(BvhBuffers& b, BvhTopology& t, hipStream_t s) {
   const uint32_t n = b.tri_count;
   if (n) hipLaunchKernelGGL(k_leaf_boxes, dim3(nblk(n)), dim3(256), 0, s, t.tri_box.as<Box6>(), t.sorted_ids.as<uint32_t>(), n,
-                            t.leaf_box.as<Box6>(), b.tris_by_id, b.tris, box_pad(b));
+                            t.leaf_box.as<Box6>(), b.tris_by_id, b.tris, box_pad(b), b.tris_any, b.shade_tris, b.materials, b.material_count);
   if (n <= t.leaf_max || n < 2) {
     hipLaunchKernelGGL(k_emit_single4, dim3(1), dim3(64), 0, s, t.leaf_box.as<Box6>(), n, b.nodes);
     b.node_count = 1;

@@ -87,6 +87,8 @@ struct SceneView {
   uint32_t pad0;
   const BvhNode4* nodes;
   const Tri* tris;             // BVH order
+  const Tri* tris_any;         // what the any-hit launches traverse (RENDER_SPEC 7.1d): == tris unless the scene has opacity-0 materials,
+                               // whose triangles are degenerate (never hit) in this copy — no test in the kernels, the launcher swaps the pointer
   const Tri* tris_by_id;       // global-id order (for shading)
   const ShadeTri* shade_tris;  // global-id order: per-vertex attributes of the hit triangle in one record
   const uint32_t* tri_instance;  // global id -> instance

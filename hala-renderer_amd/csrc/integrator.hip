@@ -633,12 +633,16 @@ void launch_trace_batch(const LaunchCfg& lc, const SceneView& sv, const hala_ray
                               launch_trace_batch_t<false, true, false>,  launch_trace_batch_t<false, true, true>,
                               launch_trace_batch_t<true, false, false>,  launch_trace_batch_t<true, false, true>,
                               launch_trace_batch_t<true, true, false>,   launch_trace_batch_t<true, true, true>};
-  table[(any ? 4 : 0) | (count ? 2 : 0) | (sv.staged ? 1 : 0)](lc, sv, rays, hits, n_ptr, n_imm, work, ctl, acc, traverse_smem(sv), s);
+  SceneView sva = sv;
+  if (any) sva.tris = sv.tris_any;  // RENDER_SPEC 7.1d
+  table[(any ? 4 : 0) | (count ? 2 : 0) | (sv.staged ? 1 : 0)](lc, sva, rays, hits, n_ptr, n_imm, work, ctl, acc, traverse_smem(sv), s);
 }
 
-void launch_trace_shadow(const LaunchCfg& lc, const SceneView& sv, const Queues& q, const PathState& ps, Control* ctl, uint32_t depth,
+void launch_trace_shadow(const LaunchCfg& lc, const SceneView& sv0, const Queues& q, const PathState& ps, Control* ctl, uint32_t depth,
                          uint32_t kind, bool count, hipStream_t s) {
-  const size_t smem = traverse_smem(sv);
+  const size_t smem = traverse_smem(sv0);
+  SceneView sv = sv0;
+  sv.tris = sv0.tris_any;  // RENDER_SPEC 7.1d: shadow rays traverse the copy in which invisible surfaces are degenerate
   dim3 grid(lc.persistent_blocks), block(kTraverseThreads);
   if (sv.staged) {
     if (count) hipLaunchKernelGGL((k_trace_shadow<true, true>), grid, block, smem, s, sv, q, ps, ctl, depth, kind, lc.spill, lc.refill);

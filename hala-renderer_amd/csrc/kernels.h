@@ -43,6 +43,9 @@ struct BvhBuffers {
   // outputs (device, allocated by the caller)
   Tri* tris_by_id;         // [tri_count]
   Tri* tris;               // [tri_count] BVH order
+  Tri* tris_any = nullptr; // [tri_count] BVH order, triangles of opacity-0 materials degenerate; null: the scene has none
+  const hala_gpu_material* materials = nullptr;  // for tris_any
+  uint32_t material_count = 0;
   ShadeTri* shade_tris;    // [tri_count] global-id order
   uint32_t* tri_instance;  // [tri_count]
   BvhNode4* nodes;         // capacity >= max(tri_count - 1, 1)

@@ -124,6 +124,7 @@ struct hala_rt_renderer {
 
   BvhBuffers bvh{};
   DeviceArray<Tri> d_tris_by_id, d_tris;
+  DeviceArray<Tri> d_tris_any;
   DeviceArray<ShadeTri> d_shade_tris;
   DeviceArray<uint32_t> d_tri_instance;
   DeviceArray<BvhNode4> d_nodes;
@@ -162,6 +163,8 @@ struct hala_rt_renderer {
   TraceEvents ring[kStatRing];
   int ring_pos = 0;
   bool vertices_dirty = false;  // hala_rt_update_vertices since the last refit
+  bool materials_dirty_any = false;  // a material edit touched an opacity-0 material (old or new)
+  bool any_invisible = false;   // the scene has materials of opacity 0: the any-hit launches traverse d_tris_any (RENDER_SPEC 7.1d)
   uint32_t launch_event_period = 1;  // per-launch timing events on every n-th update (hala_rt_set_launch_timing_period)
   unsigned long long update_counter = 0;
   hala_rt_statistics stats{};
@@ -184,7 +187,7 @@ struct hala_rt_renderer {
 
   SceneView view() const {
     SceneView sv{};
-    sv.nodes = d_nodes.ptr; sv.tris = d_tris.ptr; sv.tris_by_id = d_tris_by_id.ptr; sv.shade_tris = d_shade_tris.ptr; sv.tri_instance = d_tri_instance.ptr;
+    sv.nodes = d_nodes.ptr; sv.tris = d_tris.ptr; sv.tris_any = any_invisible ? d_tris_any.ptr : d_tris.ptr; sv.tris_by_id = d_tris_by_id.ptr; sv.shade_tris = d_shade_tris.ptr; sv.tri_instance = d_tri_instance.ptr;
     sv.inst_first_tri = d_inst_first_tri.ptr; sv.primitives = d_instances.ptr; sv.materials = d_materials.ptr;
     sv.lights = d_lights.ptr; sv.cameras = d_cameras.ptr;
     sv.textures = d_textures.ptr; sv.tex_arena = d_tex_arena.ptr; sv.texture_count = (uint32_t)host_textures.size();
@@ -428,6 +431,17 @@ int configure_traversal(hala_rt_renderer* r) {
   return HALA_OK;
 }
 
+// RENDER_SPEC 7.1d: scenes with opacity-0 materials get a second copy of the BVH-order triangles for the any-hit launches
+int attach_any_triangles(hala_rt_renderer* r) {
+  r->any_invisible = false;
+  for (const auto& m : r->hs.materials) r->any_invisible = r->any_invisible || m.opacity == 0.0f;
+  if (r->any_invisible) RT_HIP(r->d_tris_any.resize(r->hs.triangle_count));
+  r->bvh.tris_any = r->any_invisible ? r->d_tris_any.ptr : nullptr;
+  r->bvh.materials = r->d_materials.ptr;
+  r->bvh.material_count = (uint32_t)r->hs.gpu_materials.size();
+  return HALA_OK;
+}
+
 int build_bvh(hala_rt_renderer* r) {
   const uint32_t n = r->hs.triangle_count;
   RT_HIP(r->d_tris_by_id.resize(n)); RT_HIP(r->d_tris.resize(n)); RT_HIP(r->d_tri_instance.resize(n)); RT_HIP(r->d_shade_tris.resize(n));
@@ -435,6 +449,7 @@ int build_bvh(hala_rt_renderer* r) {
   r->bvh.primitives = r->d_instances.ptr; r->bvh.inst_first_tri = r->d_inst_first_tri.ptr;
   r->bvh.instance_count = (uint32_t)r->hs.instances.size(); r->bvh.tri_count = n;
   r->bvh.tris_by_id = r->d_tris_by_id.ptr; r->bvh.shade_tris = r->d_shade_tris.ptr; r->bvh.tris = r->d_tris.ptr; r->bvh.tri_instance = r->d_tri_instance.ptr; r->bvh.nodes = r->d_nodes.ptr;
+  if (attach_any_triangles(r) != HALA_OK) return HALA_ERR;
   // a scene this small will be staged in LDS (configure_traversal: 48 B per triangle + at most ~32 B of nodes per triangle)
   uint32_t leaf_max = (size_t)n * 80 <= kLdsStageBudget ? kLeafMaxStaged : kLeafMax;
   if (const char* ev = getenv("HALART_LEAF_MAX")) leaf_max = std::min(8u, std::max(1u, (uint32_t)atoi(ev)));  // tuning knob
@@ -1006,6 +1021,7 @@ int hala_rt_update_material(hala_rt_renderer* r, uint32_t material_index, const 
   if (!r || !material) RT_FAIL("Invalid argument.");
   if (!r->has_scene || material_index >= r->hs.materials.size()) RT_FAIL("The material does not exist.");
   if (material->type > 1u) RT_FAIL("Invalid material type.");  // cpu/material.rs:14
+  if (r->hs.materials[material_index].opacity == 0.0f || material->opacity == 0.0f) r->materials_dirty_any = true;
   r->hs.materials[material_index] = *material;
   return HALA_OK;
 }
@@ -1020,7 +1036,11 @@ int hala_rt_refit(hala_rt_renderer* r) {
   if (upload_packed(r, false) != HALA_OK) return HALA_ERR;
   r->bvh.primitives = r->d_instances.ptr; r->bvh.inst_first_tri = r->d_inst_first_tri.ptr;
   // only cameras / lights moved (the interactive case: a camera node): the geometry and its tree stand as they are
-  bool geometry_moved = r->vertices_dirty || before.size() != r->hs.instances.size();
+  const bool had_invisible = r->any_invisible;
+  if (attach_any_triangles(r) != HALA_OK) return HALA_ERR;
+  // (a material edit can change which triangles the shadow rays see: their copy is rewritten by the refit pass)
+  bool geometry_moved = r->vertices_dirty || r->materials_dirty_any || had_invisible != r->any_invisible || before.size() != r->hs.instances.size();
+  r->materials_dirty_any = false;
   for (size_t i = 0; i < before.size() && !geometry_moved; ++i) geometry_moved = memcmp(before[i].transform, r->hs.instances[i].transform, 64) != 0;
   if (geometry_moved) {
     const std::string e2 = bvh_refit(r->bvh, r->stream);

@@ -253,6 +253,7 @@ extern "C" orc_scene* orc_scene_create(const orc_scene_desc* desc) {
   }
   s->materials.resize(desc->material_count);
   for (uint32_t i = 0; i < desc->material_count; ++i) orc_pack_material(&desc->materials[i], &s->materials[i]);
+  orc::make_any_triangles(s, s->tris, &s->tris_any);  // RENDER_SPEC 7.1d (needs the materials)
   s->camera_count = orc_pack_cameras(desc, s->cameras);
   if (s->camera_count < 0) s->camera_count = 0;
   s->light_count = orc_pack_lights(desc, s->lights, std::vector<orc_aabb>(32).data());
@@ -473,11 +474,25 @@ Hit scene_trace_closest(const orc_scene* s, V3 o, V3 d, float tmin, float tmax, 
   if (!traverse4<false>(s->ext_nodes.data(), s->ext_tris.data(), r, tmax, &h, c)) { h.t = -1.0f; h.u = 0.0f; h.v = 0.0f; h.prim = ORC_NONE; }
   return h;
 }
+// RENDER_SPEC 7.1d: shadow rays do not see surfaces of opacity exactly 0
+bool invisible(const orc_scene* s, uint32_t tri_id) {
+  const uint32_t mi = s->instances[s->tri_instance[tri_id]].material_index;
+  return mi < s->materials.size() && s->materials[mi].opacity == 0.0f;
+}
+void make_any_triangles(const orc_scene* s, const std::vector<Tri>& in, std::vector<Tri>* out) {
+  out->clear();
+  bool some = false;
+  for (const auto& m : s->materials) some = some || m.opacity == 0.0f;
+  if (!some) return;
+  *out = in;
+  for (Tri& t : *out)
+    if (invisible(s, t.id)) { t.e1[0] = t.e1[1] = t.e1[2] = 0.0f; t.e2[0] = t.e2[1] = t.e2[2] = 0.0f; }
+}
 bool scene_trace_any(const orc_scene* s, V3 o, V3 d, float tmin, float tmax, Counters* c) {
-  if (s->ext_nodes.empty()) return trace_any(s->nodes.data(), s->tris.data(), o, d, tmin, tmax, c);
+  if (s->ext_nodes.empty()) return trace_any(s->nodes.data(), (s->tris_any.empty() ? s->tris : s->tris_any).data(), o, d, tmin, tmax, c);
   RayPre r = make_ray(o, d, tmin);
   Hit h;
-  return traverse4<true>(s->ext_nodes.data(), s->ext_tris.data(), r, tmax, &h, c);
+  return traverse4<true>(s->ext_nodes.data(), (s->ext_tris_any.empty() ? s->ext_tris : s->ext_tris_any).data(), r, tmax, &h, c);
 }
 }  // namespace orc
 
@@ -487,6 +502,7 @@ bool scene_trace_any(const orc_scene* s, V3 o, V3 d, float tmin, float tmax, Cou
 extern "C" void orc_scene_use_bvh4(orc_scene* s, const void* nodes64, uint32_t node_count, const void* tris48, uint32_t tri_count) {
   s->ext_nodes.assign((const Node4*)nodes64, (const Node4*)nodes64 + node_count);
   s->ext_tris.assign((const Tri*)tris48, (const Tri*)tris48 + (node_count ? tri_count : 0));
+  orc::make_any_triangles(s, s->ext_tris, &s->ext_tris_any);
 }
 
 static void trace_batch(const Node* nodes, const Tri* tris, const orc_ray* rays, orc_hit* hits, uint32_t count, int mode, uint64_t* counters) {
@@ -509,7 +525,7 @@ static void trace_batch(const Node* nodes, const Tri* tris, const orc_ray* rays,
 }
 
 extern "C" void orc_trace_rays(const orc_scene* s, const orc_ray* rays, orc_hit* hits, uint32_t count, int mode, uint64_t* counters) {
-  trace_batch(s->nodes.data(), s->tris.data(), rays, hits, count, mode, counters);
+  trace_batch(s->nodes.data(), (mode == 1 && !s->tris_any.empty() ? s->tris_any : s->tris).data(), rays, hits, count, mode, counters);
 }
 extern "C" void orc_trace_rays_on_bvh4(const void* nodes64, uint32_t, const void* tris48, uint32_t, const orc_ray* rays,
                                        orc_hit* hits, uint32_t count, int mode, uint64_t* counters) {
@@ -543,7 +559,7 @@ extern "C" void orc_trace_rays_brute(const orc_scene* s, const orc_ray* rays, or
     for (const Tri& tr : s->tris_by_id) {
       float t, u, v;
       if (!tri_test(r, tr, &t, &u, &v)) continue;
-      if (mode == 1) { if (t > r.tmin && t < ry.tmax) { any = true; break; } }
+      if (mode == 1) { if (t > r.tmin && t < ry.tmax && !orc::invisible(s, tr.id)) { any = true; break; } }  // RENDER_SPEC 7.1d
       else if (t > r.tmin && (t < best.t || (t == best.t && tr.id < best.prim))) best = Hit{t, u, v, tr.id};
     }
     if (mode == 1) hits[i] = orc_hit{any ? 1.0f : -1.0f, 0.0f, 0.0f, ORC_NONE};

@@ -66,6 +66,8 @@ struct orc_scene {
   std::vector<orc::Tri> tris_by_id;    // world-space, indexed by global id
   std::vector<float> tri_verts9;       // world-space v0,v1,v2 per global id (RENDER_SPEC §3)
   std::vector<orc::Tri> tris;          // BVH order
+  std::vector<orc::Tri> tris_any;      // RENDER_SPEC 7.1d: what the any-hit traversals see — the triangles of opacity-0 materials made
+                                       // degenerate (e1 = e2 = 0: never hit); empty when the scene has none (then `tris` serves both)
   std::vector<orc::Node> nodes;
   float bounds_min[3], bounds_max[3];
   float ray_eps;
@@ -80,7 +82,7 @@ struct orc_scene {
   std::vector<uint32_t> texture_image;  // texture index -> image (gpu_uploader.rs:336-338)
   // optional: a tree handed over by the product (orc_scene_use_bvh4); the integrator then traverses IT (RENDER_SPEC §4.4b)
   std::vector<orc::Node4> ext_nodes;
-  std::vector<orc::Tri> ext_tris;
+  std::vector<orc::Tri> ext_tris, ext_tris_any;
 };
 
 namespace orc {
@@ -89,6 +91,9 @@ struct Hit { float t, u, v; uint32_t prim; };
 // RENDER_SPEC §4: closest / any traversal over (nodes, tris).
 Hit trace_closest(const Node* nodes, const Tri* tris, V3 o, V3 d, float tmin, float tmax, Counters* c);
 bool trace_any(const Node* nodes, const Tri* tris, V3 o, V3 d, float tmin, float tmax, Counters* c);
+// RENDER_SPEC 7.1d: `in` with the triangles of opacity-0 materials made degenerate (empty when the scene has none)
+bool invisible(const orc_scene* s, uint32_t tri_id);
+void make_any_triangles(const orc_scene* s, const std::vector<Tri>& in, std::vector<Tri>* out);
 // the same on the scene's tree of choice: the product's 4-wide tree if one was handed over, else the oracle's own BVH2
 Hit scene_trace_closest(const orc_scene* s, V3 o, V3 d, float tmin, float tmax, Counters* c);
 bool scene_trace_any(const orc_scene* s, V3 o, V3 d, float tmin, float tmax, Counters* c);

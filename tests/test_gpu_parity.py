@@ -895,6 +895,40 @@ def test_media_glass_fixture_scene_bit_exact(halart, oracle):
     r.close()
 
 
+def test_invisible_surfaces_and_shadow_rays(halart, oracle):
+    """RENDER_SPEC 7.1d: any-hit rays do not see opacity-0 surfaces (the any-hit launches traverse a triangle copy in which they are
+    degenerate) while closest-hit rays do; a material edit that makes a surface (in)visible is picked up by refit"""
+    from test_oracle_render import fog_over_floor_scene
+    s = fog_over_floor_scene(True)
+    r = make_renderer(halart, s, 48, 48, max_depth=6)
+    osc = oracle.OracleScene(s)
+    rays = random_rays(6000, np.array((-3, 0.05, -3.0)), np.array((3, 4, 3.0)), 3)
+    for mode in (0, 1):
+        assert r.trace_rays_host(rays, mode).tobytes() == osc.trace(rays, mode).tobytes(), mode
+    assert (r.trace_rays_host(rays, 1)["t"] > 0).sum() < (r.trace_rays_host(rays, 0)["prim"] != 0xFFFFFFFF).sum()
+    r.update_batch(3); r.render()
+    imgs, st = osc.render(48, 48, frames=3, max_depth=6)
+    assert_images_equal(r, imgs)
+    lit = r.read_image(0)[20:28, 20:28, :3].mean()
+    # the fog's boundary becomes an ordinary white surface: it shadows the floor again
+    solid = H.HalaMaterial(type=0, base_color=(1.0, 1.0, 1.0), roughness=0.5, opacity=1.0)
+    r.update_material(1, solid); r.refit()
+    s.materials[1] = solid
+    osc2 = oracle.OracleScene(s)
+    assert r.trace_rays_host(rays, 1).tobytes() == osc2.trace(rays, 1).tobytes()
+    r.update_batch(3); r.render()
+    imgs2, _ = osc2.render(48, 48, frames=3, max_depth=6)
+    assert_images_equal(r, imgs2)
+    # ... and back
+    fog = fog_over_floor_scene(True).materials[1]
+    r.update_material(1, fog); r.refit()
+    assert r.trace_rays_host(rays, 1).tobytes() == osc.trace(rays, 1).tobytes()
+    r.update_batch(3); r.render()
+    assert_images_equal(r, imgs)
+    assert lit > 0.0
+    r.close()
+
+
 @pytest.mark.parametrize("boundary", ["glass", "invisible"])
 def test_render_scattering_medium_bit_exact(halart, oracle, boundary):
     """RENDER_SPEC 7.1f: free-flight sampling (polynomial log), Henyey-Greenstein scattering, no NEE at scattering vertices (the

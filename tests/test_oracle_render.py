@@ -420,3 +420,40 @@ def test_glass_is_energy_conserving_from_inside(oracle):
         s.materials = [H.HalaMaterial(medium=H.HalaMedium(2, (1.0, 1.0, 1.0), density, 0.0), **kw)]
         img = oracle.OracleScene(s).render(32, 32, **FURNACE)[0][0]
         assert abs(img[10:22, 10:22, :3].mean() - 0.7) < 0.01, density
+
+
+def fog_over_floor_scene(with_fog=True):
+    """a quad light above a floor, an invisible (opacity 0) ball of fog between them"""
+    s = H.HalaScene()
+    floor = scenes._merge_quads([((-3, 0, 3), (3, 0, 3), (3, 0, -3), (-3, 0, -3))])
+    floor.material_index = 0
+    ball = scenes.blob_mesh(subdivisions=2, amplitude=0.0)
+    ball.material_index = 1
+    s.materials = [H.HalaMaterial(type=0, base_color=(0.8, 0.8, 0.8), roughness=0.5),
+                   H.HalaMaterial(type=0, base_color=(1.0, 1.0, 1.0), roughness=0.5, opacity=0.0, medium=H.HalaMedium(2, (1.0, 1.0, 1.0), 0.3, 0.0))]
+    s.meshes = [H.HalaMesh([floor])] + ([H.HalaMesh([ball])] if with_fog else [])
+    m = np.eye(4, dtype=f32); m[:3, 3] = (0.0, 1.5, 0.0)
+    s.nodes = [H.HalaNode(name="floor", mesh_index=0)]
+    if with_fog:
+        s.nodes.append(H.HalaNode(name="fog", mesh_index=1, local_transform=m))
+    lm = np.eye(4, dtype=f32); lm[:3, :3] = np.array([[1, 0, 0], [0, 0, -1], [0, 1, 0]], dtype=f32); lm[:3, 3] = (0.0, 4.0, 0.0)  # cross(X, Y) of the node points down
+    s.nodes.append(H.HalaNode(name="light", light_index=0, local_transform=lm))
+    s.lights = [H.HalaLight(color=(1.0, 1.0, 1.0), intensity=20.0, light_type=3, params=(1.0, 1.0))]
+    s.nodes.append(H.HalaNode(name="cam", camera_index=0, local_transform=scenes.look_at_node_transform((0, 5, 6), (0, 0, 0))))
+    s.cameras = [H.HalaPerspectiveCamera(aspect=1.0, yfov=0.6)]
+    return s
+
+
+def test_invisible_surfaces_do_not_block_shadow_rays(oracle):
+    """§7.1d: the opacity-0 boundary of a thin fog ball between a light and a floor casts no shadow — the floor under it is as bright
+    as without the ball (thin medium: few paths scatter), and any-hit rays agree between the BVH and brute force"""
+    kw = dict(frames=32, max_depth=6, rr_depth=64, ground=(0, 0, 0, 1), sky=(0, 0, 0, 1))
+    fog = oracle.OracleScene(fog_over_floor_scene(True))
+    lit = fog.render(32, 32, **kw)[0][0][12:20, 12:20, :3].mean()
+    ref = oracle.OracleScene(fog_over_floor_scene(False)).render(32, 32, **kw)[0][0][12:20, 12:20, :3].mean()
+    assert ref > 0.05 and abs(lit - ref) < 0.25 * ref
+    rays = random_rays(4000, np.array((-3, 0.05, -3.0)), np.array((3, 4, 3.0)), 11)
+    assert fog.trace(rays, 1).tobytes() == fog.trace(rays, 1, brute=True).tobytes()
+    down = rays.copy(); down["origin"] = (0.0, 3.9, 0.0); down["direction"] = (0.0, -1.0, 0.0); down["tmin"] = 0.0; down["tmax"] = 3.8
+    assert (fog.trace(down[:4], 1)["t"] < 0).all()       # straight through the ball: unoccluded for a shadow ray ...
+    assert (fog.trace(down[:4], 0)["prim"] != 0xFFFFFFFF).all()  # ... while a closest-hit ray finds the boundary
