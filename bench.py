@@ -244,7 +244,7 @@ def main():
                                  "rocprofv3 --kernel-trace --stats average in profiles/. For this 32-triangle scene the whole BVH (6 nodes + "
                                  "32 triangles = 1.9 KB) is staged in LDS, so node/triangle bytes never reach HBM: `traffic` (PMC FETCH_SIZE*2 "
                                  "+ WRITE_SIZE per launch, profiles/traffic_closest.json) is just the ray-queue read + hit write (`traffic_frac_of_peak` is what HBM actually carries), and frac — a rate of "
-                                 "useful work priced in bytes, not a bandwidth — can exceed 1. The kernel is VALU-issue bound (profiles/r01_l_pmc_config2.txt: ~0.8 of the issue slots; `simt` "
+                                 "useful work priced in bytes, not a bandwidth — can exceed 1. The kernel is VALU-issue bound (profiles/r01_m_pmc_config2.txt: ~0.8 of the issue slots; `simt` "
                                  "gives the active lanes per wave on its two code paths). scripts/bench_scenes.py reports the same figures "
                                  "for the 82 k and 1 M triangle scenes, where the nodes do come from L2 / Infinity Cache / HBM.",
                          "bytes_per_ray": round(bytes_per_ray, 1), "nodes_per_ray": round(nodes_per_ray, 3),
