@@ -1,19 +1,23 @@
 #!/usr/bin/env python3
-"""bench.py — BASELINE.json's metric on BASELINE.json's config, one process per GPU.
+"""bench.py — BASELINE.json's metric on BASELINE.json's north-star workloads, one process per GPU.
 
-  metric   : Mrays/s (+ ms/frame) — rays = every BVH traversal: primary + bounce + shadow
-  workload : configs[1] — Cornell box (32 triangles), 1920x1080, 4 spp, diffuse-only closest hit, max_depth 5, rr_depth 3
-  step     : one frame = update_batch(4) == 4 x update() (the reference renders 1 spp per update,
-             src/rt_renderer.rs:458-464; the four samples travel through the wavefront kernels together) + render()
-  N > 1    : weak scaling — the same view at sqrt(N) x the linear resolution (2720x1530, 3840x2160, 5440x3060 for N = 2, 4,
-             8), cut into 32x32 tiles dealt to the ranks by a fixed permutation: every rank renders ~1920x1080 pixels
-             with the ray statistics of the 1-GPU frame; after the 4 spp the accumulated image is
-             all-gathered over RCCL (one collective per frame) and de-interleaved on every rank.
+  metric    : Mrays/s (+ ms/frame) — rays = every BVH traversal: primary + bounce + shadow
+  --gpus 1  : configs[3] — the ~1 M-triangle Sponza-class atrium (18 textures, Disney materials incl. glass, 2 quad
+              lights + env map), 1920x1080, 4 spp, max_depth 5, rr_depth 3
+  --gpus N>1: configs[4] — the same scene at 3840x2160, 4 spp, STRONG scaling: the one 4K frame is cut into 32x32 tiles
+              dealt to the N ranks by a fixed permutation; every rank accumulates its tiles for the 4 spp and the
+              accumulated image is all-gathered over RCCL (one collective per frame, inside libhalart.so) and
+              de-interleaved on every rank.  (BENCH_WORKLOAD=configs4 renders that frame on one GPU: the base of the curve;
+              the default N = 1 run also reports it under `secondary`.)
+  step      : one frame = update_batch(4) == 4 x update() (the reference renders 1 spp per update,
+              src/rt_renderer.rs:458-464; the four samples travel through the wavefront kernels together) + render()
 
-Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (closest-hit traversal) with the
-algorithmic-bytes figure of DESIGN.md; `cpu_baseline` times the CPU oracle on the host cores (N = 1 only).
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant traversal kernel with the algorithmic-bytes figure of
+DESIGN.md §4 from counts and launch times measured in this run; `cpu_baseline` times the CPU oracle on the same scene on
+the host cores (N = 1 only); `secondary` (N = 1 only, outside the timed region) holds configs[1] and configs[4]-on-one-GPU.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -23,38 +27,170 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-BASE_W, BASE_H, SPP, MAX_DEPTH, RR_DEPTH, TILE = 1920, 1080, 4, 5, 3, 32
-TIMING_PERIOD = 4  # per-launch HIP events on every 4th frame of the timed region (see main())
+TILE = 32
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def frame_for(n):
-    """Weak scaling: N GPUs render the SAME view (same camera, 16:9) at sqrt(N) x the linear resolution, so that every rank's
-    share of 32x32 tiles — dealt over the whole image — holds the same number of pixels with the same ray statistics as the
-    1-GPU frame.  Width is rounded up to a whole tile: 1920x1080, 2720x1530, 3840x2160, 5440x3060 for N = 1, 2, 4, 8."""
-    import math
-    w = int(math.ceil(BASE_W * math.sqrt(n) / TILE)) * TILE
-    return w, int(round(w * BASE_H / BASE_W))
+def source_hash():
+    """hash of everything that is compiled into libhalart.so: a committed PMC traffic figure is only quoted for the
+    code it was collected from"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "hala-renderer_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".cpp")) or name == "Makefile":
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "halart.h"), "rb").read())
+    return h.hexdigest()[:16]
 
 
-def cpu_baseline(scene_fn):
-    """The oracle (CPU restatement of the same rendering spec) on this box's host cores, on the workload's own
-    frame: 1920x1080, 4 spp.  Threads = the cores this process may run on, capped at 32 (the box is shared)."""
+def cpu_baseline(cfg):
+    """The oracle (CPU restatement of the same rendering spec, its own binned-SAH BVH) on this box's host cores, on the
+    workload's own scene and frame.  Threads = the cores this process may run on, capped at 32 (the box is shared)."""
     import oracle_lib as O
-    osc = O.OracleScene(scene_fn())
+    osc = O.OracleScene(cfg["scene"], envmap=cfg["env"])
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
     threads = max(1, min(avail, 32))
-    frames = 4  # four frames of the workload (16 spp) ~ 15-20 core-seconds
+    W, Hh, spp = cfg["width"], cfg["height"], cfg["spp"]
+    osc.render(W, Hh, frames=1, max_depth=cfg["max_depth"], rr_depth=cfg["rr_depth"], rect=(0, 0, 8, 8), threads=threads)  # builds the tree
+    frames = 2  # two frames of the workload (8 spp): ~10-25 s of CPU work
     t0 = time.perf_counter()
-    _, st = osc.render(BASE_W, BASE_H, frames=SPP * frames, max_depth=MAX_DEPTH, rr_depth=RR_DEPTH, threads=threads)
+    _, st = osc.render(W, Hh, frames=spp * frames, max_depth=cfg["max_depth"], rr_depth=cfg["rr_depth"], threads=threads)
     dt = time.perf_counter() - t0
     rays = st.rays_closest + st.rays_shadow
     return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": f"oracle (oracle/oracle_render.cpp, OpenMP, {threads} threads) on the same Cornell box: {frames} frames of {BASE_W}x{BASE_H} at {SPP} spp = {rays} rays in {dt:.2f} s ({dt * threads:.0f} core-seconds)",
+            "sample": f"oracle (oracle/oracle_render.cpp, OpenMP, {threads} threads) on the same scene, env map and camera: {frames} frames of "
+                      f"{W}x{Hh} at {spp} spp = {rays} rays in {dt:.2f} s ({dt * threads:.0f} core-seconds)",
             "ms_per_frame": round(dt * 1e3 / frames, 1)}
+
+
+class Run:
+    """one renderer on one workload; measure() times K frames bracketed by barrier + synchronize on both sides"""
+
+    def __init__(self, H, cfg, local_rank, rank, world, dist, torch):
+        self.cfg, self.dist, self.torch, self.world = cfg, dist, torch, world
+        self.r = H.HalaRenderer("bench", cfg["width"], cfg["height"], cfg["max_depth"], cfg["rr_depth"], False, False, False, 0,
+                                device_ordinal=local_rank)
+        r = self.r
+        if world > 1:
+            r.set_tile_shard(rank, world, TILE)
+        if cfg["env"] is not None:
+            r.set_envmap(cfg["env"], 0.0)
+        r.set_scene(cfg["scene"])
+        t0 = time.perf_counter()
+        r.commit()
+        self.commit_ms = (time.perf_counter() - t0) * 1e3
+        self.gather = None
+        if world > 1:
+            from hala_renderer_amd.dist import TileGather
+            # one all-gather per finished frame (SURVEY §8e): the accumulated colour image; albedo / normal are gathered the
+            # same way when save_images needs them (TileGather(aovs=(0, 1, 2)))
+            self.gather = TileGather(r, local_rank, aovs=(r.ACCUM,))
+        self.sync_gather = bool(os.environ.get("BENCH_SYNC_GATHER"))
+
+    def step(self):
+        r, g = self.r, self.gather
+        r.reset_accumulation()  # a frame restarts the accumulation: frame_index 0..spp-1 (same work every step)
+        r.update_batch(self.cfg["spp"])
+        if g is not None:
+            # pipelined: the collective of frame k runs beside the rendering of frame k + 1 and is waited for by the next
+            # begin() / the closing fence (BENCH_SYNC_GATHER=1: wait right here)
+            if self.sync_gather:
+                g.gather()
+            else:
+                g.begin()
+        r.render()
+
+    def fence(self):
+        if self.gather is not None:
+            self.gather.finish()  # the last frame's all-gather and de-interleave are part of the timed region
+        self.r.wait_idle()
+        self.torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def measure(self, steps, warmup, timing_period=1):
+        r = self.r
+        r.set_launch_timing_period(timing_period)
+        for _ in range(warmup):
+            self.step()
+        self.fence()
+        s0 = r.statistics()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        self.fence()
+        dt = time.perf_counter() - t0
+        s1 = r.statistics()
+        return dt, s0, s1
+
+    def count(self):
+        """one extra frame with the counting kernels (identical traversal; tests pin those counts to the oracle's)"""
+        r = self.r
+        r.set_launch_timing_period(1)
+        r.set_counting(True)
+        c0 = r.statistics()
+        self.step()
+        self.fence()
+        c1 = r.statistics()
+        r.set_counting(False)
+        return c0, c1
+
+    def close(self):
+        self.r.close()
+
+
+def kernel_report(dt_stats, counts, staged):
+    """per-kernel-symbol figures from the timed launches (s0, s1) and the counting frame (c0, c1)"""
+    s0, s1 = dt_stats
+    c0, c1 = counts
+    d = lambda name: getattr(s1, name) - getattr(s0, name)  # noqa: E731
+    c = lambda name: getattr(c1, name) - getattr(c0, name)  # noqa: E731
+    st = "true" if staged else "false"
+    out = {}
+    # closest-hit traversal runs as two symbols: k_trace_primary (depth 0: camera rays generated in place) and k_trace_batch (bounce queues)
+    n_b = max(c("rays_closest_counted") - c("rays_primary_counted"), 1)
+    nodes_b = (c("nodes_closest_total") - c("nodes_primary_total")) / n_b
+    tris_b = (c("tris_closest_total") - c("tris_primary_total")) / n_b
+    n_p = max(c("rays_primary_counted"), 1)
+    nodes_p, tris_p = c("nodes_primary_total") / n_p, c("tris_primary_total") / n_p
+    n_s = max(c("rays_shadow_counted"), 1)
+    nodes_s, tris_s = c("nodes_shadow_total") / n_s, c("tris_shadow_total") / n_s
+    ms_b = d("traverse_closest_ms_total") - d("traverse_primary_ms_total")
+    l_b = d("traverse_closest_launches") - d("traverse_primary_launches")
+    rays_b = d("rays_closest_timed") - d("rays_primary_timed")
+
+    def entry(symbol, what, fixed_bytes, nodes, tris, ms, launches, rays):
+        bpr = fixed_bytes + 64.0 * nodes + 48.0 * tris
+        avg = ms / max(launches, 1)
+        rpl = rays / max(launches, 1)
+        ach = bpr * rpl / (avg * 1e-3) / 1e9 if avg > 0 else 0.0
+        return {"kernel": symbol, "what": what, "bytes_per_ray": round(bpr, 1), "nodes_per_ray": round(nodes, 3), "tris_per_ray": round(tris, 3),
+                "avg_launch_ms": round(avg, 5), "launches": int(launches), "rays_per_launch": round(rpl, 1),
+                "grays_per_s_in_kernel": round(rays / max(ms, 1e-9) / 1e6, 3), "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4)}
+
+    out["batch"] = entry(f"rt::k_trace_batch<false, false, {st}>", "closest-hit traversal of the bounce-ray queues (depth >= 1): 32 B ray read + 16 B hit write per ray",
+                         48.0, nodes_b, tris_b, ms_b, l_b, rays_b)
+    out["primary"] = entry(f"rt::k_trace_primary<false, {st}>", "depth 0: camera rays generated in the lanes that trace them, 16 B hit write per ray",
+                           16.0, nodes_p, tris_p, d("traverse_primary_ms_total"), d("traverse_primary_launches"), d("rays_primary_timed"))
+    out["shadow"] = entry(f"rt::k_trace_shadow<false, {st}>", "any-hit traversal of the NEE connections: 48 B entry + 12 B radiance read per connection (+ 12 B add when unoccluded)",
+                          60.0, nodes_s, tris_s, d("traverse_shadow_ms_total"), d("traverse_shadow_launches"), d("rays_shadow_timed"))
+    simt = {}
+    for kind in ("closest", "shadow"):
+        ws = max(c(f"wave_steps_{kind}_total"), 1)
+        lp = max(c(f"leaf_passes_{kind}_total"), 1)
+        simt[kind] = {"node_path_lanes_of_64": round(c(f"nodes_{kind}_total") / ws, 1), "leaf_passes_per_wave_step": round(c(f"leaf_passes_{kind}_total") / ws, 2),
+                      "leaf_path_lanes_of_64": round(c(f"leaf_lanes_{kind}_total") / lp, 1)}
+    out["simt"] = simt
+    out["shade"] = {"kernel": "rt::k_shade<PRIMARY>", "avg_launch_ms": round(d("shade_ms_total") / max(d("shade_launches"), 1), 5), "launches": int(d("shade_launches"))}
+    frames = max(d("traverse_primary_launches"), 1)  # one depth-0 launch per timed wavefront pass (= frame)
+    out["ms_per_frame_by_kernel"] = {"closest": round(d("traverse_closest_ms_total") / frames, 4), "shade": round(d("shade_ms_total") / frames, 4),
+                                      "shadow": round(d("traverse_shadow_ms_total") / frames, 4), "gpu_total": round(d("gpu_ms_total") / frames, 4)}
+    return out
 
 
 def main():
@@ -63,6 +199,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -72,11 +209,10 @@ def main():
         if args.gpus != 1 or world != 1:
             raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
 
-    import numpy as np
     import torch
 
     import hala_renderer_amd as H
-    from hala_renderer_amd import scenes
+    from hala_renderer_amd import workloads
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libhalart has no CPU path")
@@ -96,66 +232,11 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    W, Hh = frame_for(world)
-    aspect = W / Hh
-
-    def scene_fn():
-        return scenes.cornell_box(aspect=BASE_W / BASE_H)
-
-    scene = scenes.cornell_box(aspect=aspect)
-    r = H.HalaRenderer("bench", W, Hh, MAX_DEPTH, RR_DEPTH, False, False, False, 0, device_ordinal=local_rank)
-    if world > 1:
-        r.set_tile_shard(rank, world, TILE)
-    r.set_scene(scene)
-    r.commit()
-    # Per-launch HIP events (the roofline's avg_launch_ms) cost ~22 barrier packets = 70 us of the 2.25 ms frame: they are recorded
-    # on every TIMING_PERIOD-th frame of the timed region (still live, still inside it), not on all of them.
-    timing_period = TIMING_PERIOD if args.steps >= 2 * TIMING_PERIOD else 1
-    if os.environ.get("BENCH_TIMING_PERIOD"):  # A/B knob
-        timing_period = int(os.environ["BENCH_TIMING_PERIOD"])
-    r.set_launch_timing_period(timing_period)
-
-    gather = None
-    sync_gather = bool(os.environ.get("BENCH_SYNC_GATHER"))
-    if world > 1:
-        from hala_renderer_amd.dist import TileGather
-        # one all-gather per finished frame: the accumulated colour image; albedo/normal are gathered the
-        # same way when save_images needs them (TileGather(aovs=(0, 1, 2)))
-        gather = TileGather(r, local_rank, aovs=(r.ACCUM,))
-
-    def step():
-        # a frame restarts the accumulation: frame_index 0..SPP-1 (same work every step)
-        r.reset_accumulation()
-        r.update_batch(SPP)  # == SPP x update(): the SPP samples travel through the wavefront kernels together
-        if gather is not None:
-            # one RCCL all-gather of the finished frame + de-interleave kernel; pipelined: it runs while the next frame is
-            # rendered and is waited for by the next begin() / the closing fence (BENCH_SYNC_GATHER=1: wait right here)
-            if sync_gather:
-                gather.gather()
-            else:
-                gather.begin()
-        r.render()
-
-    def fence():
-        if gather is not None:
-            gather.finish()  # the last frame's all-gather and de-interleave are part of the timed region
-        r.wait_idle()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    fence()
-    s0 = r.statistics()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    s1 = r.statistics()
-
+    index = 4 if (world > 1 or os.environ.get("BENCH_WORKLOAD") == "configs4") else 3
+    cfg = workloads.baseline_config(index)
+    run = Run(H, cfg, local_rank, rank, world, dist, torch)
+    # per-launch HIP events (the roofline's avg_launch_ms): ~22 barrier packets per frame, < 1 % of a 10+ ms frame: every frame carries them
+    dt, s0, s1 = run.measure(args.steps, args.warmup, timing_period=int(os.environ.get("BENCH_TIMING_PERIOD", "1")))
     rays_local = s1.rays_total - s0.rays_total
     t_local = torch.tensor([dt, float(rays_local)], dtype=torch.float64, device=f"cuda:{local_rank}")
     if dist is not None:
@@ -167,106 +248,89 @@ def main():
     else:
         dt_all, rays_all = dt, float(rays_local)
 
-    # ---- roofline of the dominant kernel (rank 0's launches) ---------------------------------------------------
-    # Closest-hit traversal runs as two kernel symbols: k_trace_primary (depth 0: camera rays generated in place, one
-    # launch per frame) and k_trace_batch<false,false,STAGED> (depth >= 1: bounce rays from the compact queues, four
-    # launches per frame).  The dominant one by time is k_trace_batch; it is what `roofline` prices.
-    # algorithmic bytes per ray (DESIGN.md "Kernels"): 32 B ray read + 16 B hit write + 64 B per (4-wide) BVH node
-    # visited + 48 B per triangle tested; node/triangle counts come from one extra frame with the counting kernels
-    # (identical traversal; tests/test_gpu_parity.py pins those counts to the oracle's on the same BVH).
-    closest_ms = s1.traverse_closest_ms_total - s0.traverse_closest_ms_total
-    closest_launches = s1.traverse_closest_launches - s0.traverse_closest_launches
-    primary_ms = s1.traverse_primary_ms_total - s0.traverse_primary_ms_total
-    primary_launches = s1.traverse_primary_launches - s0.traverse_primary_launches
-    shadow_ms = s1.traverse_shadow_ms_total - s0.traverse_shadow_ms_total
-    shadow_launches = s1.traverse_shadow_launches - s0.traverse_shadow_launches
-    # rays of the frames whose launches were timed (all of them when timing_period == 1)
-    rays_closest = s1.rays_closest_timed - s0.rays_closest_timed
-    rays_primary = s1.rays_primary_timed - s0.rays_primary_timed
-    rays_shadow = s1.rays_shadow_timed - s0.rays_shadow_timed
-    r.set_launch_timing_period(1)
-    r.set_counting(True)
-    c0 = r.statistics()
-    step()
-    fence()
-    c1 = r.statistics()
-    r.set_counting(False)
-    d = lambda name: getattr(c1, name) - getattr(c0, name)
-    n_bounce = max(d("rays_closest_counted") - d("rays_primary_counted"), 1)
-    nodes_per_ray = (d("nodes_closest_total") - d("nodes_primary_total")) / n_bounce
-    tris_per_ray = (d("tris_closest_total") - d("tris_primary_total")) / n_bounce
-    p_nodes_per_ray = d("nodes_primary_total") / max(d("rays_primary_counted"), 1)
-    p_tris_per_ray = d("tris_primary_total") / max(d("rays_primary_counted"), 1)
-    ns = d("rays_shadow_counted")
-    s_nodes_per_ray = d("nodes_shadow_total") / max(ns, 1)
-    s_tris_per_ray = d("tris_shadow_total") / max(ns, 1)
-    bytes_per_ray = 32.0 + 16.0 + 64.0 * nodes_per_ray + 48.0 * tris_per_ray
-    batch_ms, batch_launches, rays_bounce = closest_ms - primary_ms, closest_launches - primary_launches, rays_closest - rays_primary
-    avg_launch_ms = batch_ms / max(batch_launches, 1)
-    rays_per_launch = rays_bounce / max(batch_launches, 1)
-    achieved = bytes_per_ray * rays_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
-    simt = {}
-    for kind in ("closest", "shadow"):
-        ws = max(d(f"wave_steps_{kind}_total"), 1)
-        lp = max(d(f"leaf_passes_{kind}_total"), 1)
-        simt[kind] = {"node_path_lanes_of_64": round(d(f"nodes_{kind}_total") / ws, 1), "leaf_passes_per_wave_step": round(d(f"leaf_passes_{kind}_total") / ws, 2),
-                      "leaf_path_lanes_of_64": round(d(f"leaf_lanes_{kind}_total") / lp, 1)}
-    traffic, valu = None, None
-    tpath = os.path.join(ROOT, "profiles", "traffic_closest.json")
-    if os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath))
-            traffic = tj.get("hbm_bytes_per_launch")
-            valu = {"issue_utilisation": tj.get("valu_issue_utilisation"), "active_lanes_per_instruction": tj.get("active_lanes_per_valu_instruction"),
-                    "source": tj.get("source")}
-        except Exception:
-            traffic = None
+    # ---- roofline of the dominant kernel (rank 0's launches), from this run's own counts and launch times --------------
+    counts = run.count()
+    info = run.r.bvh_info()
+    staged = info.lds_node_count > 0
+    kr = kernel_report((s0, s1), counts, staged)
 
     out = None
     if rank == 0:
+        traffic = None
+        tnote = "not collected in this run (PMC counters need rocprofv3: scripts/profile_round.sh writes profiles/r02_traffic_config3.json)"
+        tpath = os.path.join(ROOT, "profiles", "r02_traffic_config3.json")
+        if index == 3 and os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("source_hash") == source_hash():
+                    traffic = tj
+                    tnote = f"collected by scripts/profile_round.sh from this exact source (hash {tj.get('source_hash')}, commit {tj.get('commit')}), separate --pmc passes, guide's gfx950 correction"
+                else:
+                    tnote = f"profiles/r02_traffic_config3.json was collected from other sources (hash {tj.get('source_hash')} != {source_hash()}): not quoted"
+            except Exception as e:  # noqa: BLE001
+                tnote = f"unreadable: {e}"
+        b = kr["batch"]
+        tb = traffic["hbm_bytes_per_launch"] if traffic else None
+        roof = {"bound": "hbm", "kernel": b["kernel"] + " — " + b["what"],
+                "achieved": b["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b["frac"],
+                "traffic": tb, "traffic_note": tnote,
+                "traffic_GBps": (round(tb / (b["avg_launch_ms"] * 1e-3) / 1e9, 1) if tb and b["avg_launch_ms"] > 0 else None),
+                "traffic_frac_of_peak": (round(tb / (b["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if tb and b["avg_launch_ms"] > 0 else None),
+                "counters": ({k: traffic.get(k) for k in ("l2_hit_rate", "valu_issue_utilisation", "active_lanes_per_valu_instruction", "FETCH_SIZE_KB_per_launch", "WRITE_SIZE_KB_per_launch")} if traffic else None),
+                "note": "achieved = ALGORITHMIC bytes per ray (SURVEY 8d formula with this library's formats: 64 B per 4-wide node visited, 48 B per "
+                        "triangle tested, + the ray / hit record bytes) x rays per launch / average launch time of this kernel symbol; node and triangle counts "
+                        "come from one extra frame with the counting kernels in this run; avg_launch_ms from HIP events on the renderer's stream around "
+                        "every launch of the timed region (profiles/r02_*_kernel_stats_bench.csv holds the rocprofv3 average of the same command). The tree "
+                        "(16 MB of nodes + 48 MB of triangles) sits in L2 / Infinity Cache, so `traffic` (fabric bytes by PMC) is far below the algorithmic bytes: "
+                        "frac prices useful work against the HBM peak, traffic_frac_of_peak is what the memory side really carries; the kernels are "
+                        "VALU-issue bound (`simt`: active lanes per wave on the two code paths).",
+                "bytes_per_ray": b["bytes_per_ray"], "nodes_per_ray": b["nodes_per_ray"], "tris_per_ray": b["tris_per_ray"],
+                "avg_launch_ms": b["avg_launch_ms"], "launches": b["launches"], "rays_per_launch": b["rays_per_launch"],
+                "grays_per_s_in_kernel": b["grays_per_s_in_kernel"], "simt": kr["simt"],
+                "primary_kernel": kr["primary"], "shadow_kernel": kr["shadow"], "shade_kernel": kr["shade"],
+                "ms_per_frame_by_kernel": kr["ms_per_frame_by_kernel"]}
         out = {
             "metric": "Mrays/s", "value": round(rays_all / dt_all / 1e6, 2), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt_all / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(dt_all / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"configs[1]: procedural Cornell box (32 triangles), {W}x{Hh} (~{BASE_W}x{BASE_H} pixels per GPU), {SPP} spp, diffuse-only closest hit",
-                       "resolution": [W, Hh], "spp": SPP, "max_depth": MAX_DEPTH, "rr_depth": RR_DEPTH,
-                       "parallelism": f"pixel-tile shard {TILE}x{TILE} over {world} rank(s)" + (", one RCCL all-gather of the accumulated image per frame" if world > 1 else ""),
-                       "rays_per_frame": int(rays_all / args.steps), "ms_per_frame": round(dt_all / args.steps * 1e3, 4)},
-            "roofline": {"bound": "hbm", "kernel": "rt::k_trace_batch<false, false, true> (closest-hit traversal of the bounce-ray queues, depth >= 1)",
-                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "traffic_GBps": (round(traffic / (avg_launch_ms * 1e-3) / 1e9, 1) if traffic and avg_launch_ms > 0 else None),
-                         "traffic_frac_of_peak": (round(traffic / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and avg_launch_ms > 0 else None),
-                         "note": "achieved = ALGORITHMIC bytes (SURVEY 8d formula, 64 B per 4-wide node) / launch time, both per launch of this "
-                                 "kernel symbol; avg_launch_ms is measured with HIP events on the renderer's stream, inside the timed region, "
-                                 "on every `timing_period`-th frame (`launches` = the launches so measured) and agrees with the "
-                                 "rocprofv3 --kernel-trace --stats average in profiles/. For this 32-triangle scene the whole BVH (6 nodes + "
-                                 "32 triangles = 1.9 KB) is staged in LDS, so node/triangle bytes never reach HBM: `traffic` (PMC FETCH_SIZE*2 "
-                                 "+ WRITE_SIZE per launch, profiles/traffic_closest.json) is just the ray-queue read + hit write (`traffic_frac_of_peak` is what HBM actually carries), and frac — a rate of "
-                                 "useful work priced in bytes, not a bandwidth — can exceed 1. The kernel is VALU-issue bound (profiles/r01_m_pmc_config2.txt: ~0.8 of the issue slots; `simt` "
-                                 "gives the active lanes per wave on its two code paths). scripts/bench_scenes.py reports the same figures "
-                                 "for the 82 k and 1 M triangle scenes, where the nodes do come from L2 / Infinity Cache / HBM.",
-                         "bytes_per_ray": round(bytes_per_ray, 1), "nodes_per_ray": round(nodes_per_ray, 3),
-                         "tris_per_ray": round(tris_per_ray, 3), "avg_launch_ms": round(avg_launch_ms, 5),
-                         "launches": int(batch_launches), "timing_period": timing_period, "rays_per_launch": round(rays_per_launch, 1),
-                         "grays_per_s_in_kernel": round(rays_bounce / max(batch_ms, 1e-9) / 1e6, 3),
-                         "simt": simt, "valu": valu,
-                         "primary_kernel": {"kernel": "rt::k_trace_primary<false, true> (depth 0: camera rays generated in the lanes that trace them, 16 B hit write per ray)",
-                                            "avg_launch_ms": round(primary_ms / max(primary_launches, 1), 5), "launches": int(primary_launches),
-                                            "rays_per_launch": round(rays_primary / max(primary_launches, 1), 1),
-                                            "nodes_per_ray": round(p_nodes_per_ray, 3), "tris_per_ray": round(p_tris_per_ray, 3),
-                                            "grays_per_s_in_kernel": round(rays_primary / max(primary_ms, 1e-9) / 1e6, 3)},
-                         "shadow_kernel": {"kernel": "rt::k_trace_shadow<false, true>", "avg_launch_ms": round(shadow_ms / max(shadow_launches, 1), 5),
-                                           "launches": int(shadow_launches), "rays": int(rays_shadow),
-                                           "nodes_per_ray": round(s_nodes_per_ray, 3), "tris_per_ray": round(s_tris_per_ray, 3),
-                                           "grays_per_s_in_kernel": round(rays_shadow / max(shadow_ms, 1e-9) / 1e6, 3)}},
+            "config": {"workload": cfg["name"], "resolution": [cfg["width"], cfg["height"]], "spp": cfg["spp"], "max_depth": cfg["max_depth"], "rr_depth": cfg["rr_depth"],
+                       "triangles": int(info.triangle_count), "bvh_nodes": int(info.node_count), "bvh_build_ms": round(run.commit_ms, 2),
+                       "parallelism": f"pixel-tile shard {TILE}x{TILE} of the one frame over {world} rank(s)" + (", one RCCL all-gather of the accumulated image per frame" if world > 1 else ""),
+                       "rays_per_frame": int(rays_all / args.steps), "ms_per_frame": round(dt_all / args.steps * 1e3, 4),
+                       "scaling_note": "N = 1 renders configs[3] (1920x1080); N > 1 renders configs[4] (3840x2160) strong-scaled; the single-GPU time of the 4K frame is under secondary.configs4_on_1_gpu"},
+            "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(scene_fn)
+    run.close()
+
+    if rank == 0 and world == 1:
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg)
         else:
             out["cpu_baseline"] = None
-    r.close()
+        secondary = {}
+        if not args.no_secondary and index == 3:
+            # configs[4]'s frame on this one GPU: the base of the strong-scaling curve the driver's N > 1 runs continue
+            c4 = workloads.baseline_config(4)
+            c4["scene"], c4["env"] = cfg["scene"], cfg["env"]  # same scene objects (16:9 either way)
+            r4 = Run(H, c4, local_rank, 0, 1, None, torch)
+            d4, a0, a1 = r4.measure(3, 1)
+            secondary["configs4_on_1_gpu"] = {"workload": c4["name"] + " on ONE GPU (no shard, no collective)", "steps": 3,
+                                              "value": round((a1.rays_total - a0.rays_total) / d4 / 1e6, 2), "unit": "Mrays/s", "ms_per_frame": round(d4 / 3 * 1e3, 3)}
+            r4.close()
+            # configs[1]: the 32-triangle Cornell box whose BVH lives in LDS (round 1's headline)
+            c1 = workloads.baseline_config(1)
+            r1 = Run(H, c1, local_rank, 0, 1, None, torch)
+            d1, b0, b1 = r1.measure(20, 3, timing_period=4)
+            k1 = kernel_report((b0, b1), r1.count(), True)
+            secondary["configs1"] = {"workload": c1["name"], "steps": 20, "value": round((b1.rays_total - b0.rays_total) / d1 / 1e6, 2), "unit": "Mrays/s",
+                                     "ms_per_frame": round(d1 / 20 * 1e3, 4),
+                                     "batch_kernel": k1["batch"], "shadow_kernel": k1["shadow"], "shade_kernel": k1["shade"], "simt": k1["simt"],
+                                     "note": "the whole BVH (1.9 KB) is staged in LDS: the algorithmic-bytes fraction is a rate of useful work, not an HBM bandwidth, and can exceed 1"}
+            r1.close()
+        out["secondary"] = secondary
+    elif rank == 0:
+        out["cpu_baseline"] = None
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

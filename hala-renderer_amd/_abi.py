@@ -154,7 +154,8 @@ class RtStatistics(C.Structure):
                 ("traverse_primary_ms_total", C.c_double), ("traverse_primary_launches", C.c_uint64),
                 ("nodes_primary_total", C.c_uint64), ("tris_primary_total", C.c_uint64), ("rays_primary_counted", C.c_uint64),
                 ("rays_primary_total", C.c_uint64),
-                ("rays_closest_timed", C.c_uint64), ("rays_primary_timed", C.c_uint64), ("rays_shadow_timed", C.c_uint64)]
+                ("rays_closest_timed", C.c_uint64), ("rays_primary_timed", C.c_uint64), ("rays_shadow_timed", C.c_uint64),
+                ("shade_ms_total", C.c_double), ("shade_launches", C.c_uint64)]
 
 
 class BvhInfo(C.Structure):

@@ -51,9 +51,23 @@ double num(const JsonValue& o, const char* key, double dflt) {
   return (v && v->kind == JsonValue::Number) ? v->num : dflt;
 }
 bool has(const JsonValue& o, const char* key) { return get(o, key) != nullptr; }
+// JSON numbers that stand for counts, offsets and indices must be finite non-negative integers that fit the target type
+// (a cast of NaN / a negative / 1e300 is undefined behaviour; serde rejects them in the reference's gltf crate too)
+uint64_t checked_uint(double v, uint64_t max, const char* what) {
+  if (!(v >= 0.0) || v > (double)max || v != std::floor(v)) fail(std::string("The glTF value of `") + what + "` is not a non-negative integer in range.");
+  return (uint64_t)v;
+}
+size_t usize(const JsonValue& o, const char* key, size_t dflt) {
+  const JsonValue* v = get(o, key);
+  return (v && v->kind == JsonValue::Number) ? (size_t)checked_uint(v->num, (uint64_t)1 << 48, key) : dflt;
+}
+uint32_t json_index(const JsonValue& v) {
+  if (v.kind != JsonValue::Number) fail("A glTF index is not a number.");
+  return (uint32_t)checked_uint(v.num, 0xfffffffeull, "index");
+}
 uint32_t index_or_invalid(const JsonValue& o, const char* key) {
   const JsonValue* v = get(o, key);
-  return (v && v->kind == JsonValue::Number) ? (uint32_t)v->num : HALA_INVALID_INDEX;
+  return (v && v->kind == JsonValue::Number) ? (uint32_t)checked_uint(v->num, 0xfffffffeull, key) : HALA_INVALID_INDEX;
 }
 const std::vector<JsonValue>& arr(const JsonValue& o, const char* key) {
   static const std::vector<JsonValue> empty;
@@ -116,7 +130,7 @@ Accessor read_accessor(const Doc& d, uint32_t idx) {
   const JsonValue& bv = views[bvi];
   const uint32_t bi = index_or_invalid(bv, "buffer");
   if (bi >= d.buffers.size()) fail("Buffer index out of range.");
-  const int ct = (int)num(a, "componentType", 0);
+  const int ct = (int)usize(a, "componentType", 0);
   const JsonValue* ty = get(a, "type");
   static const std::map<std::string, int> ncomp = {{"SCALAR", 1}, {"VEC2", 2}, {"VEC3", 3}, {"VEC4", 4}, {"MAT2", 4}, {"MAT3", 9}, {"MAT4", 16}};
   if (!ty || !ncomp.count(ty->str)) fail("Unknown accessor type.");
@@ -124,9 +138,9 @@ Accessor read_accessor(const Doc& d, uint32_t idx) {
   switch (ct) { case 5120: case 5121: size = 1; break; case 5122: case 5123: size = 2; break; case 5125: case 5126: size = 4; break; default: fail("Unknown component type."); }
   Accessor out;
   out.ncomp = ncomp.at(ty->str);
-  out.count = (size_t)num(a, "count", 0);
-  const size_t off = (size_t)num(bv, "byteOffset", 0) + (size_t)num(a, "byteOffset", 0);
-  size_t stride = (size_t)num(bv, "byteStride", 0);
+  out.count = usize(a, "count", 0);
+  const size_t off = usize(bv, "byteOffset", 0) + usize(a, "byteOffset", 0);
+  size_t stride = usize(bv, "byteStride", 0);
   if (stride == 0) stride = (size_t)size * out.ncomp;
   const std::vector<uint8_t>& buf = d.buffers[bi];
   if (out.count && off + (out.count - 1) * stride + (size_t)size * out.ncomp > buf.size()) fail("Accessor reads past the end of its buffer.");
@@ -171,6 +185,7 @@ void node_matrix(const JsonValue& n, float m[16]) {
 }
 
 // ---- PNG over zlib --------------------------------------------------------------------------------------------------
+constexpr uint32_t kMaxImageDim = 32768;  // decoded RGBA8 <= 4 GiB; larger headers are treated as malformed
 uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
 // decodes to RGBA8 (16-bit samples keep their high byte, like image::DynamicImage::into_rgba8's >> 8 ... rounding aside)
 bool decode_png(const std::vector<uint8_t>& raw, uint32_t* w, uint32_t* h, std::vector<uint8_t>* rgba) {
@@ -180,19 +195,23 @@ bool decode_png(const std::vector<uint8_t>& raw, uint32_t* w, uint32_t* h, std::
   uint32_t width = 0, height = 0;
   int depth = 0, ctype = 0, interlace = 0;
   std::vector<uint8_t> idat, plte, trns;
+  bool first = true;
   while (pos + 12 <= raw.size()) {
     const uint32_t len = be32(&raw[pos]);
     const char* type = reinterpret_cast<const char*>(&raw[pos + 4]);
     if (pos + 12 + (size_t)len > raw.size()) return false;
     const uint8_t* data = &raw[pos + 8];
-    if (!memcmp(type, "IHDR", 4)) { width = be32(data); height = be32(data + 4); depth = data[8]; ctype = data[9]; interlace = data[12]; }
+    const bool ihdr = !memcmp(type, "IHDR", 4);
+    if (first != ihdr || (ihdr && len != 13)) return false;  // IHDR is the first chunk, exactly once, 13 bytes (PNG 11.2.2)
+    first = false;
+    if (ihdr) { width = be32(data); height = be32(data + 4); depth = data[8]; ctype = data[9]; interlace = data[12]; }
     else if (!memcmp(type, "PLTE", 4)) plte.assign(data, data + len);
     else if (!memcmp(type, "tRNS", 4)) trns.assign(data, data + len);
     else if (!memcmp(type, "IDAT", 4)) idat.insert(idat.end(), data, data + len);
     else if (!memcmp(type, "IEND", 4)) break;
     pos += 12 + (size_t)len;
   }
-  if (!width || !height || interlace != 0) return false;
+  if (!width || !height || width > kMaxImageDim || height > kMaxImageDim || interlace != 0) return false;
   int channels = 0;
   switch (ctype) { case 0: channels = 1; break; case 2: channels = 3; break; case 3: channels = 1; break; case 4: channels = 2; break; case 6: channels = 4; break; default: return false; }
   if (!(depth == 8 || depth == 16 || (depth < 8 && (ctype == 0 || ctype == 3)))) return false;
@@ -310,12 +329,12 @@ hala_material_desc load_material(const JsonValue& m) {  // :318-385 (+ _Material
   const float zero3[3] = {0, 0, 0}, one3[3] = {1, 1, 1}, one4[4] = {1, 1, 1, 1};
   if (const JsonValue* ex = get(m, "extras")) {
     if (!has(*ex, "type")) fail("Parse material extras failed.");  // `type` has no serde default (:65-66)
-    o.type = (uint32_t)num(*ex, "type", 0);
+    o.type = (uint32_t)usize(*ex, "type", 0);
     o.opacity = (float)num(*ex, "opacity", 1.0); o.anisotropic = (float)num(*ex, "anisotropic", 0.0); o.subsurface = (float)num(*ex, "subsurface", 0.0);
     o.specular_tint = (float)num(*ex, "specular_tint", 0.0); o.sheen = (float)num(*ex, "sheen", 0.0); o.sheen_tint = (float)num(*ex, "sheen_tint", 0.0);
     o.clearcoat = (float)num(*ex, "clearcoat", 0.0); o.clearcoat_roughness = (float)num(*ex, "clearcoat_roughness", 0.0);
     floats(*ex, "clearcoat_tint", o.clearcoat_tint, 3, zero3);  // serde default [0,0,0] when extras exist (:83-84)
-    o.medium_type = (uint32_t)num(*ex, "medium_type", 0); floats(*ex, "medium_color", o.medium_color, 3, zero3);
+    o.medium_type = (uint32_t)usize(*ex, "medium_type", 0); floats(*ex, "medium_color", o.medium_color, 3, zero3);
     o.medium_density = (float)num(*ex, "medium_density", 0.0); o.medium_anisotropy = (float)num(*ex, "medium_anisotropy", 0.0);
   } else {  // Default impl (:95-113)
     o.type = 0; o.opacity = 1.0f;
@@ -358,7 +377,7 @@ hala_light_desc load_light(const JsonValue& l) {  // :434-487
     p0 = (float)num(spot, "innerConeAngle", 0.0); p1 = (float)num(spot, "outerConeAngle", 0.78539816339744830962);
   }
   if (const JsonValue* ex = get(l, "extras")) {  // :449-459
-    const int t = (int)num(*ex, "type", 0);
+    const double t = num(*ex, "type", 0);  // compared as a number: no cast of an arbitrary double
     if (t == 1) type = 3; else if (t == 2) type = 4;
     p0 = (float)num(*ex, "param0", 0.0); p1 = (float)num(*ex, "param1", 0.0);
   }
@@ -414,13 +433,16 @@ void load(const std::string& path, hala_scene* s) {
   if (scenes.empty()) fail("No scene in glTF file \"" + path + "\".");  // :130
   const auto& jnodes = arr(d.j, "nodes");
   // BFS from the scene roots, parents before children (:134-173); the reference walks all scenes into one node list
+  std::vector<uint8_t> visited(jnodes.size(), 0);  // glTF node hierarchies are strict trees (glTF 2.0 §3.5.2): a revisit is a cycle or a shared child
   for (const JsonValue& sc : scenes) {
     std::deque<std::pair<int32_t, uint32_t>> queue;
-    for (const JsonValue& r : arr(sc, "nodes")) queue.emplace_back(-1, (uint32_t)r.num);
+    for (const JsonValue& r : arr(sc, "nodes")) queue.emplace_back(-1, json_index(r));
     while (!queue.empty()) {
       const auto [parent, idx] = queue.front();
       queue.pop_front();
       if (idx >= jnodes.size()) fail("Node index out of range.");
+      if (visited[idx]) fail("The node hierarchy is not a tree (node " + std::to_string(idx) + " is reached twice).");
+      visited[idx] = 1;
       const JsonValue& n = jnodes[idx];
       const JsonValue* nm = get(n, "name");
       s->names.push_back(nm ? nm->str : "<Unnamed>");
@@ -432,7 +454,7 @@ void load(const std::string& path, hala_scene* s) {
       if (const JsonValue* e = get(n, "extensions")) if (const JsonValue* kl = get(*e, "KHR_lights_punctual")) nd.light_index = index_or_invalid(*kl, "light");
       const int32_t cur = (int32_t)s->nodes.size();
       s->nodes.push_back(nd);
-      for (const JsonValue& c : arr(n, "children")) queue.emplace_back(cur, (uint32_t)c.num);
+      for (const JsonValue& c : arr(n, "children")) queue.emplace_back(cur, json_index(c));
     }
   }
   for (const JsonValue& m : arr(d.j, "meshes")) load_mesh(d, m, s);
@@ -449,7 +471,7 @@ void load(const std::string& path, hala_scene* s) {
       const uint32_t bvi = index_or_invalid(im, "bufferView");
       if (bvi >= views.size()) fail("Image without data.");
       const uint32_t bi = index_or_invalid(views[bvi], "buffer");
-      const size_t off = (size_t)num(views[bvi], "byteOffset", 0), len = (size_t)num(views[bvi], "byteLength", 0);
+      const size_t off = usize(views[bvi], "byteOffset", 0), len = usize(views[bvi], "byteLength", 0);
       if (bi >= d.buffers.size() || off + len > d.buffers[bi].size()) fail("Image buffer view out of range.");
       raw.assign(d.buffers[bi].begin() + off, d.buffers[bi].begin() + off + len);
     }

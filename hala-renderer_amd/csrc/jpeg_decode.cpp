@@ -101,6 +101,7 @@ bool decode_jpeg(const std::vector<uint8_t>& raw, uint32_t* w, uint32_t* h, std:
   Huff dc[4], ac[4];
   std::vector<Comp> comps;
   int width = 0, height = 0, restart = 0;
+  bool baseline = false;
   size_t p = 2;
   auto be16 = [&](size_t at) { return (int)((raw[at] << 8) | raw[at + 1]); };
   for (;;) {
@@ -140,9 +141,10 @@ bool decode_jpeg(const std::vector<uint8_t>& raw, uint32_t* w, uint32_t* h, std:
       }
     } else if (m == 0xc0 || m == 0xc1) {  // SOF0 / SOF1: baseline / extended sequential, Huffman
       if (seg + 6 > seg_end || raw[seg] != 8) return false;
+      baseline = m == 0xc0;
       height = be16(seg + 1); width = be16(seg + 3);
       const int nc = raw[seg + 5];
-      if ((nc != 1 && nc != 3) || width <= 0 || height <= 0 || seg + 6 + (size_t)nc * 3 > seg_end) return false;
+      if ((nc != 1 && nc != 3) || width <= 0 || height <= 0 || width > 32768 || height > 32768 || seg + 6 + (size_t)nc * 3 > seg_end) return false;
       comps.resize((size_t)nc);
       for (int i = 0; i < nc; ++i) {
         comps[(size_t)i].id = raw[seg + 6 + (size_t)i * 3];
@@ -162,6 +164,8 @@ bool decode_jpeg(const std::vector<uint8_t>& raw, uint32_t* w, uint32_t* h, std:
       for (int i = 0; i < ns; ++i) {
         const int cid = raw[seg + 1 + (size_t)i * 2], tb = raw[seg + 2 + (size_t)i * 2];
         bool found = false;
+        // table selectors index dc[4] / ac[4]; a baseline (SOF0) scan may only name tables 0 and 1 (T.81 B.2.3)
+        if ((tb >> 4) > 3 || (tb & 15) > 3 || (baseline && ((tb >> 4) > 1 || (tb & 15) > 1))) return false;
         for (Comp& c : comps) if (c.id == cid) { c.td = tb >> 4; c.ta = tb & 15; found = true; }
         if (!found) return false;
       }

@@ -85,6 +85,7 @@ struct TraceEvents {
   hipEvent_t frame_begin = nullptr, frame_end = nullptr;
   bool pending = false, counted = false;
   uint32_t samples = 1;  // frames rendered by this wavefront pass
+  uint32_t shadow_launches = 0;  // k_trace_shadow launches inside the timed brackets of this pass (0, 1 or 2 per depth)
   unsigned long long* host_counts = nullptr;  // pinned: rays_closest, rays_shadow, steps[2][2], probe[2][3]
 };
 
@@ -168,6 +169,15 @@ struct hala_rt_renderer {
   uint32_t launch_event_period = 1;  // per-launch timing events on every n-th update (hala_rt_set_launch_timing_period)
   unsigned long long update_counter = 0;
   hala_rt_statistics stats{};
+  // update() and trace_rays() share per-renderer scratch (work counters, step counters, the stack spill area): launches that use it
+  // are ordered across streams by an event — the last user records one, a user on another stream waits for it first
+  hipEvent_t scratch_event = nullptr;       // not owned: a ring slot's frame_end or batch_done
+  hipStream_t scratch_stream = nullptr;
+  hipEvent_t batch_done = nullptr;
+  int scratch_acquire(hipStream_t s) {
+    if (scratch_event && scratch_stream != s) RT_HIP(hipStreamWaitEvent(s, scratch_event, 0));
+    return HALA_OK;
+  }
 
   ~hala_rt_renderer() {
     if (device >= 0) (void)hipSetDevice(device);
@@ -178,6 +188,7 @@ struct hala_rt_renderer {
       if (t.frame_end) (void)hipEventDestroy(t.frame_end);
       if (t.host_counts) (void)hipHostFree(t.host_counts);
     }
+    if (batch_done) (void)hipEventDestroy(batch_done);
     // images first, then everything else (src/rt_renderer.rs:620-633)
     for (auto& i : img_local) i.release();
     for (auto& i : img_full) i.release();
@@ -231,19 +242,24 @@ struct hala_rt_renderer {
     (void)hipEventSynchronize(t.frame_end);
     float ms = 0.0f;
     if (hipEventElapsedTime(&ms, t.frame_begin, t.frame_end) == hipSuccess) { stats.last_gpu_ms = ms; stats.gpu_ms_total += ms; }
-    double tr[2] = {0.0, 0.0};  // event pairs alternate: closest-hit launch, shadow launch
-    for (size_t k = 0; k + 1 < t.used; k += 2) {
+    // four events per depth: a | closest-hit launch | b | shade launch | c | shadow launch(es) | d
+    double tr[2] = {0.0, 0.0}, sh = 0.0;
+    for (size_t k = 0; k + 3 < t.used; k += 4) {
       float m = 0.0f;
       if (hipEventElapsedTime(&m, t.ev[k], t.ev[k + 1]) == hipSuccess) {
-        tr[(k / 2) & 1] += m;
+        tr[0] += m;
         if (k == 0) { stats.traverse_primary_ms_total += m; stats.traverse_primary_launches += 1; }  // depth 0: k_trace_primary
       }
+      if (hipEventElapsedTime(&m, t.ev[k + 1], t.ev[k + 2]) == hipSuccess) sh += m;
+      if (hipEventElapsedTime(&m, t.ev[k + 2], t.ev[k + 3]) == hipSuccess) tr[1] += m;
     }
     stats.traverse_ms_last_update = tr[0] + tr[1];
     stats.traverse_closest_ms_total += tr[0];
     stats.traverse_shadow_ms_total += tr[1];
+    stats.shade_ms_total += sh;
     stats.traverse_closest_launches += t.used / 4;
-    stats.traverse_shadow_launches += t.used / 4;
+    stats.shade_launches += t.used / 4;
+    stats.traverse_shadow_launches += t.used ? t.shadow_launches : 0;  // as issued: one per connection kind the scene has, per depth
     stats.updates_rendered += t.samples;
     const unsigned long long rc = t.host_counts[0], rs = t.host_counts[1];
     stats.rays_last_update = rc + rs;
@@ -421,8 +437,26 @@ int configure_traversal(hala_rt_renderer* r) {
   r->lcfg.refill = r->staged ? 64u : kRefillThreshold;
   if (const char* e = getenv("HALART_REFILL")) r->lcfg.refill = std::min(64u, std::max(1u, (uint32_t)strtoul(e, nullptr, 10)));  // tuning knob
   if (r->bvh.stack_need > traverse_stack_lds_levels()) {
+    if (r->bvh.stack_need > traverse_stack_lds_levels() + traverse_stack_spill_levels()) {
+      // 3 x levels is a loose bound (every node on the path deferring three siblings).  Before refusing the tree, take the exact
+      // one: need(node) = (inner children - 1) + max need(inner child) — the worst order visits the child with the deepest
+      // need first while all its siblings wait.  Nodes are in breadth-first order (children behind their parent): one reverse sweep.
+      std::vector<BvhNode4> nodes(r->bvh.node_count);
+      RT_HIP(hipMemcpy(nodes.data(), r->d_nodes.ptr, nodes.size() * sizeof(BvhNode4), hipMemcpyDeviceToHost));
+      std::vector<uint32_t> need(nodes.size(), 0u);
+      for (size_t i = nodes.size(); i-- > 0;) {
+        uint32_t inner = 0, deepest = 0;
+        for (uint32_t ref : nodes[i].ref) {
+          if (ref == kAbsent || (ref & kLeafRef)) continue;
+          ++inner;
+          if (ref < need.size()) deepest = std::max(deepest, need[ref]);
+        }
+        need[i] = inner ? inner - 1u + deepest : 0u;
+      }
+      r->bvh.stack_need = need.empty() ? 1u : std::max(1u, need[0]);
+    }
     if (r->bvh.stack_need > traverse_stack_lds_levels() + traverse_stack_spill_levels())
-      RT_FAIL("The BVH is deeper than the traversal stack supports (" + std::to_string(r->bvh.max_depth) + " levels).");
+      RT_FAIL("The BVH is deeper than the traversal stack supports (" + std::to_string(r->bvh.max_depth) + " levels, " + std::to_string(r->bvh.stack_need) + " stack entries).");
     RT_HIP(r->d_spill.resize((size_t)r->lcfg.persistent_blocks * 256 * traverse_stack_spill_levels()));
     r->lcfg.spill = r->d_spill.ptr;
   }
@@ -572,7 +606,9 @@ int hala_rt_load_blue_noise_texture(hala_rt_renderer* r, const char* path) {
   if (!path || !*path || file_stem(path).empty()) RT_FAIL("The file name is none!");  // src/rt_renderer.rs:1120
   uint32_t w = 0, h = 0;
   std::vector<uint8_t> px;
-  const std::string e = rt::decode_image_file_rgba8(path, &w, &h, &px);
+  std::string e;
+  try { e = rt::decode_image_file_rgba8(path, &w, &h, &px); }
+  catch (const std::exception& ex) { e = std::string("Failed to open image \"") + path + "\": " + ex.what(); }  // nothing is thrown across the C ABI
   if (!e.empty()) RT_FAIL(e);
   return hala_rt_load_blue_noise_pixels(r, px.data(), w, h);
 }
@@ -682,7 +718,7 @@ static int update_impl(hala_rt_renderer* r, uint32_t frames) {
   r->ring_pos = (r->ring_pos + 1) % kStatRing;
   r->resolve_slot(te);
   if (!te.frame_begin) { RT_HIP(hipEventCreate(&te.frame_begin)); RT_HIP(hipEventCreate(&te.frame_end)); RT_HIP(hipHostMalloc(reinterpret_cast<void**>(&te.host_counts), 14 * sizeof(unsigned long long), hipHostMallocDefault)); }
-  te.used = 0; te.counted = r->counting;
+  te.used = 0; te.counted = r->counting; te.shadow_launches = 0;
 
   te.samples = samples;
   const FrameConst fc = r->frame_const(u, samples);
@@ -691,6 +727,7 @@ static int update_impl(hala_rt_renderer* r, uint32_t frames) {
   const PathState ps = r->path_state();
   Control* ctl = r->d_ctl.ptr;
   hipStream_t s = r->stream;
+  if (r->scratch_acquire(s) != HALA_OK) return HALA_ERR;
   RT_HIP(hipEventRecord(te.frame_begin, s));
   RT_HIP(hipMemsetAsync(ctl, 0, sizeof(Control), s));
   // per-launch HIP events (statistics: traverse_*_ms_total) on every launch_event_period-th update; each record is a barrier
@@ -709,13 +746,14 @@ static int update_impl(hala_rt_renderer* r, uint32_t frames) {
     launch_shade(fc, sv, q, ps, ctl, depth, s);
     if (timed) { hipEvent_t c = r->next_event(te); RT_HIP(hipEventRecord(c, s)); }
     // light connections first, environment connections second: contributions land in spec order (RENDER_SPEC §6)
-    if (u.num_of_lights > 0) launch_trace_shadow(r->lcfg, sv, q, ps, ctl, depth, 0, r->counting, s);
-    if (u.env_type == 1u) launch_trace_shadow(r->lcfg, sv, q, ps, ctl, depth, 1, r->counting, s);
+    if (u.num_of_lights > 0) { launch_trace_shadow(r->lcfg, sv, q, ps, ctl, depth, 0, r->counting, s); te.shadow_launches += timed ? 1u : 0u; }
+    if (u.env_type == 1u) { launch_trace_shadow(r->lcfg, sv, q, ps, ctl, depth, 1, r->counting, s); te.shadow_launches += timed ? 1u : 0u; }
     if (timed) { hipEvent_t d = r->next_event(te); RT_HIP(hipEventRecord(d, s)); }
   }
   launch_resolve(fc, ps, r->img_local[0].ptr, r->img_local[1].ptr, r->img_local[2].ptr, r->img_local[3].ptr, s);
   RT_HIP(hipMemcpyAsync(te.host_counts, &ctl->rays_closest, 14 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
   RT_HIP(hipEventRecord(te.frame_end, s));
+  r->scratch_event = te.frame_end; r->scratch_stream = s;
   RT_HIP(hipGetLastError());
   te.pending = true;
   for (bool& v : r->full_valid) v = false;
@@ -943,11 +981,15 @@ int hala_rt_trace_rays(hala_rt_renderer* r, const hala_ray* d_rays, hala_hit* d_
   if (count == 0) return HALA_OK;
   if (!d_rays || !d_hits) RT_FAIL("The ray batch is null!");
   hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : r->stream;
+  if (r->scratch_acquire(s) != HALA_OK) return HALA_ERR;  // stream-ordered behind the previous user of the renderer's scratch (include/halart.h)
   RT_HIP(hipMemsetAsync(r->d_batch_work.ptr, 0, sizeof(WorkCounters), s));
   // counters: the kernel accumulates into the control block's 64-bit fields; copy them out if requested
   if (d_counters) RT_HIP(hipMemsetAsync(&r->d_ctl.ptr->steps[mode][0], 0, 16, s));
   launch_trace_batch(r->lcfg, r->view(), d_rays, d_hits, nullptr, count, r->d_batch_work.ptr, r->d_ctl.ptr, mode == 1, d_counters != nullptr, false, s);
   if (d_counters) RT_HIP(hipMemcpyAsync(d_counters, &r->d_ctl.ptr->steps[mode][0], 16, hipMemcpyDeviceToDevice, s));
+  if (!r->batch_done) RT_HIP(hipEventCreateWithFlags(&r->batch_done, hipEventDisableTiming));
+  RT_HIP(hipEventRecord(r->batch_done, s));
+  r->scratch_event = r->batch_done; r->scratch_stream = s;
   RT_HIP(hipGetLastError());
   return HALA_OK;
 }

@@ -365,7 +365,8 @@ typedef struct hala_rt_statistics {
   /* totals since create / the last accumulation reset */
   double gpu_ms_total;
   double traverse_closest_ms_total;   /* k_trace_batch<closest> launches, HIP events on the renderer's stream */
-  double traverse_shadow_ms_total;    /* k_trace_shadow launches */
+  double traverse_shadow_ms_total;    /* k_trace_shadow launches (one event pair per depth brackets the light and the
+                                       * environment launch; traverse_shadow_launches counts the launches as issued) */
   uint64_t traverse_closest_launches;
   uint64_t traverse_shadow_launches;
   uint64_t updates_rendered;
@@ -389,6 +390,10 @@ typedef struct hala_rt_statistics {
   /* rays of the updates whose launches carried timing events (hala_rt_set_launch_timing_period): the rays the
    * traverse_*_ms_total / *_launches figures belong to.  Equal to the *_total fields while every update is timed. */
   uint64_t rays_closest_timed, rays_primary_timed, rays_shadow_timed;
+  /* the shade launches between the closest-hit and the shadow launches of the timed updates (k_shade: closest-hit shading,
+   * miss, NEE set-up, BSDF sampling, queue compaction) */
+  double shade_ms_total;
+  uint64_t shade_launches;
 } hala_rt_statistics;
 int hala_rt_get_info(hala_rt_renderer* r, hala_rt_info* out);
 int hala_rt_get_statistics(hala_rt_renderer* r, hala_rt_statistics* out);
@@ -459,7 +464,12 @@ typedef struct hala_hit {
 
 /* mode 0: closest hit; mode 1: any hit (shadow): t = 1 if occluded else -1. Rays/hits are DEVICE
  * pointers (coalesced 32-B / 16-B records). If d_counters != NULL (device, 2 x uint64) the kernel
- * also adds the number of BVH nodes visited and triangles tested (for the algorithmic-bytes figure). */
+ * also adds the number of BVH nodes visited and triangles tested (for the algorithmic-bytes figure).
+ * Streams: hip_stream = NULL launches on the renderer's stream.  The launch uses per-renderer scratch (work counters,
+ * step counters, the traversal-stack spill area) that update() uses too, so all update / trace_rays launches of ONE
+ * renderer are serialised on the device: a call on another stream first makes that stream wait (hipStreamWaitEvent)
+ * for the previous such launch, wherever it ran, and records an event behind its own.  Calls may come from one host
+ * thread at a time (the reference's renderer is !Send / !Sync too). */
 int hala_rt_trace_rays(hala_rt_renderer* r, const hala_ray* d_rays, hala_hit* d_hits, uint32_t count,
                        int mode, uint64_t* d_counters, void* hip_stream);
 /* trace_rays_indirect (src/raytracing_program.rs:338-340): d_indirect points at a device-resident

@@ -81,30 +81,26 @@ def run(name, scene, w, h, spp, env=None, max_depth=5, rr_depth=3, steps=8):
 
 
 def main():
+    from hala_renderer_amd import workloads
     ap = argparse.ArgumentParser()
-    ap.add_argument("--configs", default="2,3,4")
+    ap.add_argument("--configs", default="2,3,4", help="1-based: 2..5 = BASELINE configs[1..4]")
     ap.add_argument("--save", default="")
     args = ap.parse_args()
     want = set(args.configs.split(","))
-    if "2" in want:
-        run("config2_cornell_1080p_4spp", scenes.cornell_box(aspect=16 / 9), 1920, 1080, 4)
-    if "3" in want:
-        env = scenes.sky_sun_envmap(2048, 1024)
-        img = run("config3_blob82k_env_1080p_16spp", scenes.bunny_class(subdivisions=6, disney=True), 1920, 1080, 16, env=env, steps=2)
-        if args.save:
-            np.save(os.path.join(args.save, "config3.npy"), img[::2, ::2, :3].astype(np.float16))
-    if "4" in want:
-        env = scenes.sky_sun_envmap(1024, 512, sun_gain=50.0)
-        t0 = time.perf_counter()
-        s = scenes.sponza_class(target_triangles=1_000_000)
-        if not os.environ.get("HALART_NO_TEXTURES"):
-            scenes.attach_textures(s, sets=6, size=1024)  # 18 procedural 1024^2 textures: base colour + normal + MR
-        print(json.dumps({"scene_gen_s": round(time.perf_counter() - t0, 1), "triangles": s.triangle_count(), "textures": len(s.image_data)}), flush=True)
-        img = run("config4_atrium1M_1080p_4spp", s, 1920, 1080, 4, env=env, steps=2)
-        if args.save:
-            np.save(os.path.join(args.save, "config4.npy"), img[::2, ::2, :3].astype(np.float16))
-        if "5" in want:
-            run("config5_atrium1M_4K_4spp_1gpu", s, 3840, 2160, 4, env=env, steps=1)
+    names = {"2": "config2_cornell_1080p_4spp", "3": "config3_blob82k_env_1080p_16spp", "4": "config4_atrium1M_1080p_4spp", "5": "config5_atrium1M_4K_4spp_1gpu"}
+    steps = {"2": 8, "3": 2, "4": 2, "5": 1}
+    shared = None
+    for k in ("2", "3", "4", "5"):
+        if k not in want:
+            continue
+        c = workloads.baseline_config(int(k) - 1)
+        if k in ("4", "5"):  # the same scene objects for both
+            if shared is None:
+                shared = (c["scene"], c["env"])
+            c["scene"], c["env"] = shared
+        img = run(names[k], c["scene"], c["width"], c["height"], c["spp"], env=c["env"], steps=steps[k])
+        if args.save and k in ("3", "4"):
+            np.save(os.path.join(args.save, f"config{k}.npy"), img[::2, ::2, :3].astype(np.float16))
 
 
 if __name__ == "__main__":

@@ -165,3 +165,75 @@ def test_jpeg_textures_decode_like_pil(tmp_path, variant):
     sub = variant in ("420", "ragged")  # replicated chroma vs libjpeg's triangle-filter upsampling
     assert diff[..., :3].mean() < (3.0 if sub else 1.5) and np.percentile(diff[..., :3], 99) <= (12 if sub else 6), (diff[..., :3].mean(), diff.max())
     nat.close()
+
+
+def test_malformed_inputs_are_refused_not_read_out_of_bounds(tmp_path):
+    """untrusted-input robustness of the C++ loader (round-1 advisor findings): every case must come back as an error through the
+    C ABI — no out-of-bounds table index, no endless node walk, no undefined cast"""
+    import base64
+    import io
+    import struct
+    import zlib
+    from PIL import Image
+    s = scenes.cornell_box()
+    scenes.attach_textures(s, sets=1, size=16)
+    p = tmp_path / "scene.gltf"
+    write_gltf(s, str(p))
+    doc = json.load(open(p))
+
+    def load_with(mutate, name):
+        bad = json.loads(json.dumps(doc))
+        mutate(bad)
+        q = tmp_path / name
+        json.dump(bad, open(q, "w"))
+        return NativeScene(str(q))
+
+    # (1) JPEG whose scan header names Huffman tables 15/15 (dc[4] / ac[4] are 4-entry arrays): jpeg_decode.cpp SOS parser
+    bio = io.BytesIO()
+    Image.fromarray((np.arange(64 * 48 * 3) % 251).astype(np.uint8).reshape(48, 64, 3), "RGB").save(bio, format="JPEG", quality=90, subsampling=0)
+    jpg = bytearray(bio.getvalue())
+    sos = jpg.index(b"\xff\xda")
+    ns = jpg[sos + 4]
+    assert ns == 3
+    for sel in (0xff, 0x40, 0x04, 0x22):  # out of the array; td = 4; ta = 4; tables 2/2 in a baseline (SOF0) file
+        bad_jpg = bytearray(jpg)
+        bad_jpg[sos + 6] = sel  # table selector byte of the first scan component
+        uri = "data:image/jpeg;base64," + base64.b64encode(bytes(bad_jpg)).decode()
+        with pytest.raises(H.HalaRendererError, match="Unsupported image format"):
+            load_with(lambda d: d["images"].__setitem__(0, {"uri": uri}), f"jpeg_sel_{sel:02x}.gltf")
+
+    # (2) PNG with a 5-byte IHDR, and one whose IHDR is not the first chunk
+    def chunk(t, payload):
+        return struct.pack(">I", len(payload)) + t + payload + struct.pack(">I", zlib.crc32(t + payload))
+    sig = b"\x89PNG\r\n\x1a\n"
+    ihdr = struct.pack(">IIBBBBB", 2, 2, 8, 2, 0, 0, 0)
+    idat = chunk(b"IDAT", zlib.compress(b"\0" + bytes(6) + b"\0" + bytes(6)))
+    good = sig + chunk(b"IHDR", ihdr) + idat + chunk(b"IEND", b"")
+    ok = load_with(lambda d: d["images"].__setitem__(0, {"uri": "data:image/png;base64," + base64.b64encode(good).decode()}), "png_ok.gltf")
+    assert (ok.desc.image_data[0].width, ok.desc.image_data[0].height) == (2, 2)
+    ok.close()
+    for name, blob in (("short", sig + chunk(b"IHDR", ihdr[:5]) + idat + chunk(b"IEND", b"") + bytes(16)),
+                       ("late", sig + chunk(b"gAMA", bytes(4)) + chunk(b"IHDR", ihdr) + idat + chunk(b"IEND", b"")),
+                       ("twice", sig + chunk(b"IHDR", ihdr) + chunk(b"IHDR", ihdr) + idat + chunk(b"IEND", b"")),
+                       ("huge", sig + chunk(b"IHDR", struct.pack(">IIBBBBB", 1 << 30, 1 << 30, 8, 6, 0, 0, 0)) + idat + chunk(b"IEND", b""))):
+        uri = "data:image/png;base64," + base64.b64encode(blob).decode()
+        with pytest.raises(H.HalaRendererError, match="Unsupported image format"):
+            load_with(lambda d: d["images"].__setitem__(0, {"uri": uri}), f"png_{name}.gltf")
+
+    # (3) node hierarchy with a cycle / a node reached twice
+    def cycle(d):
+        d["nodes"][0].setdefault("children", []).append(0)
+    with pytest.raises(H.HalaRendererError, match="not a tree"):
+        load_with(cycle, "cycle.gltf")
+
+    def shared(d):
+        d["scenes"][0]["nodes"] = list(d["scenes"][0]["nodes"]) + [d["scenes"][0]["nodes"][0]]
+    with pytest.raises(H.HalaRendererError, match="not a tree"):
+        load_with(shared, "shared.gltf")
+
+    # (4) numbers that are not non-negative integers where counts / offsets / indices are expected
+    for key, val in (("count", -3), ("count", 1e300), ("byteOffset", 0.5), ("bufferView", -1)):
+        with pytest.raises(H.HalaRendererError, match="not a non-negative integer|out of range|past the end"):
+            load_with(lambda d: d["accessors"][0].__setitem__(key, val), f"acc_{key}_{abs(hash(str(val))) % 997}.gltf")
+    with pytest.raises(H.HalaRendererError, match="not a non-negative integer"):
+        load_with(lambda d: d["nodes"][0].__setitem__("children", [-1]), "child_neg.gltf")
