@@ -54,7 +54,7 @@ RT_DI f3 transform_point(const float* m, f3 p) {
              __fmaf_rn(m[10], p.z, __fmaf_rn(m[6], p.y, m[2] * p.x)) + m[14]);
 }
 
-// one thread per global triangle id.  The three records a triangle gets (48-B Tri, 112-B ShadeTri, 24-B Box6) are staged in LDS and
+// one thread per global triangle id.  The three records a triangle gets (48-B Tri, 128-B ShadeTri, 24-B Box6) are staged in LDS and
 // leave the block as contiguous 16-B (8-B for the boxes) stores.  Scene bounds: NO global atomics here — a device-scope atomic
 // costs 11.4 ns per 128-B line however many waves issue it (scripts/microbench/atomic_rate.hip), and six of them per wave on one
 // line held this kernel at 1.07 ms per million triangles; each block leaves its bounds in block_ord and k_bounds_reduce folds them.
@@ -62,7 +62,7 @@ __global__ void __launch_bounds__(256) k_flatten(const hala_gpu_mesh_data* __res
                                                   uint32_t inst_count, uint32_t n, Tri* __restrict__ tris_by_id, ShadeTri* __restrict__ shade_tris,
                                                   uint32_t* __restrict__ tri_instance, Box6* __restrict__ tri_box,
                                                   uint32_t* __restrict__ block_ord /* [gridDim.x][6] min xyz, max xyz */) {
-  __shared__ float4 stage[256 * 7];
+  __shared__ float4 stage[256 * 8];
   __shared__ uint32_t wave_ord[4][6];
   const uint32_t tid = threadIdx.x, base = blockIdx.x * 256u, g = base + tid;
   const uint32_t cnt = min(256u, n - base);
@@ -85,12 +85,15 @@ __global__ void __launch_bounds__(256) k_flatten(const hala_gpu_mesh_data* __res
     for (int c = 0; c < 3; ++c) {
       const hala_vertex& vx = vb[idx[c]];
       v[c] = transform_point(md.transform, ld3(vx.position));
+      float* nc = c == 0 ? st.n0 : (c == 1 ? st.n1 : st.n2);
 #pragma unroll
-      for (int k = 0; k < 3; ++k) { st.n[c][k] = vx.normal[k]; st.tg[c][k] = vx.tangent[k]; }
+      for (int k = 0; k < 3; ++k) { nc[k] = vx.normal[k]; st.tg[c][k] = vx.tangent[k]; }
       st.uv[c][0] = vx.tex_coord[0]; st.uv[c][1] = vx.tex_coord[1];
     }
     st.inst = lo; st.material = md.material_index;
     const f3 e1 = v[1] - v[0], e2 = v[2] - v[0];
+    const f3 gc = cross3(e1, e2);  // RENDER_SPEC 6: the geometric normal is normalize(cross(e1, e2)) of the stored world-space edges
+    st.gcross[0] = gc.x; st.gcross[1] = gc.y; st.gcross[2] = gc.z;
     tri[0] = make_float4(v[0].x, v[0].y, v[0].z, __uint_as_float(g));
     tri[1] = make_float4(e1.x, e1.y, e1.z, 0.0f);
     tri[2] = make_float4(e2.x, e2.y, e2.z, 0.0f);
@@ -102,12 +105,12 @@ __global__ void __launch_bounds__(256) k_flatten(const hala_gpu_mesh_data* __res
     for (int k = 0; k < 3; ++k) { ord[k] = f2ord(b.mn[k]); ord[3 + k] = f2ord(b.mx[k]); }
     const float4* sp = reinterpret_cast<const float4*>(&st);
 #pragma unroll
-    for (int k = 0; k < 7; ++k) stage[tid * 7u + k] = sp[k];
+    for (int k = 0; k < 8; ++k) stage[tid * 8u + k] = sp[k];
   }
   __syncthreads();
   {
     float4* out = reinterpret_cast<float4*>(shade_tris + base);
-    for (uint32_t i = tid; i < cnt * 7u; i += 256u) out[i] = stage[i];
+    for (uint32_t i = tid; i < cnt * 8u; i += 256u) out[i] = stage[i];
   }
   __syncthreads();
   if (g < n) { stage[tid * 3u] = tri[0]; stage[tid * 3u + 1u] = tri[1]; stage[tid * 3u + 2u] = tri[2]; }

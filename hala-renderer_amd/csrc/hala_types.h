@@ -54,19 +54,22 @@ struct alignas(16) Tri {
 };
 static_assert(sizeof(Tri) == 48, "triangle is 48 B");
 
-// 112-B shading record of one triangle (global-id order): what the closest-hit stage interpolates, gathered once at
-// build time from the vertex / index arenas so that shading a hit costs one dependent fetch (this record) instead of a
-// chain triangle -> instance -> indices -> three 44-B vertices.  Values are the LOCAL vertex attributes, untouched: the
-// instance transform is applied to the interpolated normal exactly as RENDER_SPEC §6 says (288 GB of HBM pay for this).
-struct alignas(16) ShadeTri {
-  float n[3][3];    // vertex normals
-  float uv[3][2];   // texture coordinates
-  float tg[3][3];   // tangents (normal mapping)
-  uint32_t inst;    // instance (node x primitive) -> transform, material
-  uint32_t material;
-  uint32_t pad[2];
+// 128-B shading record of one triangle (global-id order), 128-B aligned: what the closest-hit stage interpolates, gathered once at
+// build time from the vertex / index arenas so that shading a hit costs ONE dependent 64-B line (untextured materials) or two
+// (textured) instead of a chain triangle -> instance -> indices -> three 44-B vertices.  The bounce-shade launches are bound by
+// random 64-B fabric requests (profiles/r02_*): the 112-B record + the 48-B triangle it replaces straddled four lines on average.
+// Vertex attributes are the LOCAL ones, untouched: the instance transform is applied to the interpolated normal exactly as
+// RENDER_SPEC §6 says.  gcross = cross(e1, e2) of the world-space edges (the same fma form the shading would evaluate).
+struct alignas(128) ShadeTri {
+  float gcross[3]; uint32_t inst;      // line 1: geometric normal (unnormalised; its length is twice the area) | instance (node x primitive)
+  float n0[3];     uint32_t material;  //         vertex normals | material index
+  float n1[3];     uint32_t pad0;
+  float n2[3];     uint32_t pad1;
+  float uv[3][2];                      // line 2 (textured materials only): texture coordinates
+  float tg[3][3];                      //         tangents (normal mapping)
+  uint32_t pad2;
 };
-static_assert(sizeof(ShadeTri) == 112, "shading record is 112 B");
+static_assert(sizeof(ShadeTri) == 128, "shading record is 128 B");
 
 // One texture of set 2 binding 0 (src/rt_renderer.rs:197-226): a full mip chain of linear RGBA32F texels in the
 // texture arena (8-bit sources are decoded once at upload; gen_mipmaps of gpu_uploader.rs:366-400 is a 2x2 box filter
@@ -95,6 +98,7 @@ struct SceneView {
   const uint32_t* inst_first_tri;
   const hala_gpu_mesh_data* primitives;  // set 1 binding 4
   const hala_gpu_material* materials;    // set 1 binding 3
+  const uint8_t* material_kind;          // per material: the shading-kind bin (kShadeKind*) the bounce shade kernel groups paths by
   const hala_gpu_light* lights;          // set 1 binding 2
   const hala_gpu_camera* cameras;        // set 1 binding 1
   const float* env_pixels;       // RGBA32F (set 0 binding 6)
@@ -104,6 +108,21 @@ struct SceneView {
   float ray_eps;
   uint32_t staged;  // 1: the whole BVH fits the LDS budget (lds_nodes == node_count, lds_tris == tri_count) and is staged per workgroup
 };
+
+// Shading kinds: what decides most of k_shade's control flow.  Bounce paths reach the shade kernel in arbitrary order; inside a
+// workgroup they are regrouped by kind so that a wave runs one flavour of the BSDF code (RENDER_SPEC is untouched: which lane
+// shades which path is not observable).
+constexpr uint32_t kShadeKindMiss = 0;       // no surface: environment / sky (or an analytic light in front of everything)
+constexpr uint32_t kShadeKindFirst = 1;      // 1 + (DISNEY ? 2 : 0) + (textured ? 1 : 0); DISNEY with transmission: 5 + textured
+constexpr uint32_t kShadeKindSpecial = 7;    // opacity < 1 or a participating medium
+constexpr uint32_t kShadeKinds = 9;          // + 8: no path in this lane
+inline uint8_t shade_kind_of(const hala_gpu_material& m, uint32_t texture_count) {
+  if (m.opacity < 1.0f || m.medium_type != 0u) return (uint8_t)kShadeKindSpecial;
+  const bool tex = m.base_color_map_index < texture_count || m.normal_map_index < texture_count ||
+                   m.metallic_roughness_map_index < texture_count || m.emission_map_index < texture_count;
+  if (m.type == 1u && m.specular_transmission > 0.0f) return (uint8_t)(5u + (tex ? 1u : 0u));
+  return (uint8_t)(kShadeKindFirst + (m.type == 1u ? 2u : 0u) + (tex ? 1u : 0u));
+}
 
 // per-update constants derived on the host from HalaGlobalUniform + camera 0 (RENDER_SPEC §5)
 struct FrameConst {

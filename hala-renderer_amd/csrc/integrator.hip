@@ -173,9 +173,8 @@ RT_DI void persistent_trace(const SceneView& sv, const TraverseLds& lds, uint2* 
     if (__ballot(has) == 0ull) { if (!more) break; continue; }
     for (;;) {
       if (COUNT && lane_id() == 0u) sc.wave_steps++;  // lane 0 runs every iteration of this wave-uniform loop
-      if (has) {
-        if (trav_step<ANY, COUNT, STAGED>(sv, lds, spill, t, sc)) { src.done(idx, t, pay); has = false; }
-      }
+      // every lane calls it: the large-scene variant deals the wave's leaf work out over all 64 lanes (traverse.h)
+      if (trav_step<ANY, COUNT, STAGED>(sv, lds, spill, t, has, sc)) { src.done(idx, t, pay); has = false; }
       const uint32_t nidle = (uint32_t)__popcll(__ballot(!has));
       if (nidle == 64u || (more && nidle >= refill)) break;
     }
@@ -337,7 +336,6 @@ template <bool PRIMARY>
 #endif
 __global__ void __launch_bounds__(kShadeThreads, RT_SHADE_WAVES) k_shade(FrameConst fc, SceneView sv, Queues q, PathState ps, Control* __restrict__ ctl, uint32_t depth) {
   __shared__ BlockCompact s_compact;
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t n = PRIMARY ? fc.slot_count : ctl->n_active[depth];
   // the traversal of this bounce is over and the next users (shadow pass of this bounce, closest-hit pass of the next)
   // have not started: re-arm their work counters here
@@ -348,6 +346,40 @@ __global__ void __launch_bounds__(kShadeThreads, RT_SHADE_WAVES) k_shade(FrameCo
     if (threadIdx.x == 0u) { ctl->work_closest.dry[0] = 0ull; ctl->work_shadow[0].dry[0] = 0ull; ctl->work_shadow[1].dry[0] = 0ull; }
   }
   if (blockIdx.x * blockDim.x >= n) return;  // whole workgroup beyond the queue (uniform exit: barriers below)
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (!PRIMARY) {
+    // Bounce paths arrive in no particular order and the BSDF code is a forest of branches (miss / diffuse / Disney / glass /
+    // textured ...): a wave ran its VALU instructions at 21 of 64 lanes on the 1 M-triangle scene (profiles/r02_a_pmc_config4.txt).
+    // Regroup the workgroup's 512 paths by shading kind first (counting sort through LDS: 9 ballots, one pass): a wave then
+    // shades (mostly) one kind.  Which lane shades which path is not observable: every output is indexed by path slot or comes
+    // out of the block compaction below.
+    __shared__ uint16_t s_perm[kShadeThreads];
+    __shared__ uint32_t s_bin[kShadeKinds][kShadeThreads / 64 + 1];
+    uint32_t kind = kShadeKinds - 1u;
+    if (i < n) {
+      const uint32_t prim = reinterpret_cast<const uint32_t*>(q.hits + i)[3];
+      kind = kShadeKindMiss;
+      if (prim != kAbsent) kind = sv.material_kind[sv.shade_tris[prim].material];
+    }
+    const uint32_t w = threadIdx.x >> 6, l = lane_id();
+    uint32_t rank = 0;
+#pragma unroll
+    for (uint32_t b = 0; b < kShadeKinds; ++b) {
+      const unsigned long long m = __ballot(kind == b);
+      if (kind == b) rank = mbcnt64(m);
+      if (l == 0u) s_bin[b][w] = (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0u) {  // exclusive prefix in (kind, wave) order: 72 serial adds
+      uint32_t run = 0;
+      for (uint32_t b = 0; b < kShadeKinds; ++b)
+        for (uint32_t j = 0; j < kShadeThreads / 64; ++j) { const uint32_t c = s_bin[b][j]; s_bin[b][j] = run; run += c; }
+    }
+    __syncthreads();
+    s_perm[s_bin[kind][w] + rank] = (uint16_t)threadIdx.x;
+    __syncthreads();
+    i = blockIdx.x * blockDim.x + s_perm[threadIdx.x];
+  }
   const bool active = i < n;
   const uint32_t in = depth & 1u, out = in ^ 1u;
   bool keep[3] = {false, false, false};  // path survives, light connection, environment connection
@@ -610,9 +642,12 @@ __global__ void __launch_bounds__(256) k_scatter_tiles(FrameConst fc, const floa
 // ---------------------------------------------------------------------------------------------------------
 static inline uint32_t blocks_for(uint32_t n, uint32_t per) { return (n + per - 1) / per; }
 
-size_t traverse_stack_bytes() { return (size_t)kStackLds * kTraverseThreads * 8; }
-uint32_t traverse_stack_lds_levels() { return kStackLds; }
+size_t traverse_fixed_lds_bytes(bool staged) {  // per-lane stacks (+ the waves' leaf work lists and merge slots of the large-scene variant)
+  return staged ? (size_t)kStackLdsStaged * kTraverseThreads * 8 : (size_t)kStackLdsGlobal * kTraverseThreads * 8 + (kTraverseThreads / 64) * kCoopBytesPerWave;
+}
+uint32_t traverse_stack_lds_levels(bool staged) { return staged ? kStackLdsStaged : kStackLdsGlobal; }
 uint32_t traverse_stack_spill_levels() { return kStackSpill; }
+uint32_t traverse_max_leaf(bool staged) { return staged ? 8u : (uint32_t)kLeafSlots; }
 uint32_t traverse_blocks_per_cu(size_t dynamic_lds_bytes, bool staged) {
   int a = 0, b = 0;
   const hipError_t ea = staged ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_batch<false, false, true>, kTraverseThreads, dynamic_lds_bytes)
@@ -623,7 +658,7 @@ uint32_t traverse_blocks_per_cu(size_t dynamic_lds_bytes, bool staged) {
   return (uint32_t)std::max(0, std::min(a, b));
 }
 static size_t traverse_smem(const SceneView& sv) {
-  return traverse_stack_bytes() + (sv.staged ? (size_t)sv.lds_nodes * 64 + (size_t)sv.lds_tris * 48 : 0);
+  return traverse_fixed_lds_bytes(sv.staged != 0u) + (sv.staged ? (size_t)sv.lds_nodes * 64 + (size_t)sv.lds_tris * 48 : 0);
 }
 
 // the traversal kernels are compiled per (any-hit, counting, BVH staged in LDS); all three are launch-time constants

@@ -15,8 +15,9 @@ struct LaunchCfg {
 };
 
 // integrator.hip
-size_t traverse_stack_bytes();          // LDS bytes of the per-lane traversal stacks of one workgroup
-uint32_t traverse_stack_lds_levels();    // stack entries kept in LDS
+size_t traverse_fixed_lds_bytes(bool staged);  // LDS bytes of one workgroup besides a staged BVH: per-lane stacks (+ leaf work lists)
+uint32_t traverse_stack_lds_levels(bool staged);  // stack entries kept in LDS
+uint32_t traverse_max_leaf(bool staged);  // largest leaf (triangles) the traversal variant accepts
 uint32_t traverse_stack_spill_levels();  // deeper entries spilled to global scratch (8 B each, per lane)
 uint32_t traverse_blocks_per_cu(size_t dynamic_lds_bytes, bool staged);  // resident workgroups per CU (occupancy query)
 void launch_trace_batch(const LaunchCfg& lc, const SceneView& sv, const hala_ray* rays, hala_hit* hits, const uint32_t* n_ptr,

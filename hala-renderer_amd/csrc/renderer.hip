@@ -25,10 +25,10 @@ using namespace rt;
 
 namespace {
 
-constexpr uint32_t kLeafMax = 2;  // triangles per leaf: a triangle test costs ~2x a child box test, profiles/r01_h_experiments.txt
+constexpr uint32_t kLeafMax = 4;  // triangles per leaf, large scenes: the wave tests a leaf's triangles side by side (traverse.h), so fewer, fuller leaves win (profiles/r02_experiments.txt; 2 while each lane tested its own leaves)
 constexpr uint32_t kLeafMaxStaged = 4;  // ... unless the whole tree sits in LDS: leaves of two packed pairs, fewer node steps (+2 % on Cornell)
 constexpr size_t kLdsStageBudget = 40 * 1024;  // a BVH up to this size is staged whole in LDS (next to the 24-KB stack)
-constexpr uint32_t kRefillThreshold = 32;      // idle lanes that trigger a refill of the wave (persistent_trace)
+constexpr uint32_t kRefillThreshold = 24;      // idle lanes that trigger a refill of the wave (persistent_trace; profiles/r02_experiments.txt)
 constexpr int kStatRing = 16;
 constexpr uint32_t kMaxSampleBatch = 16;  // frames per wavefront pass in hala_rt_update_batch (~250 B of state per path)
 
@@ -117,6 +117,7 @@ struct hala_rt_renderer {
   DeviceArray<hala_gpu_camera> d_cameras;
   DeviceArray<hala_gpu_light> d_lights;
   DeviceArray<hala_gpu_material> d_materials;
+  DeviceArray<uint8_t> d_material_kind;
   DeviceArray<hala_gpu_mesh_data> d_instances;
   DeviceArray<uint32_t> d_inst_first_tri;
   DeviceArray<float4> d_tex_arena;
@@ -131,6 +132,7 @@ struct hala_rt_renderer {
   DeviceArray<BvhNode4> d_nodes;
   uint32_t lds_nodes = 0, lds_tris = 0;
   bool staged = false;  // whole BVH staged in LDS by the traversal kernels
+  uint32_t leaf_max_built = 0;
   float ray_eps = 0.0f;
   DeviceArray<uint2> d_spill;
   LaunchCfg lcfg{};
@@ -199,7 +201,7 @@ struct hala_rt_renderer {
   SceneView view() const {
     SceneView sv{};
     sv.nodes = d_nodes.ptr; sv.tris = d_tris.ptr; sv.tris_any = any_invisible ? d_tris_any.ptr : d_tris.ptr; sv.tris_by_id = d_tris_by_id.ptr; sv.shade_tris = d_shade_tris.ptr; sv.tri_instance = d_tri_instance.ptr;
-    sv.inst_first_tri = d_inst_first_tri.ptr; sv.primitives = d_instances.ptr; sv.materials = d_materials.ptr;
+    sv.inst_first_tri = d_inst_first_tri.ptr; sv.primitives = d_instances.ptr; sv.materials = d_materials.ptr; sv.material_kind = d_material_kind.ptr;
     sv.lights = d_lights.ptr; sv.cameras = d_cameras.ptr;
     sv.textures = d_textures.ptr; sv.tex_arena = d_tex_arena.ptr; sv.texture_count = (uint32_t)host_textures.size();
     sv.env_pixels = reinterpret_cast<const float*>(d_env.ptr); sv.env_marginal = d_marginal.ptr; sv.env_conditional = d_conditional.ptr;
@@ -375,6 +377,11 @@ int upload_packed(hala_rt_renderer* r, bool geometry = true) {
   RT_HIP(r->d_cameras.upload(hs.cameras.data(), hs.cameras.size(), r->stream));
   RT_HIP(r->d_lights.upload(hs.lights.data(), hs.lights.size(), r->stream));
   RT_HIP(r->d_materials.upload(hs.gpu_materials.data(), hs.gpu_materials.size(), r->stream));
+  {
+    std::vector<uint8_t> kind(hs.gpu_materials.size());
+    for (size_t i = 0; i < kind.size(); ++i) kind[i] = shade_kind_of(hs.gpu_materials[i], (uint32_t)hs.texture_image.size());
+    RT_HIP(r->d_material_kind.upload(kind.data(), kind.size(), r->stream));
+  }
   RT_HIP(r->d_instances.upload(hs.instances.data(), hs.instances.size(), r->stream));
   RT_HIP(r->d_inst_first_tri.upload(hs.inst_first_tri.data(), hs.inst_first_tri.size(), r->stream));
   RT_HIP(hipStreamSynchronize(r->stream));
@@ -426,7 +433,8 @@ int configure_traversal(hala_rt_renderer* r) {
   r->staged = nb + tb <= budget;
   r->lds_nodes = r->staged ? r->bvh.node_count : 0u;
   r->lds_tris = r->staged ? r->bvh.tri_count : 0u;
-  const size_t smem = (size_t)r->lds_nodes * 64 + (size_t)r->lds_tris * 48 + traverse_stack_bytes();
+  if (r->leaf_max_built > traverse_max_leaf(r->staged)) RT_FAIL("The BVH was built with larger leaves than the traversal variant for its size accepts.");
+  const size_t smem = (size_t)r->lds_nodes * 64 + (size_t)r->lds_tris * 48 + traverse_fixed_lds_bytes(r->staged);
   uint32_t per_cu = traverse_blocks_per_cu(smem, r->staged);
   if (per_cu == 0) RT_FAIL("The traversal kernel does not fit on a compute unit with the requested LDS staging.");
   per_cu = std::min(per_cu, 8u);
@@ -436,8 +444,8 @@ int configure_traversal(hala_rt_renderer* r) {
   // refilling once half the wave is idle is best when node fetches go to L2 / Infinity Cache
   r->lcfg.refill = r->staged ? 64u : kRefillThreshold;
   if (const char* e = getenv("HALART_REFILL")) r->lcfg.refill = std::min(64u, std::max(1u, (uint32_t)strtoul(e, nullptr, 10)));  // tuning knob
-  if (r->bvh.stack_need > traverse_stack_lds_levels()) {
-    if (r->bvh.stack_need > traverse_stack_lds_levels() + traverse_stack_spill_levels()) {
+  if (r->bvh.stack_need > traverse_stack_lds_levels(r->staged)) {
+    if (r->bvh.stack_need > traverse_stack_lds_levels(r->staged) + traverse_stack_spill_levels()) {
       // 3 x levels is a loose bound (every node on the path deferring three siblings).  Before refusing the tree, take the exact
       // one: need(node) = (inner children - 1) + max need(inner child) — the worst order visits the child with the deepest
       // need first while all its siblings wait.  Nodes are in breadth-first order (children behind their parent): one reverse sweep.
@@ -455,7 +463,7 @@ int configure_traversal(hala_rt_renderer* r) {
       }
       r->bvh.stack_need = need.empty() ? 1u : std::max(1u, need[0]);
     }
-    if (r->bvh.stack_need > traverse_stack_lds_levels() + traverse_stack_spill_levels())
+    if (r->bvh.stack_need > traverse_stack_lds_levels(r->staged) + traverse_stack_spill_levels())
       RT_FAIL("The BVH is deeper than the traversal stack supports (" + std::to_string(r->bvh.max_depth) + " levels, " + std::to_string(r->bvh.stack_need) + " stack entries).");
     RT_HIP(r->d_spill.resize((size_t)r->lcfg.persistent_blocks * 256 * traverse_stack_spill_levels()));
     r->lcfg.spill = r->d_spill.ptr;
@@ -487,8 +495,10 @@ int build_bvh(hala_rt_renderer* r) {
   // a scene this small will be staged in LDS (configure_traversal: 48 B per triangle + at most ~32 B of nodes per triangle)
   uint32_t leaf_max = (size_t)n * 80 <= kLdsStageBudget ? kLeafMaxStaged : kLeafMax;
   if (const char* ev = getenv("HALART_LEAF_MAX")) leaf_max = std::min(8u, std::max(1u, (uint32_t)atoi(ev)));  // tuning knob
+  if ((size_t)n * 80 > kLdsStageBudget) leaf_max = std::min(leaf_max, traverse_max_leaf(false));  // one consumer lane per triangle of a leaf item
   const std::string e = bvh_build(r->bvh, leaf_max, r->stream);
   if (!e.empty()) RT_FAIL(e);
+  r->leaf_max_built = leaf_max;
   return configure_traversal(r);
 }
 

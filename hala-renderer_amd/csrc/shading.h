@@ -499,21 +499,15 @@ RT_DI f3 transform_vector(const float* m, f3 p) {
 }
 RT_DI Surface make_surface(const SceneView& sv, float pixel_spread, f3 o, f3 d, float t, float u, float v, uint32_t prim) {
   Surface sf;
-  const float4* tp = reinterpret_cast<const float4*>(sv.tris_by_id + prim);
-  const float4 tb = tp[1], tc = tp[2];
-  // one 112-B record holds the three vertices' attributes, the instance and the material of the hit triangle
+  // line 1 of the 128-B shading record: geometric normal, vertex normals, instance, material
   const float4* sp = reinterpret_cast<const float4*>(sv.shade_tris + prim);
-  const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3], s6 = sp[6];
-  const uint32_t inst = __float_as_uint(s6.x), material = __float_as_uint(s6.y);
+  const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3];
+  const uint32_t inst = __float_as_uint(s0.w), material = __float_as_uint(s1.w);
   const hala_gpu_mesh_data& md = sv.primitives[inst];
-  struct VA { float normal[3], tex_coord[2], tangent[3]; };
-  const VA a = {{s0.x, s0.y, s0.z}, {s2.y, s2.z}, {0.0f, 0.0f, 0.0f}};
-  const VA b = {{s0.w, s1.x, s1.y}, {s2.w, s3.x}, {0.0f, 0.0f, 0.0f}};
-  const VA c = {{s1.z, s1.w, s2.x}, {s3.y, s3.z}, {0.0f, 0.0f, 0.0f}};
   float w0 = 1.0f - u - v;
-  f3 nl = madd3(ld3(c.normal), v, madd3(ld3(b.normal), u, ld3(a.normal) * w0));
+  f3 nl = madd3(mk3(s3.x, s3.y, s3.z), v, madd3(mk3(s2.x, s2.y, s2.z), u, mk3(s1.x, s1.y, s1.z) * w0));
   sf.ns = normalize3(transform_normal(md.transform, nl));
-  const f3 gcross = cross3(mk3(tb.x, tb.y, tb.z), mk3(tc.x, tc.y, tc.z));
+  const f3 gcross = mk3(s0.x, s0.y, s0.z);
   sf.ng = normalize3(gcross);
   sf.P = madd3(d, t, o);
   const hala_gpu_material& m = sv.materials[material];
@@ -529,6 +523,10 @@ RT_DI Surface make_surface(const SceneView& sv, float pixel_spread, f3 o, f3 d, 
   const bool has_base = m.base_color_map_index < nt, has_nrm = m.normal_map_index < nt;
   const bool has_mr = m.metallic_roughness_map_index < nt, has_em = m.emission_map_index < nt;
   if (has_base || has_nrm || has_mr || has_em) {
+    // line 2: texture coordinates and tangents (in flight together with the texture descriptors)
+    const float4 s4 = sp[4], s5 = sp[5], s6 = sp[6], s7 = sp[7];
+    struct VA { float tex_coord[2]; };
+    const VA a = {{s4.x, s4.y}}, b = {{s4.z, s4.w}}, c = {{s5.x, s5.y}};
     const float tu = __fmaf_rn(c.tex_coord[0], v, __fmaf_rn(b.tex_coord[0], u, a.tex_coord[0] * w0));
     const float tv = __fmaf_rn(c.tex_coord[1], v, __fmaf_rn(b.tex_coord[1], u, a.tex_coord[1] * w0));
     // footprint of one pixel's cone on the surface vs. the uv density of this triangle
@@ -563,8 +561,8 @@ RT_DI Surface make_surface(const SceneView& sv, float pixel_spread, f3 o, f3 d, 
     }
     if (has_nrm) {
       const float4 s = tex_sample(sv, m.normal_map_index, tu, tv, tex_lod(sv, m.normal_map_index, lod_base));
-      const float4 s4 = sp[4], s5 = sp[5];  // tangents: s3.w s4.x s4.y | s4.z s4.w s5.x | s5.y s5.z s5.w
-      const f3 tl = madd3(mk3(s5.y, s5.z, s5.w), v, madd3(mk3(s4.z, s4.w, s5.x), u, mk3(s3.w, s4.x, s4.y) * w0));
+      // tangents: s5.z s5.w s6.x | s6.y s6.z s6.w | s7.x s7.y s7.z
+      const f3 tl = madd3(mk3(s7.x, s7.y, s7.z), v, madd3(mk3(s6.y, s6.z, s6.w), u, mk3(s5.z, s5.w, s6.x) * w0));
       f3 tw = transform_vector(md.transform, tl);
       tw = tw - sf.ns * dot3(sf.ns, tw);  // Gram-Schmidt against the shading normal
       const float tl2 = dot3(tw, tw);

@@ -21,7 +21,7 @@ namespace rt {
 constexpr int kTraverseThreads = 256;
 // second launch-bound argument = waves per SIMD; it caps the register allocation (512 / waves)
 #ifndef RT_WAVES_PER_SIMD
-#define RT_WAVES_PER_SIMD 6  // profiles/r01_e_variant_sweep.txt, re-checked for BVH4 in profiles/r01_h_experiments.txt
+#define RT_WAVES_PER_SIMD 5  // 28 KB of LDS per workgroup (stacks + leaf work lists): five workgroups per CU; 96 VGPRs
 #endif
 constexpr int kTraverseWavesPerSimd = RT_WAVES_PER_SIMD;
 #ifndef RT_WAVES_PER_SIMD_STAGED
@@ -30,29 +30,58 @@ constexpr int kTraverseWavesPerSimd = RT_WAVES_PER_SIMD;
 constexpr int kTraverseWavesPerSimdStaged = RT_WAVES_PER_SIMD_STAGED;
 // Per-lane traversal stack: 8-B entries (ordering key = entry distance | slot, child reference).  96 B of LDS per lane
 // = 24 KB per workgroup: six workgroups plus their staged BVH fill the 160 KB of a CU at 6 waves/SIMD.
-constexpr int kStackLds = 12;    // entries kept in LDS per lane
+constexpr int kStackLdsStaged = 12;  // entries kept in LDS per lane, LDS-staged scenes (shallow trees: never spills)
+#ifndef RT_STACK_LDS
+#define RT_STACK_LDS 8  // large scenes: the LDS also holds the wave's leaf work list (below); pops drop culled entries, deep stacks are rare
+#endif
+constexpr int kStackLdsGlobal = RT_STACK_LDS;
+template <bool STAGED> RT_DI constexpr int stack_lds() { return STAGED ? kStackLdsStaged : kStackLdsGlobal; }
 constexpr int kStackSpill = 56;  // deeper entries, global scratch
+// Wave-cooperative leaf pass of the large-scene kernels (trav_step, !STAGED): every wave owns a work list of up to 64 x 4 leaf items
+// (8 B: leaf reference, owner lane) and one 16-B merge slot per lane (best hit so far as a 64-bit key | u, v).
+#ifndef RT_LEAF_SLOTS
+#define RT_LEAF_SLOTS 4
+#endif
+constexpr int kLeafSlots = RT_LEAF_SLOTS;  // consumer lanes per leaf item = the largest leaf the large-scene builds may emit (power of two)
+constexpr int kCoopItems = 64 * 4;
+constexpr size_t kCoopBytesPerWave = (size_t)kCoopItems * 8 + 64 * 16;
 
+// LDS is addressed through explicit address-space-3 pointers to builtin vectors: a generic pointer kept in a struct makes hipcc emit
+// flat_load / flat_store (both memory pipes, both wait counters) instead of ds_read / ds_write.
+#define RT_LDS __attribute__((address_space(3)))
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct TraverseLds {
-  const float4* nodes;  // staged variant only: node_count * 4
-  const float4* tris;   // staged variant only: tri_count * 3
-  uint2* stack;         // kStackLds * kTraverseThreads
+  const RT_LDS f32x4* nodes;  // staged variant only: node_count * 4
+  const RT_LDS f32x4* tris;   // staged variant only: tri_count * 3
+  RT_LDS u32x2* stack;        // stack_lds() * kTraverseThreads
+  RT_LDS u32x2* items;        // !STAGED: this wave's leaf work list
+  RT_LDS u32x4* slots;        // !STAGED: this wave's merge slots
 };
+RT_DI float4 ld4(const RT_LDS f32x4* p) { const f32x4 v = *p; return make_float4(v.x, v.y, v.z, v.w); }
 
-// LDS layout: stack | nodes | triangles.  STAGED: cooperative copy of the whole BVH (coalesced 16-B loads).
+// LDS layout: stack | STAGED: nodes | triangles; else: per-wave work lists | per-wave merge slots.  STAGED: cooperative copy of the
+// whole BVH (coalesced 16-B loads).
 template <bool STAGED>
 RT_DI TraverseLds stage_bvh(const SceneView& sv, unsigned char* smem) {
-  uint2* st = reinterpret_cast<uint2*>(smem);
-  float4* ln = reinterpret_cast<float4*>(smem + (size_t)kStackLds * kTraverseThreads * 8);
-  float4* lt = ln + (size_t)sv.lds_nodes * 4;
+  RT_LDS unsigned char* base = (RT_LDS unsigned char*)smem;
+  RT_LDS u32x2* st = (RT_LDS u32x2*)base;
+  RT_LDS unsigned char* rest = base + (size_t)stack_lds<STAGED>() * kTraverseThreads * 8;
   if (STAGED) {
-    const float4* gn = reinterpret_cast<const float4*>(sv.nodes);
-    const float4* gt = reinterpret_cast<const float4*>(sv.tris);
+    RT_LDS f32x4* ln = (RT_LDS f32x4*)rest;
+    RT_LDS f32x4* lt = ln + (size_t)sv.lds_nodes * 4;
+    const f32x4* gn = reinterpret_cast<const f32x4*>(sv.nodes);
+    const f32x4* gt = reinterpret_cast<const f32x4*>(sv.tris);
     for (uint32_t i = threadIdx.x; i < sv.lds_nodes * 4; i += blockDim.x) ln[i] = gn[i];
     for (uint32_t i = threadIdx.x; i < sv.lds_tris * 3; i += blockDim.x) lt[i] = gt[i];
     __syncthreads();
+    return TraverseLds{ln, lt, st, nullptr, nullptr};
   }
-  return TraverseLds{ln, lt, st};
+  const uint32_t w = threadIdx.x >> 6;
+  RT_LDS u32x2* items = (RT_LDS u32x2*)rest + (size_t)w * kCoopItems;
+  RT_LDS u32x4* slots = (RT_LDS u32x4*)(rest + (size_t)(kTraverseThreads / 64) * kCoopItems * 8) + (size_t)w * 64;
+  return TraverseLds{nullptr, nullptr, st, items, slots};
 }
 
 struct RayPre {
@@ -66,21 +95,21 @@ RT_DI RayPre make_ray(f3 o, f3 d, float tmin) {
   r.ood = r.o * r.idir;
   return r;
 }
-// §4.2 Möller–Trumbore
-RT_DI bool tri_test(const RayPre& r, float4 a, float4 b, float4 c, float* t, float* u, float* v) {
-  f3 e1 = mk3(b.x, b.y, b.z), e2 = mk3(c.x, c.y, c.z);
-  f3 p = cross3(r.d, e2);
-  float det = dot3(e1, p);
-  if (det == 0.0f) return false;
-  float inv = 1.0f / det;
-  f3 tv = r.o - mk3(a.x, a.y, a.z);
-  float uu = dot3(tv, p) * inv;
-  if (!(uu >= 0.0f && uu <= 1.0f)) return false;
-  f3 q = cross3(tv, e1);
-  float vv = dot3(r.d, q) * inv;
-  if (!(vv >= 0.0f && uu + vv <= 1.0f)) return false;
+// §4.2 Möller–Trumbore, straight-line: the same operations in the same order as the early-out form of the spec (an accepted hit
+// has the same t, u, v bit for bit; a rejected one is rejected by the same comparisons, evaluated at the end).  No branch sits
+// between the three 16-B loads of the triangle and their uses, so the loads leave together — with early-outs hipcc sank the load of
+// v0 below the `det == 0` branch: two dependent memory round trips per triangle.
+RT_DI bool tri_test_od(f3 o, f3 d, float4 a, float4 b, float4 c, float* t, float* u, float* v) {
+  const f3 e1 = mk3(b.x, b.y, b.z), e2 = mk3(c.x, c.y, c.z);
+  const f3 p = cross3(d, e2);
+  const float det = dot3(e1, p);
+  const float inv = 1.0f / det;
+  const f3 tv = o - mk3(a.x, a.y, a.z);
+  const float uu = dot3(tv, p) * inv;
+  const f3 q = cross3(tv, e1);
+  const float vv = dot3(d, q) * inv;
   *t = dot3(e2, q) * inv; *u = uu; *v = vv;
-  return true;
+  return det != 0.0f && uu >= 0.0f && uu <= 1.0f && vv >= 0.0f && uu + vv <= 1.0f;
 }
 
 struct HitRec {
@@ -144,48 +173,27 @@ RT_DI void tri_test2(const RayPre& r, float4 a0, float4 b0, float4 c0, float4 a1
   t[0] = tt.x; t[1] = tt.y; u[0] = uu.x; u[1] = uu.y; v[0] = vv.x; v[1] = vv.y;
 }
 
-// closest-hit / any-hit test of one leaf (count <= 8 triangles from `first`, storage order; fetched and tested two at a
-// time: a leaf costs ceil(count/2) memory round trips and ceil(count/2) packed triangle tests)
-template <bool ANY, bool STAGED>
-RT_DI bool leaf_test(const SceneView& sv, const TraverseLds& lds, const RayPre& r, float tmax, HitRec& best, uint32_t first, uint32_t count) {
-  const float4* base = STAGED ? lds.tris : reinterpret_cast<const float4*>(sv.tris);
+// LDS-staged scenes: closest-hit / any-hit test of one leaf (count <= 8 triangles from `first`, storage order; fetched and tested
+// two at a time on the packed FP32 pipe: a leaf costs ceil(count/2) LDS round trips and ceil(count/2) packed tests; 4 waves/SIMD,
+// 128 VGPRs).  ANY: true on the first accepted triangle.
+template <bool ANY>
+RT_DI bool leaf_test_staged(const TraverseLds& lds, const RayPre& r, float tmax, HitRec& best, uint32_t first, uint32_t count) {
   for (uint32_t i = 0; i < count; i += 2u) {
     const bool two = i + 1u < count;
-    const float4* p = base + (size_t)(first + i) * 3;
-    if (STAGED) {
-      // LDS-resident scenes (4 waves/SIMD, 128 VGPRs): the pair is tested on the packed pipe
-      const float4 a0 = p[0], b0 = p[1], c0 = p[2];
-      float4 a1 = a0, b1 = b0, c1 = c0;  // a single triangle is tested against itself in the second component (result unused)
-      if (two) { a1 = p[3]; b1 = p[4]; c1 = p[5]; }
-      bool ok[2]; float tt[2], uu[2], vv[2];
-      tri_test2(r, a0, b0, c0, a1, b1, c1, ok, tt, uu, vv);
+    const RT_LDS f32x4* p = lds.tris + (size_t)(first + i) * 3;
+    const float4 a0 = ld4(p), b0 = ld4(p + 1), c0 = ld4(p + 2);
+    float4 a1 = a0, b1 = b0, c1 = c0;  // a single triangle is tested against itself in the second component (result unused)
+    if (two) { a1 = ld4(p + 3); b1 = ld4(p + 4); c1 = ld4(p + 5); }
+    bool ok[2]; float tt[2], uu[2], vv[2];
+    tri_test2(r, a0, b0, c0, a1, b1, c1, ok, tt, uu, vv);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        if (!ok[j] || (j == 1 && !two)) continue;
-        const uint32_t id = __float_as_uint(j ? a1.w : a0.w);
-        if (ANY) {
-          if (tt[j] > r.tmin && tt[j] < tmax) { best.t = tt[j]; best.u = uu[j]; best.v = vv[j]; best.prim = id; return true; }
-        } else if (tt[j] > r.tmin && (tt[j] < best.t || (tt[j] == best.t && id < best.prim))) {
-          best.t = tt[j]; best.u = uu[j]; best.v = vv[j]; best.prim = id;
-        }
-      }
-    } else {
-      // large scenes keep 6 waves/SIMD to hide L2 / Infinity Cache latency; the register pairs of the packed form would
-      // spill there (profiles/r01_h_experiments.txt), so the two triangles are tested one after the other
-      float4 a0 = p[0], b0 = p[1], c0 = p[2], a1, b1, c1;
-      if (two) { a1 = p[3]; b1 = p[4]; c1 = p[5]; }
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        if (j == 1 && !two) break;
-        const float4 a = j ? a1 : a0, b = j ? b1 : b0, c = j ? c1 : c0;
-        float t, u, v;
-        if (!tri_test(r, a, b, c, &t, &u, &v)) continue;
-        const uint32_t id = __float_as_uint(a.w);
-        if (ANY) {
-          if (t > r.tmin && t < tmax) { best.t = t; best.u = u; best.v = v; best.prim = id; return true; }
-        } else if (t > r.tmin && (t < best.t || (t == best.t && id < best.prim))) {
-          best.t = t; best.u = u; best.v = v; best.prim = id;
-        }
+    for (int j = 0; j < 2; ++j) {
+      if (!ok[j] || (j == 1 && !two)) continue;
+      const uint32_t id = __float_as_uint(j ? a1.w : a0.w);
+      if (ANY) {
+        if (tt[j] > r.tmin && tt[j] < tmax) { best.t = tt[j]; best.u = uu[j]; best.v = vv[j]; best.prim = id; return true; }
+      } else if (tt[j] > r.tmin && (tt[j] < best.t || (tt[j] == best.t && id < best.prim))) {
+        best.t = tt[j]; best.u = uu[j]; best.v = vv[j]; best.prim = id;
       }
     }
   }
@@ -197,82 +205,177 @@ struct StepCounters {
   uint32_t nodes = 0, tris = 0, leaf_lanes = 0, leaf_passes = 0, wave_steps = 0;
 };
 
-// returns true when the ray is finished (ANY: also on the first hit inside (tmin, tmax))
+RT_DI uint32_t mbcnt64(unsigned long long m) {  // number of set bits of m below this lane
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+RT_DI float lane_read(uint32_t src_lane_x4, float v) {  // v of lane src_lane_x4 / 4 (ds_bpermute_b32: every lane of the wave must take part)
+  return __int_as_float(__builtin_amdgcn_ds_bpermute((int)src_lane_x4, __float_as_int(v)));
+}
+
+// One node visit of every lane that holds a ray (`has`); returns true when the lane's ray is finished (ANY: also on the first hit
+// inside (tmin, tmax)).  The whole wave must call it together: the large-scene variant (!STAGED) tests the leaves the wave's lanes
+// reached in this step COOPERATIVELY — the (ray, triangle) pairs are dealt out over all 64 lanes, whoever owns the ray:
+//   lane with nl leaves in reach -> nl items {leaf reference, owner lane} in the wave's LDS work list (position by a ballot prefix sum),
+//                                   its best hit so far as a 64-bit key (t bits | triangle id) in its merge slot;
+//   consumer lane s of a pass     -> item s / 4, triangle s % 4 of that leaf: fetches the OWNER's ray with ds_bpermute, the triangle
+//                                   from memory, runs the one scalar triangle test, and merges an accepted hit into the owner's slot
+//                                   with an LDS 64-bit unsigned min (t > 0, so the keys order like (t, id): exactly the closest-hit
+//                                   rule of 4.2, whatever the order of the merges); the winner then publishes its (u, v);
+//   owner                         -> reads its slot back.
+// A per-lane leaf loop ran at 4-6 of 64 lanes on the 1 M-triangle scene (1.4-1.6 passes of <= 2 sequential triangle tests per wave
+// step, each with its own dependent fetch); dealt out, a wave step has ONE pass of one triangle test at ~4x the lanes.
 template <bool ANY, bool COUNT, bool STAGED>
-RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, Trav& t, StepCounters& sc) {
-  uint2* stack = lds.stack + threadIdx.x;
+RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, Trav& t, bool has, StepCounters& sc) {
+  constexpr int kS = stack_lds<STAGED>();
+  RT_LDS u32x2* stack = lds.stack + threadIdx.x;
   const RayPre& r = t.r;
   HitRec& best = t.best;
   int sp = t.sp;
-  const float4* p = (STAGED ? lds.nodes : reinterpret_cast<const float4*>(sv.nodes)) + (size_t)t.cur * 4;
-  const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
-  if (COUNT) sc.nodes++;
-  // plane distances without materialising the planes: t = q * (2^e * idir) + (pmin * idir - o * idir)
-  const uint32_t ex = __float_as_uint(q0.w);
-  const float kx = __uint_as_float((ex & 0xffu) << 23) * r.idir.x, ky = __uint_as_float(((ex >> 8) & 0xffu) << 23) * r.idir.y,
-              kz = __uint_as_float(((ex >> 16) & 0xffu) << 23) * r.idir.z;
-  const float ax = __fmaf_rn(q0.x, r.idir.x, -r.ood.x), ay = __fmaf_rn(q0.y, r.idir.y, -r.ood.y), az = __fmaf_rn(q0.z, r.idir.z, -r.ood.z);
-  const uint32_t lox = __float_as_uint(q1.x), loy = __float_as_uint(q1.y), loz = __float_as_uint(q1.z);
-  const uint32_t hix = __float_as_uint(q1.w), hiy = __float_as_uint(q2.x), hiz = __float_as_uint(q2.y);
-  uint32_t ref[4] = {__float_as_uint(q3.x), __float_as_uint(q3.y), __float_as_uint(q3.z), __float_as_uint(q3.w)};
-  // Slab test (§4.3b): tn = max(min(x0,x1), min(y0,y1), min(z0,z1), tmin), tf = min(max(x0,x1), ..., best.t) with
-  // x0/x1 = fma(qlo/qhi, k, a).  qlo <= qhi and fma rounding is monotonic, so min(x0,x1) is simply the plane picked by the
-  // sign of the direction: select the near / far byte words once per node (6 v_cndmask) instead of 6 min/max per child,
-  // and compute (near, far) of one axis with one packed v_pk_fma_f32.  Bit-identical to the min/max form.
-  const bool px = r.idir.x >= 0.0f, py = r.idir.y >= 0.0f, pz = r.idir.z >= 0.0f;
-  const uint32_t nx = px ? lox : hix, fx = px ? hix : lox, ny = py ? loy : hiy, fy = py ? hiy : loy, nz = pz ? loz : hiz, fz = pz ? hiz : loz;
-  const v2f kx2 = {kx, kx}, ky2 = {ky, ky}, kz2 = {kz, kz}, ax2 = {ax, ax}, ay2 = {ay, ay}, az2 = {az, az};
-  // ordering key: entry distance (>= tmin >= +0, so its sign bit is free) with the child slot in its two low mantissa
-  // bits (ties -> lower slot) and the sign bit set for inner children: one sort puts the leaves first, nearest first,
-  // then the inner children, nearest first, then the misses.  Lane by lane that is the order they are processed in anyway;
-  // wave-wide it lines the lanes' k-th leaves up at position k, so the k-th copy of the triangle test runs for every lane
-  // that has a k-th leaf instead of one copy per sorted position at a few percent lane utilisation (profiles/r01_h_pmc_*).  hw_minf / hw_maxf are the one-instruction IEEE minNum / maxNum (v_min3 / v_max3 fuse them).
-  uint32_t key[4];
+  uint32_t ref[4] = {kAbsent, kAbsent, kAbsent, kAbsent}, key[4] = {kMissKey, kMissKey, kMissKey, kMissKey};
+  uint32_t next = kAbsent, next_key = 0, nl = 0;
+  if (has) {
+    float4 q0, q1, q2, q3;
+    if (STAGED) { const RT_LDS f32x4* p = lds.nodes + (size_t)t.cur * 4; q0 = ld4(p); q1 = ld4(p + 1); q2 = ld4(p + 2); q3 = ld4(p + 3); }
+    else { const float4* p = reinterpret_cast<const float4*>(sv.nodes) + (size_t)t.cur * 4; q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3]; }
+    if (COUNT) sc.nodes++;
+    // plane distances without materialising the planes: t = q * (2^e * idir) + (pmin * idir - o * idir)
+    const uint32_t ex = __float_as_uint(q0.w);
+    const float kx = __uint_as_float((ex & 0xffu) << 23) * r.idir.x, ky = __uint_as_float(((ex >> 8) & 0xffu) << 23) * r.idir.y,
+                kz = __uint_as_float(((ex >> 16) & 0xffu) << 23) * r.idir.z;
+    const float ax = __fmaf_rn(q0.x, r.idir.x, -r.ood.x), ay = __fmaf_rn(q0.y, r.idir.y, -r.ood.y), az = __fmaf_rn(q0.z, r.idir.z, -r.ood.z);
+    const uint32_t lox = __float_as_uint(q1.x), loy = __float_as_uint(q1.y), loz = __float_as_uint(q1.z);
+    const uint32_t hix = __float_as_uint(q1.w), hiy = __float_as_uint(q2.x), hiz = __float_as_uint(q2.y);
+    ref[0] = __float_as_uint(q3.x); ref[1] = __float_as_uint(q3.y); ref[2] = __float_as_uint(q3.z); ref[3] = __float_as_uint(q3.w);
+    // Slab test (§4.3b): tn = max(min(x0,x1), min(y0,y1), min(z0,z1), tmin), tf = min(max(x0,x1), ..., best.t) with
+    // x0/x1 = fma(qlo/qhi, k, a).  qlo <= qhi and fma rounding is monotonic, so min(x0,x1) is simply the plane picked by the
+    // sign of the direction: select the near / far byte words once per node (6 v_cndmask) instead of 6 min/max per child,
+    // and compute (near, far) of one axis with one packed v_pk_fma_f32.  Bit-identical to the min/max form.
+    const bool px = r.idir.x >= 0.0f, py = r.idir.y >= 0.0f, pz = r.idir.z >= 0.0f;
+    const uint32_t nx = px ? lox : hix, fx = px ? hix : lox, ny = py ? loy : hiy, fy = py ? hiy : loy, nz = pz ? loz : hiz, fz = pz ? hiz : loz;
+    const v2f kx2 = {kx, kx}, ky2 = {ky, ky}, kz2 = {kz, kz}, ax2 = {ax, ax}, ay2 = {ay, ay}, az2 = {az, az};
+    // ordering key: entry distance (>= tmin >= +0, so its sign bit is free) with the child slot in its two low mantissa
+    // bits (ties -> lower slot) and the sign bit set for inner children: one sort puts the leaves first, nearest first,
+    // then the inner children, nearest first, then the misses.  hw_minf / hw_maxf are the one-instruction IEEE minNum / maxNum
+    // (v_min3 / v_max3 fuse them).
 #pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const v2f tx = __builtin_elementwise_fma(v2f{ubyte_f32(nx, c), ubyte_f32(fx, c)}, kx2, ax2);
-    const v2f ty = __builtin_elementwise_fma(v2f{ubyte_f32(ny, c), ubyte_f32(fy, c)}, ky2, ay2);
-    const v2f tz = __builtin_elementwise_fma(v2f{ubyte_f32(nz, c), ubyte_f32(fz, c)}, kz2, az2);
-    const float tn = hw_maxf(hw_maxf(tx.x, ty.x), hw_maxf(tz.x, r.tmin));
-    const float tf = hw_minf(hw_minf(tx.y, ty.y), hw_minf(tz.y, best.t));
-    const bool hit = ref[c] != kAbsent && tn <= tf * 1.0000004f;
-    key[c] = hit ? ((__float_as_uint(tn) & ~3u) | (uint32_t)c | (~ref[c] & kInnerKey)) : kMissKey;
-  }
-  sort2kv(key[0], key[1], ref[0], ref[1]); sort2kv(key[2], key[3], ref[2], ref[3]); sort2kv(key[0], key[2], ref[0], ref[2]);
-  sort2kv(key[1], key[3], ref[1], ref[3]); sort2kv(key[1], key[2], ref[1], ref[2]);
-  // inner children: the nearest is visited next, the others go on the stack farthest first, each with its key so that
-  // a pop can drop entries that a hit found in the meantime has put out of reach
-  uint32_t next = kAbsent, next_key = 0;
-#pragma unroll
-  for (int k = 3; k >= 0; --k) {
-    if (key[k] == kMissKey || !(key[k] & kInnerKey)) continue;
-    if (next != kAbsent) {
-      if (sp < kStackLds) stack[sp * kTraverseThreads] = make_uint2(next_key, next); else spill[sp - kStackLds] = make_uint2(next_key, next);
-      ++sp;
+    for (int c = 0; c < 4; ++c) {
+      const v2f tx = __builtin_elementwise_fma(v2f{ubyte_f32(nx, c), ubyte_f32(fx, c)}, kx2, ax2);
+      const v2f ty = __builtin_elementwise_fma(v2f{ubyte_f32(ny, c), ubyte_f32(fy, c)}, ky2, ay2);
+      const v2f tz = __builtin_elementwise_fma(v2f{ubyte_f32(nz, c), ubyte_f32(fz, c)}, kz2, az2);
+      const float tn = hw_maxf(hw_maxf(tx.x, ty.x), hw_maxf(tz.x, r.tmin));
+      const float tf = hw_minf(hw_minf(tx.y, ty.y), hw_minf(tz.y, best.t));
+      const bool hit = ref[c] != kAbsent && tn <= tf * 1.0000004f;
+      key[c] = hit ? ((__float_as_uint(tn) & ~3u) | (uint32_t)c | (~ref[c] & kInnerKey)) : kMissKey;
     }
-    next = ref[k]; next_key = key[k];
-  }
-  // leaves, nearest first (each one can shrink best.t for the ones after it)
+    sort2kv(key[0], key[1], ref[0], ref[1]); sort2kv(key[2], key[3], ref[2], ref[3]); sort2kv(key[0], key[2], ref[0], ref[2]);
+    sort2kv(key[1], key[3], ref[1], ref[3]); sort2kv(key[1], key[2], ref[1], ref[2]);
+    // inner children: the nearest is visited next, the others go on the stack farthest first, each with its key so that
+    // a pop can drop entries that a hit found in the meantime has put out of reach
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    if (key[k] & kInnerKey) break;  // inner child or miss: no more leaves
-    if (!(key_tn(key[k]) <= best.t)) break;  // sorted: the leaves after it are out of reach too
-    const uint32_t count = ((ref[k] >> 28) & 7u) + 1u;
+    for (int k = 3; k >= 0; --k) {
+      if (key[k] == kMissKey || !(key[k] & kInnerKey)) continue;
+      if (next != kAbsent) {
+        if (sp < kS) stack[sp * kTraverseThreads] = u32x2{next_key, next}; else spill[sp - kS] = make_uint2(next_key, next);
+        ++sp;
+      }
+      next = ref[k]; next_key = key[k];
+    }
+    // the leaves in reach as the node is entered (§4.4b): a sorted prefix; ALL of them are tested, none is culled by a sibling's hit
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (!(key[k] & kInnerKey) && key_tn(key[k]) <= best.t) nl = (uint32_t)k + 1u;
     if (COUNT) {
-      sc.tris += count;
-      const unsigned long long m = __ballot(1);  // the lanes inside this copy of the leaf test
-      sc.leaf_lanes++;
-      if ((uint32_t)__ffsll((long long)m) - 1u == (threadIdx.x & 63u)) sc.leaf_passes++;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) if ((uint32_t)k < nl) sc.tris += ((ref[k] >> 28) & 7u) + 1u;
     }
-    if (leaf_test<ANY, STAGED>(sv, lds, r, t.tmax, best, ref[k] & 0x0fffffffu, count)) return true;
   }
+  bool found = false;  // ANY: an occluder was hit
+  if (STAGED) {
+    if (!has) return false;
+    // LDS-resident scenes: the lane tests its own leaves (4.6 lanes of 64 would be the large-scene figure; here 28-36 are busy and a
+    // triangle pair costs one packed test), nearest first
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if ((uint32_t)k >= nl) break;
+      if (COUNT) {
+        const unsigned long long m = __ballot(1);  // the lanes inside this copy of the leaf test
+        sc.leaf_lanes++;
+        if ((uint32_t)__ffsll((long long)m) - 1u == (threadIdx.x & 63u)) sc.leaf_passes++;
+      }
+      if (leaf_test_staged<ANY>(lds, r, t.tmax, best, ref[k] & 0x0fffffffu, ((ref[k] >> 28) & 7u) + 1u)) { found = true; break; }
+    }
+  } else {
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long b0 = __ballot((nl & 1u) != 0u), b1 = __ballot((nl & 2u) != 0u), b2 = __ballot((nl & 4u) != 0u);
+    if ((b0 | b1 | b2) != 0ull) {  // wave-uniform: some lane reached a leaf in this step
+      const uint32_t pre = mbcnt64(b0) + 2u * mbcnt64(b1) + 4u * mbcnt64(b2);
+      const uint32_t total = (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1) + 4u * (uint32_t)__popcll(b2);  // leaf items of the wave
+      RT_LDS u32x2* items = lds.items;
+      RT_LDS u32x4* slots = lds.slots;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if ((uint32_t)k < nl) items[pre + (uint32_t)k] = u32x2{ref[k], lane};
+      if (nl) slots[lane] = u32x4{best.prim, __float_as_uint(best.t), __float_as_uint(best.u), __float_as_uint(best.v)};
+      // One wave, one instruction stream: its LDS operations execute in program order, so a lane sees what another lane of the wave
+      // wrote by an earlier instruction.  The fences only keep the COMPILER from moving or forwarding LDS accesses across the phases.
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const float4* tris = reinterpret_cast<const float4*>(sv.tris);
+      for (uint32_t base = 0; base < total * (uint32_t)kLeafSlots; base += 64u) {  // one pass unless > 16 leaves were reached at once
+        const uint32_t s = base + lane;
+        const u32x2 it = items[min(s / (uint32_t)kLeafSlots, total - 1u)];
+        const uint32_t leaf = it.x, owner = it.y & 63u;
+        const uint32_t j = s % (uint32_t)kLeafSlots;
+        const bool valid = s / (uint32_t)kLeafSlots < total && j <= ((leaf >> 28) & 7u);
+        // the owner's ray (all lanes take part in the permutes)
+        const uint32_t src = owner << 2;
+        const f3 o = mk3(lane_read(src, r.o.x), lane_read(src, r.o.y), lane_read(src, r.o.z));
+        const f3 d = mk3(lane_read(src, r.d.x), lane_read(src, r.d.y), lane_read(src, r.d.z));
+        const float tmin = lane_read(src, r.tmin);
+        const float tlim = ANY ? lane_read(src, t.tmax) : 0.0f;
+        if (COUNT) {
+          const unsigned long long m = __ballot(valid);
+          if (valid) sc.leaf_lanes++;
+          if (m && (uint32_t)__ffsll((long long)m) - 1u == lane) sc.leaf_passes++;
+        }
+        unsigned long long mine = ~0ull;
+        float tu = 0.0f, tv = 0.0f;
+        RT_LDS unsigned long long* okey = (RT_LDS unsigned long long*)(slots + owner);
+        if (valid) {
+          const float4* p = tris + (size_t)((leaf & 0x0fffffffu) + j) * 3;
+          const float4 a = p[0], b = p[1], c = p[2];
+          asm volatile("" ::"v"(a.w));  // the id travels with v0 (one dwordx4), not as a dependent dword load inside the hit branch
+          float tt;
+          if (tri_test_od(o, d, a, b, c, &tt, &tu, &tv) && tt > tmin) {
+            if (ANY) { if (tt < tlim) *(RT_LDS uint32_t*)okey = 0u; }  // any accepted triangle: the owner's prim field leaves kAbsent
+            else {
+              mine = ((unsigned long long)__float_as_uint(tt) << 32) | (unsigned long long)__float_as_uint(a.w);
+              __hip_atomic_fetch_min(okey, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+          }
+        }
+        if (!ANY) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          // the merge that stands publishes its barycentrics (keys are unique: one triangle, one item)
+          if (mine != ~0ull && *okey == mine) ((RT_LDS u32x2*)okey)[1] = u32x2{__float_as_uint(tu), __float_as_uint(tv)};
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+      if (nl) {
+        const u32x4 w4 = slots[lane];
+        if (ANY) found = w4.x != kAbsent;
+        else { best.prim = w4.x; best.t = __uint_as_float(w4.y); best.u = __uint_as_float(w4.z); best.v = __uint_as_float(w4.w); }
+      }
+    }
+    if (!has) return false;
+  }
+  if (ANY && found) { if (!STAGED) best.prim = 0u; return true; }
   // go on with the nearest inner child if it is still in reach, else with the first stack entry that is
   if (next != kAbsent && !(key_tn(next_key) <= best.t)) next = kAbsent;
   while (next == kAbsent) {
     if (sp == 0) return true;
     --sp;
     uint2 e;
-    if (sp < kStackLds) e = stack[sp * kTraverseThreads]; else e = spill[sp - kStackLds];  // (a ?: of the two address spaces becomes a flat_load)
+    if (sp < kS) { const u32x2 v = stack[sp * kTraverseThreads]; e = make_uint2(v.x, v.y); } else e = spill[sp - kS];
     if (key_tn(e.x) <= best.t) next = e.y;
   }
   t.cur = next;

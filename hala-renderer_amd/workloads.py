@@ -1,6 +1,8 @@
 """The five BASELINE.json configs as (scene, environment, frame) bundles, so that bench.py, the parity tests and the
 profiling scripts all render exactly the same thing.  No assets exist in the container: every scene is
 procedural (`scenes.py`), built as the `cpu::HalaScene` the reference's loader would hand to `set_scene`."""
+import os
+
 from . import scenes
 
 MAX_DEPTH, RR_DEPTH = 5, 3
@@ -19,7 +21,7 @@ _FRAMES = [(512, 512, 1), (1920, 1080, 4), (1920, 1080, 16), (1920, 1080, 4), (3
 def atrium(target_triangles=1_000_000, aspect=16.0 / 9.0, textures=True, texture_size=1024):
     """configs[3]/[4]'s scene + env map (the 18 textures: 6 sets of base colour + normal + metallic-roughness)"""
     s = scenes.sponza_class(target_triangles=target_triangles, aspect=aspect)
-    if textures:
+    if textures and not os.environ.get("HALART_NO_TEXTURES"):  # (experiment knob: what the texture fetches cost)
         scenes.attach_textures(s, sets=6, size=texture_size)
     return s, scenes.sky_sun_envmap(1024, 512, sun_gain=50.0)
 

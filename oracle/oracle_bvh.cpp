@@ -437,15 +437,19 @@ static inline bool traverse4(const Node4* nodes, const Tri* tris, const RayPre& 
       if (next != kAbsent) stack[sp++] = Entry{next_key, next};
       next = e[i].ref; next_key = e[i].key;
     }
-    // leaves, nearest first
+    // leaves (RENDER_SPEC 4.4b): every leaf in reach AS THE NODE IS ENTERED is tested in full and counted — a hit in one does not
+    // cull its siblings (the kernels test them side by side), and an any-hit ray still counts all of them before it stops
+    const float reach = best->t;
+    bool occluded = false;
     for (int i = 0; i < 4 && e[i].key != 0xffffffffu; ++i) {
       uint32_t rf = e[i].ref;
       if (!(rf & 0x80000000u)) continue;
-      if (!(key_tn(e[i].key) <= best->t)) continue;
+      if (!(key_tn(e[i].key) <= reach)) continue;
       uint32_t count = ((rf >> 28) & 7u) + 1u;
       if (c) c->tris += count;
-      if (leaf_test<ANY>(tris, r, tmax, best, rf & 0x0fffffffu, count)) return true;
+      if (!occluded && leaf_test<ANY>(tris, r, tmax, best, rf & 0x0fffffffu, count)) occluded = true;
     }
+    if (occluded) return true;
     if (next != kAbsent && !(key_tn(next_key) <= best->t)) next = kAbsent;
     while (next == kAbsent) {
       if (sp == 0) return best->prim != ORC_NONE;

@@ -1,12 +1,25 @@
 #!/bin/bash
-# Compile-time / env knob sweep on the GPU box (the box has hipcc and rebuilds libhalart.so in ~10 s):
-#   gpurun -- 'bash scripts/variant_sweep.sh "-DRT_WAVES_PER_SIMD_STAGED=5" "-DRT_WORK_SHARDS=32" ...'
-# prints Mrays/s and ms/frame of bench.py (40 steps) for the default build and for each EXTRA flag; the default is rebuilt at the end.
+# Compile-time / env knob sweep on the GPU box (the box has hipcc and rebuilds libhalart.so in ~20 s):
+#   gpurun -- 'bash scripts/variant_sweep.sh "-DRT_STACK_LDS=6" "ENV:HALART_LEAF_MAX=4" ...'
+# prints Mrays/s, ms/frame and the per-kernel split of bench.py (configs[3]) for the default build and for each variant
+# (a compile flag rebuilds the library; "ENV:NAME=VALUE" runs the current build with that environment variable); the default is rebuilt at the end.
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd $ROOT
-run() { timeout -k 10 200 python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline 2>/dev/null | python3 -c "import sys,json; b=json.loads(sys.stdin.read()); print(b['value'], b['ms_per_step'])"; }
-build() { touch hala-renderer_amd/csrc/integrator.hip hala-renderer_amd/csrc/renderer.hip hala-renderer_amd/csrc/bvh_build.hip; make -C hala-renderer_amd/csrc -j8 EXTRA="$1" > gpurun_out/variant_make.log 2>&1 || { echo "build failed: $1"; tail -n 5 gpurun_out/variant_make.log; }; }
+STEPS=${SWEEP_STEPS:-20}
+run() { env $1 timeout -k 10 300 python3 bench.py --steps $STEPS --warmup 3 --no-cpu-baseline --no-secondary 2>/dev/null | python3 -c "
+import sys,json
+b=json.loads(sys.stdin.read()); r=b['roofline']; k=r['ms_per_frame_by_kernel']; s=r['simt']
+print(b['value'], b['ms_per_step'], 'closest', k['closest'], 'shade', k['shade'], 'shadow', k['shadow'], '| nodes/tris per bounce ray', r['nodes_per_ray'], r['tris_per_ray'],
+      '| leaf passes/step @ lanes', s['closest']['leaf_passes_per_wave_step'], s['closest']['leaf_path_lanes_of_64'], s['shadow']['leaf_passes_per_wave_step'], s['shadow']['leaf_path_lanes_of_64'],
+      '| node lanes', s['closest']['node_path_lanes_of_64'], s['shadow']['node_path_lanes_of_64'])"; }
+build() { touch hala-renderer_amd/csrc/integrator.hip hala-renderer_amd/csrc/renderer.hip hala-renderer_amd/csrc/bvh_build.hip; make -C hala-renderer_amd/csrc -j16 EXTRA="$1" > gpurun_out/variant_make.log 2>&1 || { echo "build failed: $1"; tail -n 5 gpurun_out/variant_make.log; }; }
 mkdir -p gpurun_out
-echo "default"; run
-for v in "$@"; do build "$v"; echo "$v"; run; done
-build ""
+echo "default"; run ""
+rebuilt=0
+for v in "$@"; do
+  case "$v" in
+    ENV:*) echo "$v"; run "${v#ENV:}";;
+    *) build "$v"; rebuilt=1; echo "$v"; run "";;
+  esac
+done
+[ $rebuilt = 1 ] && build ""
