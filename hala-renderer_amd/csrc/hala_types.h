@@ -87,7 +87,7 @@ struct SceneView {
   const TexDesc* textures;   // set 2 binding 0, indexed by the material's *_map_index
   const float4* tex_arena;
   uint32_t texture_count;
-  uint32_t pad0;
+  uint32_t shade_sort;  // 1: the scene's materials span several shading kinds — the bounce shade kernel regroups its paths by kind
   const BvhNode4* nodes;
   const Tri* tris;             // BVH order
   const Tri* tris_any;         // what the any-hit launches traverse (RENDER_SPEC 7.1d): == tris unless the scene has opacity-0 materials,

@@ -139,9 +139,14 @@ RT_DI void persistent_trace(const SceneView& sv, const TraverseLds& lds, uint2* 
   // taken if it lies inside the shard, else replaced by the searching dequeue — before anything else is asked for.
   bool pre_out = false;  // wave-uniform: a request is outstanding
   uint32_t pre_raw = 0, pre_shard = 0;
+  // A finished ray keeps its result in the lane until the wave next refills (or ends): the results of all lanes that finished in
+  // between leave in ONE store instruction — whole 1-KB runs for the whole-wave batches of the LDS-staged kernels (64 consecutive
+  // queue entries: full lines for the nontemporal stores) — instead of one divergent store per lane and step.
+  bool fin = false;
   for (;;) {
     const unsigned long long idle = __ballot(!has);
     if (more && idle) {
+      if (fin) { src.done(idx, t, pay); fin = false; }
       uint32_t got = 0, base = kAbsent;
       if (pre_out) {
         const uint32_t v = (uint32_t)__shfl((int)pre_raw, 0);
@@ -174,11 +179,16 @@ RT_DI void persistent_trace(const SceneView& sv, const TraverseLds& lds, uint2* 
     for (;;) {
       if (COUNT && lane_id() == 0u) sc.wave_steps++;  // lane 0 runs every iteration of this wave-uniform loop
       // every lane calls it: the large-scene variant deals the wave's leaf work out over all 64 lanes (traverse.h)
+#ifdef RT_NO_DEFER
       if (trav_step<ANY, COUNT, STAGED>(sv, lds, spill, t, has, sc)) { src.done(idx, t, pay); has = false; }
+#else
+      if (trav_step<ANY, COUNT, STAGED>(sv, lds, spill, t, has, sc)) { fin = true; has = false; }
+#endif
       const uint32_t nidle = (uint32_t)__popcll(__ballot(!has));
       if (nidle == 64u || (more && nidle >= refill)) break;
     }
   }
+  if (fin) src.done(idx, t, pay);
 }
 
 struct BatchSource {
@@ -187,6 +197,10 @@ struct BatchSource {
   hala_hit* hits;
   bool any;
   bool queue;  // the renderer's own bounce-ray queue: tmin = 0, tmax = FLT_MAX, their fields carry path slot and RNG counter
+  // Hit records of whole-wave batches (LDS-staged kernels) leave as full 1-KB runs: nontemporal stores.  Per-lane refills finish
+  // scattered entries at scattered times: ordinary stores, so that L2 puts the 16-B pieces of a line together before it goes to
+  // memory (nontemporal 16-B pieces reached the fabric at 1.8-2.1x their bytes: profiles/r01_m_pmc_config2.txt, r02_a_pmc_config4).
+  bool streaming;
   RT_DI bool load(uint32_t i, f3* o, f3* d, float* tmin, float* tmax, Payload*) const {
     const float4* rp = reinterpret_cast<const float4*>(rays + i);
     const float4 ro = rp[0], rd = rp[1];
@@ -198,7 +212,8 @@ struct BatchSource {
     float4 out;
     if (any) out = make_float4(found ? 1.0f : -1.0f, 0.0f, 0.0f, __uint_as_float(kAbsent));
     else out = found ? make_float4(t.best.t, t.best.u, t.best.v, __uint_as_float(t.best.prim)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(kAbsent));
-    st4(reinterpret_cast<float4*>(hits) + i, out);
+    if (streaming) st4(reinterpret_cast<float4*>(hits) + i, out);
+    else reinterpret_cast<float4*>(hits)[i] = out;
   }
 };
 // The camera ray of path slot `slot` (RENDER_SPEC §5) and the RNG state after it; false for the padding slots of a
@@ -218,6 +233,7 @@ struct CameraSource {
   const FrameConst& fc;
   const SceneView& sv;
   hala_hit* hits;
+  bool streaming;
   RT_DI bool load(uint32_t i, f3* o, f3* d, float* tmin, float* tmax, Payload*) const {
     uint32_t rng;
     *tmin = 0.0f; *tmax = kTMax;
@@ -227,8 +243,9 @@ struct CameraSource {
   }
   RT_DI void done(uint32_t i, const Trav& t, const Payload&) const {
     const bool found = t.best.prim != kAbsent;
-    st4(reinterpret_cast<float4*>(hits) + i, found ? make_float4(t.best.t, t.best.u, t.best.v, __uint_as_float(t.best.prim))
-                                               : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(kAbsent)));
+    const float4 out = found ? make_float4(t.best.t, t.best.u, t.best.v, __uint_as_float(t.best.prim)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(kAbsent));
+    if (streaming) st4(reinterpret_cast<float4*>(hits) + i, out);
+    else reinterpret_cast<float4*>(hits)[i] = out;
   }
 };
 template <bool PREFETCH>
@@ -288,7 +305,7 @@ k_trace_batch(SceneView sv, const hala_ray* __restrict__ rays, hala_hit* __restr
   if (account && blockIdx.x == 0 && threadIdx.x == 0) {
     if (ANY) ctl->rays_shadow += n; else ctl->rays_closest += n;
   }
-  BatchSource src{rays, hits, ANY, account != 0};
+  BatchSource src{rays, hits, ANY, account != 0, STAGED && refill == 64u};
   persistent_trace<ANY, COUNT, STAGED>(sv, lds, spill, work, n, refill, src, sc);
   if (COUNT) flush_counters(ctl, ANY ? 1 : 0, sc);
 }
@@ -303,7 +320,7 @@ k_trace_primary(SceneView sv, FrameConst fc, hala_hit* __restrict__ hits, WorkCo
   uint2* spill = spill_base ? spill_base + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * kStackSpill : nullptr;
   StepCounters sc;
   if (blockIdx.x == 0 && threadIdx.x == 0) ctl->rays_closest += n_account;
-  CameraSource src{fc, sv, hits};
+  CameraSource src{fc, sv, hits, STAGED && refill == 64u};
   persistent_trace<false, COUNT, STAGED>(sv, lds, spill, work, fc.slot_count, refill, src, sc);
   if (COUNT) flush_counters(ctl, 0, sc);
 }
@@ -347,7 +364,8 @@ __global__ void __launch_bounds__(kShadeThreads, RT_SHADE_WAVES) k_shade(FrameCo
   }
   if (blockIdx.x * blockDim.x >= n) return;  // whole workgroup beyond the queue (uniform exit: barriers below)
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (!PRIMARY) {
+#ifndef RT_SHADE_NOSORT
+  if (!PRIMARY && sv.shade_sort) {
     // Bounce paths arrive in no particular order and the BSDF code is a forest of branches (miss / diffuse / Disney / glass /
     // textured ...): a wave ran its VALU instructions at 21 of 64 lanes on the 1 M-triangle scene (profiles/r02_a_pmc_config4.txt).
     // Regroup the workgroup's 512 paths by shading kind first (counting sort through LDS: 9 ballots, one pass): a wave then
@@ -380,6 +398,7 @@ __global__ void __launch_bounds__(kShadeThreads, RT_SHADE_WAVES) k_shade(FrameCo
     __syncthreads();
     i = blockIdx.x * blockDim.x + s_perm[threadIdx.x];
   }
+#endif
   const bool active = i < n;
   const uint32_t in = depth & 1u, out = in ^ 1u;
   bool keep[3] = {false, false, false};  // path survives, light connection, environment connection

@@ -118,6 +118,7 @@ struct hala_rt_renderer {
   DeviceArray<hala_gpu_light> d_lights;
   DeviceArray<hala_gpu_material> d_materials;
   DeviceArray<uint8_t> d_material_kind;
+  bool shade_sort = false;
   DeviceArray<hala_gpu_mesh_data> d_instances;
   DeviceArray<uint32_t> d_inst_first_tri;
   DeviceArray<float4> d_tex_arena;
@@ -134,8 +135,11 @@ struct hala_rt_renderer {
   bool staged = false;  // whole BVH staged in LDS by the traversal kernels
   uint32_t leaf_max_built = 0;
   float ray_eps = 0.0f;
-  DeviceArray<uint2> d_spill;
-  LaunchCfg lcfg{};
+  DeviceArray<uint2> d_spill, d_spill_shadow;
+  LaunchCfg lcfg{}, lcfg_shadow{};  // the shadow launches of bounce d run beside the closest-hit launch of bounce d + 1: own spill area
+  hipStream_t shadow_stream = nullptr;
+  std::vector<hipEvent_t> ev_shaded, ev_shadowed;  // per bounce: shade(d) done (main stream) / shadow passes of d done (shadow stream)
+  bool overlap_shadow = true;
 
   bool has_env = false;
   uint32_t env_w = 0, env_h = 0;
@@ -191,6 +195,9 @@ struct hala_rt_renderer {
       if (t.host_counts) (void)hipHostFree(t.host_counts);
     }
     if (batch_done) (void)hipEventDestroy(batch_done);
+    if (shadow_stream) { (void)hipStreamSynchronize(shadow_stream); (void)hipStreamDestroy(shadow_stream); }
+    for (auto e : ev_shaded) (void)hipEventDestroy(e);
+    for (auto e : ev_shadowed) (void)hipEventDestroy(e);
     // images first, then everything else (src/rt_renderer.rs:620-633)
     for (auto& i : img_local) i.release();
     for (auto& i : img_full) i.release();
@@ -203,7 +210,7 @@ struct hala_rt_renderer {
     sv.nodes = d_nodes.ptr; sv.tris = d_tris.ptr; sv.tris_any = any_invisible ? d_tris_any.ptr : d_tris.ptr; sv.tris_by_id = d_tris_by_id.ptr; sv.shade_tris = d_shade_tris.ptr; sv.tri_instance = d_tri_instance.ptr;
     sv.inst_first_tri = d_inst_first_tri.ptr; sv.primitives = d_instances.ptr; sv.materials = d_materials.ptr; sv.material_kind = d_material_kind.ptr;
     sv.lights = d_lights.ptr; sv.cameras = d_cameras.ptr;
-    sv.textures = d_textures.ptr; sv.tex_arena = d_tex_arena.ptr; sv.texture_count = (uint32_t)host_textures.size();
+    sv.textures = d_textures.ptr; sv.tex_arena = d_tex_arena.ptr; sv.texture_count = (uint32_t)host_textures.size(); sv.shade_sort = shade_sort ? 1u : 0u;
     sv.env_pixels = reinterpret_cast<const float*>(d_env.ptr); sv.env_marginal = d_marginal.ptr; sv.env_conditional = d_conditional.ptr;
     sv.node_count = bvh.node_count; sv.tri_count = bvh.tri_count; sv.lds_nodes = lds_nodes; sv.lds_tris = lds_tris;
     sv.ray_eps = ray_eps;
@@ -381,6 +388,9 @@ int upload_packed(hala_rt_renderer* r, bool geometry = true) {
     std::vector<uint8_t> kind(hs.gpu_materials.size());
     for (size_t i = 0; i < kind.size(); ++i) kind[i] = shade_kind_of(hs.gpu_materials[i], (uint32_t)hs.texture_image.size());
     RT_HIP(r->d_material_kind.upload(kind.data(), kind.size(), r->stream));
+    uint32_t seen = 0;
+    for (uint8_t k : kind) seen |= 1u << k;
+    r->shade_sort = (seen & (seen - 1u)) != 0u;  // two kinds or more (a one-kind scene like the Cornell box only pays for the sort)
   }
   RT_HIP(r->d_instances.upload(hs.instances.data(), hs.instances.size(), r->stream));
   RT_HIP(r->d_inst_first_tri.upload(hs.inst_first_tri.data(), hs.inst_first_tri.size(), r->stream));
@@ -466,8 +476,11 @@ int configure_traversal(hala_rt_renderer* r) {
     if (r->bvh.stack_need > traverse_stack_lds_levels(r->staged) + traverse_stack_spill_levels())
       RT_FAIL("The BVH is deeper than the traversal stack supports (" + std::to_string(r->bvh.max_depth) + " levels, " + std::to_string(r->bvh.stack_need) + " stack entries).");
     RT_HIP(r->d_spill.resize((size_t)r->lcfg.persistent_blocks * 256 * traverse_stack_spill_levels()));
+    RT_HIP(r->d_spill_shadow.resize((size_t)r->lcfg.persistent_blocks * 256 * traverse_stack_spill_levels()));
     r->lcfg.spill = r->d_spill.ptr;
   }
+  r->lcfg_shadow = r->lcfg;
+  if (r->lcfg.spill) r->lcfg_shadow.spill = r->d_spill_shadow.ptr;
   const float ex = r->bvh.scene_max[0] - r->bvh.scene_min[0], ey = r->bvh.scene_max[1] - r->bvh.scene_min[1], ez = r->bvh.scene_max[2] - r->bvh.scene_min[2];
   r->ray_eps = std::sqrt(std::fmaf(ez, ez, std::fmaf(ey, ey, ex * ex))) * 1e-5f;  // RENDER_SPEC §3
   return HALA_OK;
@@ -572,6 +585,8 @@ int hala_rt_create(const char* name, uint32_t width, uint32_t height, int device
   RT_HIP(hipGetDeviceProperties(&prop, device_ordinal));
   r->cu_count = (uint32_t)prop.multiProcessorCount;
   RT_HIP(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
+  RT_HIP(hipStreamCreateWithFlags(&r->shadow_stream, hipStreamNonBlocking));
+  if (const char* ev = getenv("HALART_OVERLAP")) r->overlap_shadow = atoi(ev) != 0;  // A/B knob
   compute_tiling(r.get());
   // create_storage_images (src/rt_renderer.rs:818-917): final, accum, albedo, normal
   if (alloc_frame_buffers(r.get()) != HALA_OK) return HALA_ERR;
@@ -744,6 +759,19 @@ static int update_impl(hala_rt_renderer* r, uint32_t frames) {
   // packet on the stream, i.e. a few microseconds between two launches
   const bool timed = r->launch_event_period == 1u || (r->launch_event_period > 1u && (r->update_counter % r->launch_event_period) == 0u);
   r->update_counter++;
+  // The shadow passes of bounce d only add to the paths' radiance; the closest-hit traversal of bounce d + 1 only reads the ray queue
+  // shade(d) wrote: they run side by side on two streams (a persistent launch ends in a tail of a few long rays — the other launch's
+  // workgroups fill the compute units it vacates), and shade(d + 1) waits for both.  Updates that carry per-launch timing events or
+  // counting kernels stay serial on the main stream, so every measured launch has the chip to itself.
+  const bool overlap = r->overlap_shadow && !timed && !r->counting && (u.num_of_lights > 0 || u.env_type == 1u);
+  hipStream_t ss = overlap ? r->shadow_stream : s;
+  if (overlap) {
+    while (r->ev_shaded.size() < r->max_depth) {
+      hipEvent_t a = nullptr, b = nullptr;
+      RT_HIP(hipEventCreateWithFlags(&a, hipEventDisableTiming)); RT_HIP(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+      r->ev_shaded.push_back(a); r->ev_shadowed.push_back(b);
+    }
+  }
   for (uint32_t depth = 0; depth < r->max_depth; ++depth) {
     if (timed) { hipEvent_t a = r->next_event(te); RT_HIP(hipEventRecord(a, s)); }
     // depth 0: the camera rays are generated inside the traversal kernel, there is no ray-generation pass
@@ -753,13 +781,17 @@ static int update_impl(hala_rt_renderer* r, uint32_t frames) {
     }
     else launch_trace_batch(r->lcfg, sv, q.rays[depth & 1u], q.hits, &ctl->n_active[depth], 0, &ctl->work_closest, ctl, false, r->counting, true, s);
     if (timed) { hipEvent_t b = r->next_event(te); RT_HIP(hipEventRecord(b, s)); }
+    if (overlap && depth > 0) RT_HIP(hipStreamWaitEvent(s, r->ev_shadowed[depth - 1], 0));  // shade(d) re-arms the work counters and adds to radiance
     launch_shade(fc, sv, q, ps, ctl, depth, s);
     if (timed) { hipEvent_t c = r->next_event(te); RT_HIP(hipEventRecord(c, s)); }
+    if (overlap) { RT_HIP(hipEventRecord(r->ev_shaded[depth], s)); RT_HIP(hipStreamWaitEvent(ss, r->ev_shaded[depth], 0)); }
     // light connections first, environment connections second: contributions land in spec order (RENDER_SPEC §6)
-    if (u.num_of_lights > 0) { launch_trace_shadow(r->lcfg, sv, q, ps, ctl, depth, 0, r->counting, s); te.shadow_launches += timed ? 1u : 0u; }
-    if (u.env_type == 1u) { launch_trace_shadow(r->lcfg, sv, q, ps, ctl, depth, 1, r->counting, s); te.shadow_launches += timed ? 1u : 0u; }
+    if (u.num_of_lights > 0) { launch_trace_shadow(r->lcfg_shadow, sv, q, ps, ctl, depth, 0, r->counting, ss); te.shadow_launches += timed ? 1u : 0u; }
+    if (u.env_type == 1u) { launch_trace_shadow(r->lcfg_shadow, sv, q, ps, ctl, depth, 1, r->counting, ss); te.shadow_launches += timed ? 1u : 0u; }
+    if (overlap) RT_HIP(hipEventRecord(r->ev_shadowed[depth], ss));
     if (timed) { hipEvent_t d = r->next_event(te); RT_HIP(hipEventRecord(d, s)); }
   }
+  if (overlap) RT_HIP(hipStreamWaitEvent(s, r->ev_shadowed[r->max_depth - 1], 0));
   launch_resolve(fc, ps, r->img_local[0].ptr, r->img_local[1].ptr, r->img_local[2].ptr, r->img_local[3].ptr, s);
   RT_HIP(hipMemcpyAsync(te.host_counts, &ctl->rays_closest, 14 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
   RT_HIP(hipEventRecord(te.frame_end, s));

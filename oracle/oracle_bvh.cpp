@@ -401,8 +401,10 @@ static inline float hw_maxf(float a, float b) {
 }
 static inline float key_tn(uint32_t key) { return bits_f(key & ~3u); }
 
+constexpr size_t kSmallTreeBytes = 40 * 1024;  // RENDER_SPEC 4.4b: node_count * 64 + triangle_count * 48 <= this -> sequential leaf culling
+static inline bool is_small_tree(size_t node_count, size_t tri_count) { return node_count * 64 + tri_count * 48 <= kSmallTreeBytes; }
 template <bool ANY>
-static inline bool traverse4(const Node4* nodes, const Tri* tris, const RayPre& r, float tmax, Hit* best, Counters* c) {
+static inline bool traverse4(const Node4* nodes, const Tri* tris, bool small_tree, const RayPre& r, float tmax, Hit* best, Counters* c) {
   best->t = tmax; best->prim = ORC_NONE; best->u = 0.0f; best->v = 0.0f;
   struct Entry { uint32_t key, ref; };
   Entry stack[1024]; int sp = 0;
@@ -437,17 +439,20 @@ static inline bool traverse4(const Node4* nodes, const Tri* tris, const RayPre& 
       if (next != kAbsent) stack[sp++] = Entry{next_key, next};
       next = e[i].ref; next_key = e[i].key;
     }
-    // leaves (RENDER_SPEC 4.4b): every leaf in reach AS THE NODE IS ENTERED is tested in full and counted — a hit in one does not
-    // cull its siblings (the kernels test them side by side), and an any-hit ray still counts all of them before it stops
+    // leaves (RENDER_SPEC 4.4b).  Large trees: every leaf in reach AS THE NODE IS ENTERED is tested in full and counted — a hit in one
+    // does not cull its siblings (the kernels test them side by side), and an any-hit ray still counts all of them before it stops.
+    // Small trees (<= 40 KB: the ones the kernels hold in LDS): nearest first, each leaf only while it is still in reach, an any-hit
+    // ray stops at the first accepted triangle.
     const float reach = best->t;
     bool occluded = false;
     for (int i = 0; i < 4 && e[i].key != 0xffffffffu; ++i) {
       uint32_t rf = e[i].ref;
       if (!(rf & 0x80000000u)) continue;
-      if (!(key_tn(e[i].key) <= reach)) continue;
+      if (!(key_tn(e[i].key) <= (small_tree ? best->t : reach))) continue;
       uint32_t count = ((rf >> 28) & 7u) + 1u;
       if (c) c->tris += count;
       if (!occluded && leaf_test<ANY>(tris, r, tmax, best, rf & 0x0fffffffu, count)) occluded = true;
+      if (occluded && small_tree) return true;
     }
     if (occluded) return true;
     if (next != kAbsent && !(key_tn(next_key) <= best->t)) next = kAbsent;
@@ -475,7 +480,7 @@ Hit scene_trace_closest(const orc_scene* s, V3 o, V3 d, float tmin, float tmax, 
   if (s->ext_nodes.empty()) return trace_closest(s->nodes.data(), s->tris.data(), o, d, tmin, tmax, c);
   RayPre r = make_ray(o, d, tmin);
   Hit h;
-  if (!traverse4<false>(s->ext_nodes.data(), s->ext_tris.data(), r, tmax, &h, c)) { h.t = -1.0f; h.u = 0.0f; h.v = 0.0f; h.prim = ORC_NONE; }
+  if (!traverse4<false>(s->ext_nodes.data(), s->ext_tris.data(), is_small_tree(s->ext_nodes.size(), s->ext_tris.size()), r, tmax, &h, c)) { h.t = -1.0f; h.u = 0.0f; h.v = 0.0f; h.prim = ORC_NONE; }
   return h;
 }
 // RENDER_SPEC 7.1d: shadow rays do not see surfaces of opacity exactly 0
@@ -496,7 +501,7 @@ bool scene_trace_any(const orc_scene* s, V3 o, V3 d, float tmin, float tmax, Cou
   if (s->ext_nodes.empty()) return trace_any(s->nodes.data(), (s->tris_any.empty() ? s->tris : s->tris_any).data(), o, d, tmin, tmax, c);
   RayPre r = make_ray(o, d, tmin);
   Hit h;
-  return traverse4<true>(s->ext_nodes.data(), (s->ext_tris_any.empty() ? s->ext_tris : s->ext_tris_any).data(), r, tmax, &h, c);
+  return traverse4<true>(s->ext_nodes.data(), (s->ext_tris_any.empty() ? s->ext_tris : s->ext_tris_any).data(), is_small_tree(s->ext_nodes.size(), s->ext_tris.size()), r, tmax, &h, c);
 }
 }  // namespace orc
 
@@ -531,10 +536,11 @@ static void trace_batch(const Node* nodes, const Tri* tris, const orc_ray* rays,
 extern "C" void orc_trace_rays(const orc_scene* s, const orc_ray* rays, orc_hit* hits, uint32_t count, int mode, uint64_t* counters) {
   trace_batch(s->nodes.data(), (mode == 1 && !s->tris_any.empty() ? s->tris_any : s->tris).data(), rays, hits, count, mode, counters);
 }
-extern "C" void orc_trace_rays_on_bvh4(const void* nodes64, uint32_t, const void* tris48, uint32_t, const orc_ray* rays,
+extern "C" void orc_trace_rays_on_bvh4(const void* nodes64, uint32_t node_count, const void* tris48, uint32_t tri_count, const orc_ray* rays,
                                        orc_hit* hits, uint32_t count, int mode, uint64_t* counters) {
   const Node4* nodes = (const Node4*)nodes64;
   const Tri* tris = (const Tri*)tris48;
+  const bool small_tree = orc::is_small_tree(node_count, tri_count);
   uint64_t cn = 0, ct = 0;
 #pragma omp parallel for schedule(dynamic, 4096) reduction(+ : cn, ct)
   for (int64_t i = 0; i < (int64_t)count; ++i) {
@@ -543,10 +549,10 @@ extern "C" void orc_trace_rays_on_bvh4(const void* nodes64, uint32_t, const void
     RayPre r = make_ray(v3(ry.origin[0], ry.origin[1], ry.origin[2]), v3(ry.direction[0], ry.direction[1], ry.direction[2]), ry.tmin);
     Hit h;
     if (mode == 0) {
-      if (traverse4<false>(nodes, tris, r, ry.tmax, &h, &c)) hits[i] = orc_hit{h.t, h.u, h.v, h.prim};
+      if (traverse4<false>(nodes, tris, small_tree, r, ry.tmax, &h, &c)) hits[i] = orc_hit{h.t, h.u, h.v, h.prim};
       else hits[i] = orc_hit{-1.0f, 0.0f, 0.0f, ORC_NONE};
     } else {
-      hits[i] = orc_hit{traverse4<true>(nodes, tris, r, ry.tmax, &h, &c) ? 1.0f : -1.0f, 0.0f, 0.0f, ORC_NONE};
+      hits[i] = orc_hit{traverse4<true>(nodes, tris, small_tree, r, ry.tmax, &h, &c) ? 1.0f : -1.0f, 0.0f, 0.0f, ORC_NONE};
     }
     cn += c.nodes; ct += c.tris;
   }

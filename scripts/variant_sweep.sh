@@ -6,12 +6,15 @@
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd $ROOT
 STEPS=${SWEEP_STEPS:-20}
-run() { env $1 timeout -k 10 300 python3 bench.py --steps $STEPS --warmup 3 --no-cpu-baseline --no-secondary 2>/dev/null | python3 -c "
+SEC=${SWEEP_SECONDARY:---no-secondary}
+run() { env $1 timeout -k 10 300 python3 bench.py --steps $STEPS --warmup 3 --no-cpu-baseline $SEC 2>/dev/null | python3 -c "
 import sys,json
 b=json.loads(sys.stdin.read()); r=b['roofline']; k=r['ms_per_frame_by_kernel']; s=r['simt']
 print(b['value'], b['ms_per_step'], 'closest', k['closest'], 'shade', k['shade'], 'shadow', k['shadow'], '| nodes/tris per bounce ray', r['nodes_per_ray'], r['tris_per_ray'],
       '| leaf passes/step @ lanes', s['closest']['leaf_passes_per_wave_step'], s['closest']['leaf_path_lanes_of_64'], s['shadow']['leaf_passes_per_wave_step'], s['shadow']['leaf_path_lanes_of_64'],
-      '| node lanes', s['closest']['node_path_lanes_of_64'], s['shadow']['node_path_lanes_of_64'])"; }
+      '| node lanes', s['closest']['node_path_lanes_of_64'], s['shadow']['node_path_lanes_of_64'])
+c=b.get('secondary',{}).get('configs1')
+if c: print('   cornell', c['value'], c['ms_per_frame'], 'batch', c['batch_kernel']['avg_launch_ms'], 'shadow', c['shadow_kernel']['avg_launch_ms'], 'shade', c['shade_kernel']['avg_launch_ms'], '| 4K on 1 GPU', b['secondary']['configs4_on_1_gpu']['ms_per_frame'])"; }
 build() { touch hala-renderer_amd/csrc/integrator.hip hala-renderer_amd/csrc/renderer.hip hala-renderer_amd/csrc/bvh_build.hip; make -C hala-renderer_amd/csrc -j16 EXTRA="$1" > gpurun_out/variant_make.log 2>&1 || { echo "build failed: $1"; tail -n 5 gpurun_out/variant_make.log; }; }
 mkdir -p gpurun_out
 echo "default"; run ""
