@@ -195,4 +195,8 @@ EXPORTS = [
     "hala_rt_update_node_transform", "hala_rt_update_vertices", "hala_rt_update_material", "hala_rt_refit", "hala_envmap_build_distribution",
     "hala_tonemap_pixels", "hala_write_pfm", "hala_rtprog_parse_desc", "hala_version",
     "hala_scene_load_gltf", "hala_scene_get_desc", "hala_scene_free", "hala_load_float_image",
+    "hala_rtprog_create", "hala_rtprog_destroy", "hala_rtprog_get_desc_info", "hala_rtprog_bind", "hala_rtprog_push_constants",
+    "hala_rtprog_push_constants_f32", "hala_rtprog_trace_rays", "hala_rtprog_trace_rays_indirect",
+    "hala_rt_comm_unique_id", "hala_rt_comm_init_rank", "hala_rt_comm_attach", "hala_rt_comm_destroy",
+    "hala_rt_tile_allgather", "hala_rt_tile_allgather_begin", "hala_rt_tile_allgather_finish", "hala_rt_get_gathered_buffer",
 ]

@@ -3,6 +3,7 @@
 // wavefront kernel sequence of integrator.hip, timestamp queries become HIP events, staging buffers become
 // hipMemcpyAsync from the caller's memory.  Everything that computes runs on the GPU; this file only orchestrates.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <cmath>
@@ -180,6 +181,14 @@ struct hala_rt_renderer {
   hipEvent_t scratch_event = nullptr;       // not owned: a ring slot's frame_end or batch_done
   hipStream_t scratch_stream = nullptr;
   hipEvent_t batch_done = nullptr;
+  // multi-GPU exchange (C1 of SURVEY 2.1): one RCCL all-gather of the rank's tile buffer per AOV and frame, inside the library
+  ncclComm_t comm = nullptr;
+  bool comm_owned = false;
+  int comm_rank = 0, comm_world = 1;
+  hipStream_t gather_stream = nullptr;
+  DeviceArray<float4> gather_stage[4], gather_recv[4];
+  hipEvent_t ev_rendered = nullptr, ev_staged = nullptr, ev_gathered = nullptr;
+  uint32_t gather_pending = 0;  // AOV mask of the collective in flight (hala_rt_tile_allgather_begin)
   int scratch_acquire(hipStream_t s) {
     if (scratch_event && scratch_stream != s) RT_HIP(hipStreamWaitEvent(s, scratch_event, 0));
     return HALA_OK;
@@ -195,6 +204,9 @@ struct hala_rt_renderer {
       if (t.host_counts) (void)hipHostFree(t.host_counts);
     }
     if (batch_done) (void)hipEventDestroy(batch_done);
+    if (gather_stream) { (void)hipStreamSynchronize(gather_stream); (void)hipStreamDestroy(gather_stream); }
+    for (hipEvent_t e : {ev_rendered, ev_staged, ev_gathered}) if (e) (void)hipEventDestroy(e);
+    if (comm && comm_owned) (void)ncclCommDestroy(comm);
     if (shadow_stream) { (void)hipStreamSynchronize(shadow_stream); (void)hipStreamDestroy(shadow_stream); }
     for (auto e : ev_shaded) (void)hipEventDestroy(e);
     for (auto e : ev_shadowed) (void)hipEventDestroy(e);
@@ -1015,6 +1027,120 @@ int hala_rt_scatter_gathered_tiles(hala_rt_renderer* r, int which, const void* d
   return hala_rt_scatter_gathered_tiles_on_stream(r, which, d_gathered, bytes, nullptr);
 }
 
+
+// ---- RCCL tile all-gather (BASELINE.json north_star: "RCCL all-gather of tiles over xGMI") -----------------------------------------
+#define RT_NCCL(expr)                                                                                         \
+  do {                                                                                                        \
+    const ncclResult_t _r = (expr);                                                                           \
+    if (_r != ncclSuccess) RT_FAIL(std::string("RCCL: ") + ncclGetErrorString(_r) + " (" #expr ")");         \
+  } while (0)
+
+int hala_rt_comm_unique_id(void* out_128_bytes) {
+  if (!out_128_bytes) RT_FAIL("Invalid argument.");
+  static_assert(sizeof(ncclUniqueId) == HALA_COMM_UNIQUE_ID_BYTES, "ncclUniqueId is 128 bytes");
+  ncclUniqueId id;
+  RT_NCCL(ncclGetUniqueId(&id));
+  memcpy(out_128_bytes, &id, sizeof(id));
+  return HALA_OK;
+}
+static int comm_common(hala_rt_renderer* r, int rank, int world) {
+  if ((uint32_t)world != r->world || (uint32_t)rank != r->rank)
+    RT_FAIL("The communicator's rank / size (" + std::to_string(rank) + " / " + std::to_string(world) + ") differ from the renderer's tile shard (" +
+            std::to_string(r->rank) + " / " + std::to_string(r->world) + "): call hala_rt_set_tile_shard first.");
+  r->comm_rank = rank; r->comm_world = world;
+  if (!r->gather_stream) RT_HIP(hipStreamCreateWithFlags(&r->gather_stream, hipStreamNonBlocking));
+  for (hipEvent_t* e : {&r->ev_rendered, &r->ev_staged, &r->ev_gathered}) if (!*e) RT_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+  return HALA_OK;
+}
+int hala_rt_comm_init_rank(hala_rt_renderer* r, const void* unique_id_128_bytes, uint32_t rank, uint32_t world) {
+  if (ensure_device(r) != HALA_OK) return HALA_ERR;
+  if (!unique_id_128_bytes || world == 0 || rank >= world) RT_FAIL("Invalid argument.");
+  if (r->comm) RT_FAIL("The renderer already has a communicator.");
+  if (comm_common(r, (int)rank, (int)world) != HALA_OK) return HALA_ERR;
+  ncclUniqueId id;
+  memcpy(&id, unique_id_128_bytes, sizeof(id));
+  RT_NCCL(ncclCommInitRank(&r->comm, (int)world, id, (int)rank));
+  r->comm_owned = true;
+  return HALA_OK;
+}
+int hala_rt_comm_attach(hala_rt_renderer* r, void* nccl_comm) {
+  if (ensure_device(r) != HALA_OK) return HALA_ERR;
+  if (!nccl_comm) RT_FAIL("Invalid argument.");
+  if (r->comm) RT_FAIL("The renderer already has a communicator.");
+  int rank = 0, world = 0;
+  RT_NCCL(ncclCommUserRank(static_cast<ncclComm_t>(nccl_comm), &rank));
+  RT_NCCL(ncclCommCount(static_cast<ncclComm_t>(nccl_comm), &world));
+  if (comm_common(r, rank, world) != HALA_OK) return HALA_ERR;
+  r->comm = static_cast<ncclComm_t>(nccl_comm);
+  r->comm_owned = false;
+  return HALA_OK;
+}
+int hala_rt_comm_destroy(hala_rt_renderer* r) {
+  if (ensure_device(r) != HALA_OK) return HALA_ERR;
+  if (r->gather_stream) RT_HIP(hipStreamSynchronize(r->gather_stream));
+  if (r->comm && r->comm_owned) RT_NCCL(ncclCommDestroy(r->comm));
+  r->comm = nullptr; r->comm_owned = false; r->gather_pending = 0;
+  return HALA_OK;
+}
+
+// finish(k - 1) -> [side stream waits for the renderer's stream: frame k is complete] -> staging <- tiles -> [renderer's stream waits
+// for that copy: frame k + 1 may overwrite the tiles] -> ncclAllGather(receive <- staging) on the side stream.  Nothing blocks the host.
+int hala_rt_tile_allgather_begin(hala_rt_renderer* r, uint32_t aov_mask) {
+  if (ensure_device(r) != HALA_OK) return HALA_ERR;
+  if (!r->comm) RT_FAIL("The renderer has no communicator: call hala_rt_comm_init_rank or hala_rt_comm_attach first.");
+  if (aov_mask == 0u || aov_mask > 15u) RT_FAIL("Invalid AOV mask.");
+  if (hala_rt_tile_allgather_finish(r) != HALA_OK) return HALA_ERR;
+  const size_t n = r->slot_count;
+  hipStream_t g = r->gather_stream;
+  RT_HIP(hipEventRecord(r->ev_rendered, r->stream));
+  RT_HIP(hipStreamWaitEvent(g, r->ev_rendered, 0));
+  for (int which = 0; which < 4; ++which) {
+    if (!(aov_mask & (1u << which))) continue;
+    RT_HIP(r->gather_stage[which].resize(n));
+    RT_HIP(r->gather_recv[which].resize(n * (size_t)r->comm_world));
+    RT_HIP(hipMemcpyAsync(r->gather_stage[which].ptr, r->img_local[which].ptr, n * sizeof(float4), hipMemcpyDeviceToDevice, g));
+  }
+  RT_HIP(hipEventRecord(r->ev_staged, g));
+  RT_HIP(hipStreamWaitEvent(r->stream, r->ev_staged, 0));
+  for (int which = 0; which < 4; ++which)
+    if (aov_mask & (1u << which))
+      RT_NCCL(ncclAllGather(r->gather_stage[which].ptr, r->gather_recv[which].ptr, n * 4, ncclFloat, r->comm, g));
+  r->gather_pending = aov_mask;
+  return HALA_OK;
+}
+// de-interleave on the side stream (beside the rendering of the next frame), then whatever the renderer's stream does next — and
+// whoever waits for it — sees the row-major images complete
+int hala_rt_tile_allgather_finish(hala_rt_renderer* r) {
+  if (ensure_device(r) != HALA_OK) return HALA_ERR;
+  if (!r->gather_pending) return HALA_OK;
+  const uint32_t mask = r->gather_pending;
+  r->gather_pending = 0;
+  hipStream_t g = r->gather_stream;
+  if (r->world > 1) {
+    const FrameConst fc = r->frame_const(r->last_uniform);
+    for (int which = 0; which < 4; ++which) {
+      if (!(mask & (1u << which))) continue;
+      RT_HIP(r->img_full[which].resize((size_t)r->width * r->height));
+      launch_scatter_tiles(fc, r->gather_recv[which].ptr, r->img_full[which].ptr, g);
+      r->full_valid[which] = true;
+    }
+  }
+  RT_HIP(hipEventRecord(r->ev_gathered, g));
+  RT_HIP(hipStreamWaitEvent(r->stream, r->ev_gathered, 0));
+  RT_HIP(hipGetLastError());
+  return HALA_OK;
+}
+int hala_rt_tile_allgather(hala_rt_renderer* r, uint32_t aov_mask) {
+  if (hala_rt_tile_allgather_begin(r, aov_mask) != HALA_OK) return HALA_ERR;
+  return hala_rt_tile_allgather_finish(r);
+}
+int hala_rt_get_gathered_buffer(hala_rt_renderer* r, int which, void** d_ptr, size_t* bytes) {
+  if (!r || which < 0 || which > 3 || !d_ptr || !bytes) RT_FAIL("Invalid argument.");
+  *d_ptr = r->gather_recv[which].ptr;
+  *bytes = r->gather_recv[which].bytes();
+  return HALA_OK;
+}
+
 // ---- ray-batch operator ------------------------------------------------------------------------------------------------
 int hala_rt_trace_rays(hala_rt_renderer* r, const hala_ray* d_rays, hala_hit* d_hits, uint32_t count, int mode, uint64_t* d_counters, void* hip_stream) {
   if (ensure_device(r) != HALA_OK) return HALA_ERR;
@@ -1219,6 +1345,76 @@ int hala_rtprog_parse_desc(const char* desc_json, hala_rtprog_desc_info* out) {
   if (u32_field("push_constant_size", 0, &out->push_constant_size) != HALA_OK) return HALA_ERR;
   if (u32_field("ray_recursion_depth", 1, &out->ray_recursion_depth) != HALA_OK) return HALA_ERR;  // default_ray_recursion_depth :53-55
   return HALA_OK;
+}
+
+
+// ---- HalaRayTracingProgram (src/raytracing_program.rs:70-341) as an object of the C ABI -------------------------------------------------
+// Reference: {shader groups, pipeline, SBT}; bind() attaches descriptor sets, push_constants() writes the constant block, trace_rays(w, h, d)
+// launches w*h*d ray-gen invocations against the acceleration structure the descriptor sets name.  Here the shader groups are the library's
+// traversal kernels (the SPIR-V paths of the description are recorded, as hala_rt_push_*_shader does), the "descriptor sets" are the device
+// buffers of one ray batch, and the acceleration structure is the committed renderer's.  Bytes 0..3 of the constant block select the
+// hit-group behaviour: 0 = closest hit, 1 = any hit.
+struct hala_rtprog {
+  hala_rt_renderer* renderer = nullptr;
+  hala_rtprog_desc_info info{};
+  std::string debug_name;
+  std::vector<uint8_t> constants;
+  const hala_ray* d_rays = nullptr;
+  hala_hit* d_hits = nullptr;
+};
+
+int hala_rtprog_create(hala_rt_renderer* r, const char* desc_json, const char* debug_name, hala_rtprog** out) {
+  if (!out) RT_FAIL("The output handle is null!");
+  *out = nullptr;
+  if (!r) RT_FAIL("The renderer handle is null!");
+  hala_rtprog_desc_info info;
+  if (hala_rtprog_parse_desc(desc_json, &info) != HALA_OK) return HALA_ERR;
+  if (info.raygen_count == 0) RT_FAIL("The raygen shader list is empty!");  // a pipeline without a ray generation group cannot be built (:85-106)
+  if (info.push_constant_size % 4u != 0u) RT_FAIL("push_constant_size must be a multiple of 4.");  // VkPushConstantRange.size
+  std::unique_ptr<hala_rtprog> p(new hala_rtprog());
+  p->renderer = r; p->info = info; p->debug_name = debug_name ? debug_name : "";
+  p->constants.assign(std::max<uint32_t>(info.push_constant_size, 4u), 0);
+  *out = p.release();
+  return HALA_OK;
+}
+void hala_rtprog_destroy(hala_rtprog* p) { delete p; }
+int hala_rtprog_get_desc_info(const hala_rtprog* p, hala_rtprog_desc_info* out) {
+  if (!p || !out) RT_FAIL("Invalid argument.");
+  *out = p->info;
+  return HALA_OK;
+}
+int hala_rtprog_bind(hala_rtprog* p, const hala_ray* d_rays, hala_hit* d_hits) {  // :264-278
+  if (!p) RT_FAIL("The program handle is null!");
+  if (!d_rays || !d_hits) RT_FAIL("The ray batch is null!");
+  p->d_rays = d_rays; p->d_hits = d_hits;
+  return HALA_OK;
+}
+int hala_rtprog_push_constants(hala_rtprog* p, uint32_t offset, const void* data, size_t len) {  // :285-300
+  if (!p) RT_FAIL("The program handle is null!");
+  if (!data && len) RT_FAIL("Invalid argument.");
+  if ((size_t)offset + len > p->constants.size()) RT_FAIL("The push constant range exceeds push_constant_size.");
+  if (len) memcpy(p->constants.data() + offset, data, len);
+  return HALA_OK;
+}
+int hala_rtprog_push_constants_f32(hala_rtprog* p, uint32_t offset, const float* data, size_t count) {  // :307-322
+  return hala_rtprog_push_constants(p, offset, data, count * sizeof(float));
+}
+static int rtprog_mode(const hala_rtprog* p) {
+  uint32_t m = 0;
+  memcpy(&m, p->constants.data(), 4);
+  return (int)(m & 1u);
+}
+int hala_rtprog_trace_rays(hala_rtprog* p, uint32_t width, uint32_t height, uint32_t depth, void* hip_stream) {  // :330-332
+  if (!p) RT_FAIL("The program handle is null!");
+  if (!p->d_rays || !p->d_hits) RT_FAIL("The program is not bound to a ray batch.");
+  const uint64_t n = (uint64_t)width * height * depth;
+  if (n > 0xffffffffull) RT_FAIL("The launch is too large.");
+  return hala_rt_trace_rays(p->renderer, p->d_rays, p->d_hits, (uint32_t)n, rtprog_mode(p), nullptr, hip_stream);
+}
+int hala_rtprog_trace_rays_indirect(hala_rtprog* p, const uint32_t* d_indirect, void* hip_stream) {  // :338-340
+  if (!p) RT_FAIL("The program handle is null!");
+  if (!p->d_rays || !p->d_hits) RT_FAIL("The program is not bound to a ray batch.");
+  return hala_rt_trace_rays_indirect(p->renderer, p->d_rays, p->d_hits, d_indirect, rtprog_mode(p), hip_stream);
 }
 
 }  // extern "C"

@@ -69,29 +69,45 @@ class TileLayout:
 
 
 class _DeviceView:
-    """zero-copy torch view of a device allocation owned by libhalart.so"""
+    """zero-copy torch view of a device allocation owned by libhalart.so (gloo rehearsal only)"""
 
     def __init__(self, ptr, nfloats):
         self.__cuda_array_interface__ = {"shape": (nfloats,), "typestr": "<f4", "data": (ptr, False), "version": 2}
 
 
 class TileGather:
-    """RCCL all-gather of a sharded renderer's AOVs + de-interleave on every rank.
+    """All-gather of a sharded renderer's AOVs + de-interleave on every rank.
 
-    Usage (one process per GPU, torch.distributed initialised with backend "nccl" == RCCL):
+    The exchange itself lives in libhalart.so (`hala_rt_tile_allgather*`: RCCL on a side stream, stream-ordered against the
+    renderer's stream, nothing blocks the host); this class only sets the communicator up.  `torch.distributed` is used for ONE
+    thing: handing rank 0's 128-byte ncclUniqueId to the other ranks (any host channel would do — a C / Rust host uses its own).
+
+    Usage (one process per GPU, torch.distributed initialised):
         r.set_tile_shard(rank, world, 32); r.set_scene(...); r.commit()
         g = TileGather(r, device_index)
         for _ in range(spp): r.update()
         g.gather()            # accum, albedo, normal are now complete row-major images on every rank
+    or pipelined, one frame deep: g.begin() after frame k's updates, g.finish() before the images of frame k are read.
+
+    backend "gloo" (CPU collectives; several ranks rehearsed on ONE GPU, which RCCL refuses): the same buffers travel through
+    torch.distributed.all_gather on the host instead, and only the de-interleave runs in the library.
     """
 
     def __init__(self, renderer, device_index, aovs=(0, 1, 2), group=None):
         import torch
         import torch.distributed as dist
-        self.r, self.dist, self.group, self.torch = renderer, dist, group, torch
+        self.r, self.dist, self.group, self.torch, self.aovs = renderer, dist, group, torch, tuple(aovs)
         self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self._gloo = dist.get_backend(group) == "gloo"
+        self._pending = False
+        if not self._gloo:
+            ident = [renderer.comm_unique_id() if self.rank == 0 else None]
+            dist.broadcast_object_list(ident, src=0, group=group)
+            renderer.comm_init_rank(ident[0], self.rank, self.world)
+            return
         self.bufs = []
-        for which in aovs:
+        for which in self.aovs:
             ptr, nbytes = renderer.tile_buffer(which)
             src = torch.as_tensor(_DeviceView(ptr, nbytes // 4), device=f"cuda:{device_index}")
             if src.data_ptr() != ptr:
@@ -99,74 +115,34 @@ class TileGather:
             dst = torch.empty(self.world * (nbytes // 4), dtype=torch.float32, device=f"cuda:{device_index}")
             self.bufs.append((which, src, dst, nbytes))
 
-    # ---- pipelined form: the all-gather of frame k runs while frame k + 1 is rendered -------------------------------
-    # xGMI is point-to-point: a ring all-gather of N x 33 MB (1080p RGBA32F per rank) is bound by ONE link per hop, i.e.
-    # it can take as long as rendering the frame.  begin() snapshots the rank's tile buffer (the next frame overwrites
-    # it) and starts the collective on a side stream; finish() — called by the next begin(), or explicitly — makes the
-    # renderer's stream wait for it and de-interleaves.  Every frame is still gathered and de-interleaved in full.
-    # With RCCL nothing here blocks the host: the hand-overs are stream dependencies between the renderer's HIP stream R
-    # (hala_rt_get_stream) and the side stream S,
-    #   finish(k-1): S waits for the collective; S: de-interleave(k-1), beside frame k on R; R's later work waits for S
-    #   begin(k):    S waits for R (frame k rendered, receive buffer read out); S: staging <- tiles; R waits for that copy
-    #                (frame k+1 may overwrite the tiles); S: all-gather(receive <- staging)
-    # so the host can keep enqueueing frames (hala_rt_render bounds them to two in flight).  gloo (CPU collectives; the
-    # 1-GPU rehearsal) synchronises instead.
-    def _streams(self):
-        torch = self.torch
-        if not hasattr(self, "_side"):
-            self._side = torch.cuda.Stream()
-            self._stage = [torch.empty_like(src) for _, src, _, _ in self.bufs]
-            self._rstream = torch.cuda.ExternalStream(self.r.stream_handle())
-            self._gloo = self.dist.get_backend(self.group) == "gloo"
-        return self._side, self._rstream
-
     def begin(self):
-        torch = self.torch
-        side, rstream = self._streams()
-        self.finish()  # frame k - 1 must have left the staging / receive buffers
-        if self._gloo:
-            self.r.wait_idle()
-        side.wait_stream(rstream)  # frame k is complete in the rank's tile buffer, de-interleave k - 1 has read the receive buffer
-        self._works = []
-        with torch.cuda.stream(side):
-            for (_, src, dst, _), stage in zip(self.bufs, self._stage):
-                stage.copy_(src, non_blocking=True)
-            copied = torch.cuda.Event()
-            copied.record(side)
-            rstream.wait_event(copied)  # the next frame overwrites the tile buffer
-            for (_, src, dst, _), stage in zip(self.bufs, self._stage):
-                if self._gloo:
-                    side.synchronize()
-                    self._works.append(self.dist.all_gather(list(dst.view(self.world, -1).unbind(0)), stage, group=self.group, async_op=True))
-                else:
-                    self._works.append(self.dist.all_gather_into_tensor(dst, stage, group=self.group, async_op=True))
+        if not self._gloo:
+            self.r.tile_allgather_begin(self.aovs)
+            return
+        self.finish()
+        self.r.wait_idle()
+        self._stage = [src.clone() for _, src, _, _ in self.bufs]  # the next frame overwrites the tile buffer
+        self.torch.cuda.synchronize()
         self._pending = True
 
     def finish(self):
-        if not getattr(self, "_pending", False):
+        if not self._gloo:
+            self.r.tile_allgather_finish()
             return
-        side, rstream = self._streams()
-        with self.torch.cuda.stream(side):
-            for w in self._works:
-                w.wait()  # RCCL: the side stream waits for the collective; gloo: the host does
-        if self._gloo:
-            side.synchronize()
+        if not self._pending:
+            return
         self._pending = False
+        for (which, _, dst, nbytes), stage in zip(self.bufs, self._stage):
+            self.dist.all_gather(list(dst.view(self.world, -1).unbind(0)), stage, group=self.group)
+        self.torch.cuda.synchronize()
         if self.world > 1:
-            for which, _, dst, nbytes in self.bufs:  # on the side stream: the de-interleave of frame k runs beside the rendering of k + 1
-                self.r.scatter_gathered_tiles(which, dst.data_ptr(), nbytes * self.world, stream=side.cuda_stream)
-        rstream.wait_stream(side)  # whatever the renderer's stream does next (and whoever waits for it) sees the images complete
+            for which, _, dst, nbytes in self.bufs:
+                self.r.scatter_gathered_tiles(which, dst.data_ptr(), nbytes * self.world)
 
     def gather(self):
+        self.begin()
         self.finish()
-        self.r.wait_idle()  # the renderer works on its own HIP stream
-        for _, src, dst, _ in self.bufs:
-            if self.dist.get_backend(self.group) == "gloo":  # rehearsal on a 1-GPU box; same buffer layout
-                self.dist.all_gather(list(dst.view(self.world, -1).unbind(0)), src, group=self.group)
-            else:
-                self.dist.all_gather_into_tensor(dst, src, group=self.group)
-        self.torch.cuda.synchronize()
-        if self.world == 1:
-            return  # an unsharded frame is already row-major
-        for which, _, dst, nbytes in self.bufs:
-            self.r.scatter_gathered_tiles(which, dst.data_ptr(), nbytes * self.world)
+
+    def close(self):
+        if not self._gloo:
+            self.r.comm_destroy()

@@ -32,6 +32,15 @@ class HalaRayTracingProgramDesc:
     bindings: List[str] = field(default_factory=list)
     ray_recursion_depth: int = 1
 
+    def to_json(self) -> str:
+        """the serde form (:33-47)"""
+        return json.dumps({
+            "raygen_shader_file_paths": self.raygen_shader_file_paths, "miss_shader_file_paths": self.miss_shader_file_paths,
+            "hit_shader_file_paths": [{"closest_hit_shader_file_path": h.closest_hit_shader_file_path, "any_hit_shader_file_path": h.any_hit_shader_file_path,
+                                       "intersection_shader_file_path": h.intersection_shader_file_path} for h in self.hit_shader_file_paths],
+            "callable_shader_file_paths": self.callable_shader_file_paths, "push_constant_size": self.push_constant_size,
+            "bindings": self.bindings, "ray_recursion_depth": self.ray_recursion_depth})
+
     @staticmethod
     def from_json(text: str) -> "HalaRayTracingProgramDesc":
         """Parses with the library's parser (hala_rtprog_parse_desc) for validation — required keys are
@@ -54,21 +63,33 @@ class HalaRayTracingProgramDesc:
 
 
 class HalaRayTracingProgram:
-    """src/raytracing_program.rs:70-341"""
+    """src/raytracing_program.rs:70-341 — a thin ctypes twin of the library's `hala_rtprog_*` object (include/halart.h)"""
 
     CLOSEST_HIT, ANY_HIT = 0, 1
 
-    def __init__(self, renderer, desc: HalaRayTracingProgramDesc, debug_name: str = ""):
-        """HalaRayTracingProgram::new (:85-252): `renderer` supplies the device and acceleration structure
-        (logical_device + descriptor_set_layouts in the reference)."""
-        from . import HalaRendererError
-        if not desc.raygen_shader_file_paths:
-            raise HalaRendererError("The raygen shader list is empty!")
+    def __init__(self, renderer, desc, debug_name: str = ""):
+        """HalaRayTracingProgram::new (:85-252): `renderer` supplies the device and acceleration structure (logical_device +
+        descriptor_set_layouts in the reference); `desc` is a HalaRayTracingProgramDesc or its serde JSON text."""
+        from . import check, load_library
+        self._lib = load_library()
+        self._check = check
         self.renderer = renderer
-        self.desc = desc
+        self.desc = desc if isinstance(desc, HalaRayTracingProgramDesc) else HalaRayTracingProgramDesc.from_json(desc)
         self.debug_name = debug_name
-        self._rays = self._hits = 0
-        self._constants = bytearray(max(desc.push_constant_size, 4))
+        self._h = C.c_void_p()
+        text = desc if isinstance(desc, str) else self.desc.to_json()
+        check(self._lib.hala_rtprog_create(renderer._h, text.encode(), debug_name.encode(), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.hala_rtprog_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def get_pso(self):
         """:256 — the 'pipeline' is the traversal kernel pair of the library"""
@@ -76,29 +97,21 @@ class HalaRayTracingProgram:
 
     def bind(self, d_rays: int, d_hits: int):
         """:264-278 — bind the ray batch (device addresses) in place of descriptor sets"""
-        self._rays, self._hits = int(d_rays), int(d_hits)
+        self._check(self._lib.hala_rtprog_bind(self._h, C.c_void_p(int(d_rays)), C.c_void_p(int(d_hits))))
 
     def push_constants(self, offset: int, data: bytes):
         """:285-300 — byte 0..3 of the constant block selects the hit mode (0 closest, 1 any)"""
-        from . import HalaRendererError
-        if offset + len(data) > len(self._constants):
-            raise HalaRendererError("push constant range exceeds push_constant_size")
-        self._constants[offset:offset + len(data)] = data
+        self._check(self._lib.hala_rtprog_push_constants(self._h, C.c_uint32(offset), bytes(data), C.c_size_t(len(data))))
 
     def push_constants_f32(self, offset: int, data):
         """:307-322"""
-        import struct
-        self.push_constants(offset, struct.pack(f"<{len(data)}f", *data))
-
-    def _mode(self):
-        return int.from_bytes(self._constants[0:4], "little") & 1
+        arr = (C.c_float * len(data))(*data)
+        self._check(self._lib.hala_rtprog_push_constants_f32(self._h, C.c_uint32(offset), arr, C.c_size_t(len(data))))
 
     def trace_rays(self, width: int, height: int, depth: int = 1, stream: int = 0):
         """:330-332"""
-        self.renderer.trace_rays(self._rays, self._hits, width * height * depth, self._mode(), 0, stream)
+        self._check(self._lib.hala_rtprog_trace_rays(self._h, C.c_uint32(width), C.c_uint32(height), C.c_uint32(depth), C.c_void_p(stream or None)))
 
     def trace_rays_indirect(self, indirect_device_address: int, stream: int = 0):
         """:338-340"""
-        from . import check
-        r = self.renderer
-        check(r._lib.hala_rt_trace_rays_indirect(r._h, C.c_void_p(self._rays), C.c_void_p(self._hits), C.c_void_p(indirect_device_address), C.c_int(self._mode()), C.c_void_p(stream)))
+        self._check(self._lib.hala_rtprog_trace_rays_indirect(self._h, C.c_void_p(indirect_device_address), C.c_void_p(stream or None)))

@@ -279,6 +279,38 @@ class HalaRenderer:
         self._check(self._lib.hala_rt_tile_buffer(self._h, C.c_int(which), C.byref(p), C.byref(n)))
         return p.value, n.value
 
+    # -- the exchange step inside the library (RCCL; include/halart.h "hala_rt_comm_*", "hala_rt_tile_allgather*") --------------
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """ncclGetUniqueId: made on rank 0, handed to the other ranks over any host channel"""
+        from . import check, load_library
+        buf = (C.c_uint8 * 128)()
+        check(load_library().hala_rt_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init_rank(self, unique_id: bytes, rank: int, world: int):
+        self._check(self._lib.hala_rt_comm_init_rank(self._h, (C.c_uint8 * 128)(*unique_id), C.c_uint32(rank), C.c_uint32(world)))
+
+    def comm_attach(self, nccl_comm: int):
+        self._check(self._lib.hala_rt_comm_attach(self._h, C.c_void_p(nccl_comm)))
+
+    def comm_destroy(self):
+        self._check(self._lib.hala_rt_comm_destroy(self._h))
+
+    def tile_allgather(self, aovs=(0,)):
+        self._check(self._lib.hala_rt_tile_allgather(self._h, C.c_uint32(sum(1 << a for a in aovs))))
+
+    def tile_allgather_begin(self, aovs=(0,)):
+        self._check(self._lib.hala_rt_tile_allgather_begin(self._h, C.c_uint32(sum(1 << a for a in aovs))))
+
+    def tile_allgather_finish(self):
+        self._check(self._lib.hala_rt_tile_allgather_finish(self._h))
+
+    def gathered_buffer(self, which=0):
+        p = C.c_void_p(); n = C.c_size_t()
+        self._check(self._lib.hala_rt_get_gathered_buffer(self._h, C.c_int(which), C.byref(p), C.byref(n)))
+        return p.value, n.value
+
     def scatter_gathered_tiles(self, which, d_gathered: int, nbytes: int, stream: int = 0):
         """de-interleave a gathered buffer into this renderer's row-major image; stream = a hipStream_t of the caller's (0: the renderer's)"""
         self._check(self._lib.hala_rt_scatter_gathered_tiles_on_stream(self._h, C.c_int(which), C.c_void_p(d_gathered), C.c_size_t(nbytes), C.c_void_p(stream or None)))

@@ -440,6 +440,31 @@ int hala_rt_tile_buffer(hala_rt_renderer* r, int which, void** d_ptr, size_t* by
 /* the hipStream_t every launch of this renderer goes to (for stream-ordered hand-overs: hipStreamWaitEvent both ways) */
 int hala_rt_get_stream(hala_rt_renderer* r, void** hip_stream);
 int hala_rt_scatter_gathered_tiles(hala_rt_renderer* r, int which, const void* d_gathered, size_t bytes);
+
+/* The exchange step itself (ncclAllGather over xGMI), inside the library so that a Rust / C host has a multi-GPU
+ * path without any Python: libhalart.so links librccl.  One process (or thread) per GPU; every rank calls the same sequence.
+ *   hala_rt_comm_unique_id   : ncclGetUniqueId — rank 0 makes the 128-byte id and hands it to the other ranks over the host
+ *                               application's own channel (MPI, a socket, torch.distributed.broadcast ...)
+ *   hala_rt_comm_init_rank   : ncclCommInitRank on the renderer's device; rank / world must equal hala_rt_set_tile_shard's.
+ *   hala_rt_comm_attach      : use a communicator the caller owns (an ncclComm_t) instead; it is not destroyed by the library.
+ *   hala_rt_tile_allgather   : aov_mask bit k = AOV k (0 accum, 1 albedo, 2 normal, 3 final).  Gathers the rank's tile buffers and
+ *                               de-interleaves them into this renderer's row-major images (read_image / save_images then work on
+ *                               every rank).  Stream-ordered, never blocks the host: the collective runs on a side stream behind
+ *                               the updates enqueued so far, and the renderer's stream waits for it.
+ *   _begin / _finish         : the pipelined form: begin(k) snapshots the tile buffers (frame k + 1 may then overwrite them) and
+ *                               starts the collective; it runs beside the rendering of frame k + 1 until finish() — called by the
+ *                               next begin(), or explicitly — de-interleaves.  xGMI is point-to-point: a ring all-gather of
+ *                               N x 33 MB is bound by one link per hop and can take as long as rendering a rank's share.
+ *   hala_rt_get_gathered_buffer: the [world][tiles_per_rank][ts][ts][4] receive buffer of the last collective (tests). */
+#define HALA_COMM_UNIQUE_ID_BYTES 128
+int hala_rt_comm_unique_id(void* out_128_bytes);
+int hala_rt_comm_init_rank(hala_rt_renderer* r, const void* unique_id_128_bytes, uint32_t rank, uint32_t world);
+int hala_rt_comm_attach(hala_rt_renderer* r, void* nccl_comm);
+int hala_rt_comm_destroy(hala_rt_renderer* r);
+int hala_rt_tile_allgather(hala_rt_renderer* r, uint32_t aov_mask);
+int hala_rt_tile_allgather_begin(hala_rt_renderer* r, uint32_t aov_mask);
+int hala_rt_tile_allgather_finish(hala_rt_renderer* r);
+int hala_rt_get_gathered_buffer(hala_rt_renderer* r, int which, void** d_ptr, size_t* bytes);
 /* the same launched on a stream of the caller's (NULL: the renderer's): the de-interleave of frame k can then run beside the rendering
  * of frame k + 1.  The caller orders it against the renderer's stream (hala_rt_get_stream) before anything reads the images. */
 int hala_rt_scatter_gathered_tiles_on_stream(hala_rt_renderer* r, int which, const void* d_gathered, size_t bytes, void* hip_stream);
@@ -541,6 +566,30 @@ typedef struct hala_rtprog_desc_info {
   uint32_t ray_recursion_depth;
 } hala_rtprog_desc_info;
 int hala_rtprog_parse_desc(const char* desc_json, hala_rtprog_desc_info* out);
+
+/* HalaRayTracingProgram (src/raytracing_program.rs:70-341), one export per method: the generic "RT pass" object an application
+ * builds beside the renderer.  The shader paths of the description are recorded (SPIR-V has no meaning for the HIP kernels), the
+ * pipeline is the library's traversal kernel pair, bind() takes the device buffers of one ray batch where the reference takes
+ * descriptor sets, and bytes 0..3 of the push-constant block select the hit group: 0 closest hit, 1 any hit.
+ *   hala_rtprog_create              <- HalaRayTracingProgram::new (:85-252): desc_json = the serde form of HalaRayTracingProgramDesc
+ *                                      (:33-55); the renderer supplies device + acceleration structure (logical_device and
+ *                                      descriptor_set_layouts there); fails on a parse error or an empty raygen list
+ *   hala_rtprog_bind                <- bind (:264-278)
+ *   hala_rtprog_push_constants{,_f32} <- push_constants / push_constants_f32 (:285-322): offset + length must lie inside
+ *                                      push_constant_size (at least 4 bytes are kept for the mode word)
+ *   hala_rtprog_trace_rays          <- trace_rays(index, command_buffers, width, height, depth) (:330-332): width*height*depth rays of
+ *                                      the bound batch; hip_stream as in hala_rt_trace_rays (the command buffer of the reference)
+ *   hala_rtprog_trace_rays_indirect <- trace_rays_indirect (:338-340): device-resident {width, height, depth}
+ * The program borrows the renderer: destroy it before the renderer. */
+typedef struct hala_rtprog hala_rtprog;
+int hala_rtprog_create(hala_rt_renderer* r, const char* desc_json, const char* debug_name, hala_rtprog** out);
+void hala_rtprog_destroy(hala_rtprog* p);
+int hala_rtprog_get_desc_info(const hala_rtprog* p, hala_rtprog_desc_info* out);
+int hala_rtprog_bind(hala_rtprog* p, const hala_ray* d_rays, hala_hit* d_hits);
+int hala_rtprog_push_constants(hala_rtprog* p, uint32_t offset, const void* data, size_t len);
+int hala_rtprog_push_constants_f32(hala_rtprog* p, uint32_t offset, const float* data, size_t count);
+int hala_rtprog_trace_rays(hala_rtprog* p, uint32_t width, uint32_t height, uint32_t depth, void* hip_stream);
+int hala_rtprog_trace_rays_indirect(hala_rtprog* p, const uint32_t* d_indirect, void* hip_stream);
 
 const char* hala_version(void);
 

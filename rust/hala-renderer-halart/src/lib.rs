@@ -56,6 +56,7 @@ pub mod sys {
   #[repr(C)] #[derive(Default)] pub struct hala_rt_info { pub width: u32, pub height: u32 }
 
   #[repr(C)] pub struct hala_scene { _private: [u8; 0] }
+  #[repr(C)] pub struct hala_rtprog { _private: [u8; 0] }
   extern "C" {
     pub fn hala_last_error_message() -> *const c_char;
     pub fn hala_rt_create(name: *const c_char, width: u32, height: u32, device_ordinal: c_int, max_depth: u32, rr_depth: u32,
@@ -89,6 +90,22 @@ pub mod sys {
     pub fn hala_rt_refit(r: *mut hala_rt_renderer) -> c_int;
     pub fn hala_rt_load_blue_noise_texture(r: *mut hala_rt_renderer, path: *const c_char) -> c_int;
     pub fn hala_rt_set_tile_shard(r: *mut hala_rt_renderer, rank: u32, world: u32, tile_size: u32) -> c_int;
+    // the exchange step (RCCL all-gather + de-interleave) inside the library
+    pub fn hala_rt_comm_unique_id(out_128_bytes: *mut u8) -> c_int;
+    pub fn hala_rt_comm_init_rank(r: *mut hala_rt_renderer, unique_id_128_bytes: *const u8, rank: u32, world: u32) -> c_int;
+    pub fn hala_rt_comm_attach(r: *mut hala_rt_renderer, nccl_comm: *mut c_void) -> c_int;
+    pub fn hala_rt_comm_destroy(r: *mut hala_rt_renderer) -> c_int;
+    pub fn hala_rt_tile_allgather(r: *mut hala_rt_renderer, aov_mask: u32) -> c_int;
+    pub fn hala_rt_tile_allgather_begin(r: *mut hala_rt_renderer, aov_mask: u32) -> c_int;
+    pub fn hala_rt_tile_allgather_finish(r: *mut hala_rt_renderer) -> c_int;
+    // HalaRayTracingProgram as a C object
+    pub fn hala_rtprog_create(r: *mut hala_rt_renderer, desc_json: *const c_char, debug_name: *const c_char, out: *mut *mut hala_rtprog) -> c_int;
+    pub fn hala_rtprog_destroy(p: *mut hala_rtprog);
+    pub fn hala_rtprog_bind(p: *mut hala_rtprog, d_rays: *const hala_ray, d_hits: *mut hala_hit) -> c_int;
+    pub fn hala_rtprog_push_constants(p: *mut hala_rtprog, offset: u32, data: *const c_void, len: usize) -> c_int;
+    pub fn hala_rtprog_push_constants_f32(p: *mut hala_rtprog, offset: u32, data: *const f32, count: usize) -> c_int;
+    pub fn hala_rtprog_trace_rays(p: *mut hala_rtprog, width: u32, height: u32, depth: u32, hip_stream: *mut c_void) -> c_int;
+    pub fn hala_rtprog_trace_rays_indirect(p: *mut hala_rtprog, d_indirect: *const u32, hip_stream: *mut c_void) -> c_int;
     pub fn hala_rt_tile_buffer(r: *mut hala_rt_renderer, which: c_int, d_ptr: *mut *mut c_void, bytes: *mut usize) -> c_int;
     pub fn hala_rt_scatter_gathered_tiles(r: *mut hala_rt_renderer, which: c_int, d_gathered: *const c_void, bytes: usize) -> c_int;
     pub fn hala_rt_scatter_gathered_tiles_on_stream(r: *mut hala_rt_renderer, which: c_int, d_gathered: *const c_void, bytes: usize, hip_stream: *mut c_void) -> c_int;
@@ -235,20 +252,51 @@ impl HalaRenderer {
   }
 }
 
-/// src/raytracing_program.rs:70-341 — a ray batch traced against a committed renderer's acceleration structure.
-pub struct HalaRayTracingProgram<'a> { renderer: &'a HalaRenderer, rays: *const sys::hala_ray, hits: *mut sys::hala_hit, any_hit: bool }
+/// src/raytracing_program.rs:70-341 — the generic "RT pass" object, over the library's `hala_rtprog_*` exports: a ray batch traced
+/// against a committed renderer's acceleration structure.  `desc` is serialised with serde exactly as the reference's
+/// HalaRayTracingProgramDesc (:33-47), so an application's existing JSON descriptions load unchanged.
+pub struct HalaRayTracingProgram<'a> { h: *mut sys::hala_rtprog, _renderer: std::marker::PhantomData<&'a HalaRenderer> }
 impl<'a> HalaRayTracingProgram<'a> {
-  pub fn new(renderer: &'a HalaRenderer) -> Self { Self { renderer, rays: std::ptr::null(), hits: std::ptr::null_mut(), any_hit: false } }
+  /// :85-252 — the renderer stands for logical_device + descriptor_set_layouts
+  pub fn new(renderer: &'a HalaRenderer, desc_json: &str, debug_name: &str) -> Result<Self, HalaRendererError> {
+    let (d, n) = (CString::new(desc_json).unwrap(), CString::new(debug_name).unwrap());
+    let mut h = std::ptr::null_mut();
+    check(unsafe { sys::hala_rtprog_create(renderer.h, d.as_ptr(), n.as_ptr(), &mut h) })?;
+    Ok(Self { h, _renderer: std::marker::PhantomData })
+  }
   /// :264-278 — device addresses of the batch stand in for descriptor sets
-  pub fn bind(&mut self, d_rays: *const sys::hala_ray, d_hits: *mut sys::hala_hit) { self.rays = d_rays; self.hits = d_hits; }
-  /// :285-300
-  pub fn push_constants(&mut self, _offset: u32, data: &[u8]) { self.any_hit = data.first().map_or(false, |b| b & 1 == 1); }
+  pub fn bind(&mut self, d_rays: *const sys::hala_ray, d_hits: *mut sys::hala_hit) -> Result<(), HalaRendererError> {
+    check(unsafe { sys::hala_rtprog_bind(self.h, d_rays, d_hits) })
+  }
+  /// :285-300 — bytes 0..3 select the hit group: 0 closest hit, 1 any hit
+  pub fn push_constants(&mut self, offset: u32, data: &[u8]) -> Result<(), HalaRendererError> {
+    check(unsafe { sys::hala_rtprog_push_constants(self.h, offset, data.as_ptr() as *const c_void, data.len()) })
+  }
+  /// :307-322
+  pub fn push_constants_f32(&mut self, offset: u32, data: &[f32]) -> Result<(), HalaRendererError> {
+    check(unsafe { sys::hala_rtprog_push_constants_f32(self.h, offset, data.as_ptr(), data.len()) })
+  }
   /// :330-332
   pub fn trace_rays(&self, width: u32, height: u32, depth: u32) -> Result<(), HalaRendererError> {
-    check(unsafe { sys::hala_rt_trace_rays(self.renderer.h, self.rays, self.hits, width * height * depth, self.any_hit as c_int, std::ptr::null_mut(), std::ptr::null_mut()) })
+    check(unsafe { sys::hala_rtprog_trace_rays(self.h, width, height, depth, std::ptr::null_mut()) })
   }
   /// :338-340
   pub fn trace_rays_indirect(&self, indirect_device_address: u64) -> Result<(), HalaRendererError> {
-    check(unsafe { sys::hala_rt_trace_rays_indirect(self.renderer.h, self.rays, self.hits, indirect_device_address as *const u32, self.any_hit as c_int, std::ptr::null_mut()) })
+    check(unsafe { sys::hala_rtprog_trace_rays_indirect(self.h, indirect_device_address as *const u32, std::ptr::null_mut()) })
   }
+}
+impl<'a> Drop for HalaRayTracingProgram<'a> { fn drop(&mut self) { unsafe { sys::hala_rtprog_destroy(self.h) } } }
+
+/// multi-GPU: one process (or thread) per GPU; rank 0 makes the id, the application hands it to the other ranks
+impl HalaRenderer {
+  pub fn comm_unique_id() -> Result<[u8; 128], HalaRendererError> {
+    let mut id = [0u8; 128];
+    check(unsafe { sys::hala_rt_comm_unique_id(id.as_mut_ptr()) })?;
+    Ok(id)
+  }
+  pub fn comm_init_rank(&mut self, id: &[u8; 128], rank: u32, world: u32) -> Result<(), HalaRendererError> { check(unsafe { sys::hala_rt_comm_init_rank(self.h, id.as_ptr(), rank, world) }) }
+  /// aov_mask bit k = AOV k (0 accum, 1 albedo, 2 normal, 3 final): RCCL all-gather of the rank's tiles + de-interleave, stream-ordered
+  pub fn tile_allgather(&mut self, aov_mask: u32) -> Result<(), HalaRendererError> { check(unsafe { sys::hala_rt_tile_allgather(self.h, aov_mask) }) }
+  pub fn tile_allgather_begin(&mut self, aov_mask: u32) -> Result<(), HalaRendererError> { check(unsafe { sys::hala_rt_tile_allgather_begin(self.h, aov_mask) }) }
+  pub fn tile_allgather_finish(&mut self) -> Result<(), HalaRendererError> { check(unsafe { sys::hala_rt_tile_allgather_finish(self.h) }) }
 }

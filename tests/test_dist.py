@@ -75,15 +75,80 @@ def test_gloo_world2_all_gather_deinterleave():
     assert sorted(results) == [(0, True), (1, True)]
 
 
+def _gathered(r, which, shape):
+    """the receive buffer of the library's last collective, read through a zero-copy torch view"""
+    import torch
+    from hala_renderer_amd.dist import _DeviceView
+    ptr, nbytes = r.gathered_buffer(which)
+    torch.cuda.synchronize()
+    return torch.as_tensor(_DeviceView(ptr, nbytes // 4), device="cuda:0").cpu().numpy().reshape(shape)
+
+
 @pytest.mark.gpu
-def test_rccl_all_gather_aliases_library_memory(halart):
-    """the RCCL leg with the ranks this box has (one): TileGather must alias the library's device buffer (no copy) and
-    all_gather_into_tensor must deliver it"""
+def test_rccl_all_gather_inside_the_library(halart):
+    """the RCCL leg with the ranks this box has (one), through the C ABI only — no torch.distributed: ncclGetUniqueId, ncclCommInitRank,
+    ncclAllGather on the library's side stream; the receive buffer must hold the rank's accumulated tiles, and a second communicator
+    on the same renderer, a wrong rank and a gather without communicator must be refused"""
+    r = halart.HalaRenderer("rccl", 96, 64, 4, 2, False, False, False, 0)
+    r.set_scene(scenes.cornell_box(aspect=1.5))
+    r.commit()
+    with pytest.raises(halart.HalaRendererError, match="no communicator"):
+        r.tile_allgather((r.ACCUM,))
+    ident = halart.HalaRenderer.comm_unique_id()
+    assert len(ident) == 128 and any(ident)
+    with pytest.raises(halart.HalaRendererError, match="differ from the renderer's tile shard"):
+        r.comm_init_rank(ident, 1, 2)
+    r.comm_init_rank(ident, 0, 1)
+    with pytest.raises(halart.HalaRendererError, match="already has a communicator"):
+        r.comm_init_rank(ident, 0, 1)
+    r.update_batch(2)
+    r.tile_allgather((r.ACCUM, r.ALBEDO))
+    r.wait_idle()
+    assert np.array_equal(_gathered(r, r.ACCUM, (64, 96, 4)), r.read_image(r.ACCUM))
+    assert np.array_equal(_gathered(r, r.ALBEDO, (64, 96, 4)), r.read_image(r.ALBEDO))
+    r.comm_destroy()
+    r.close()
+
+
+@pytest.mark.gpu
+def test_rccl_pipelined_gather_is_stream_ordered(halart):
+    """begin() / finish() never block the host: frame k + 1 is enqueued on the renderer's stream before frame k's gather is finished;
+    the receive buffer must still hold frame k (snapshot taken before the tiles are overwritten) — one rank, which is what this box
+    has"""
+    w, h = 480, 270
+    scene = scenes.cornell_box(aspect=w / h)
+    r = halart.HalaRenderer("rccl-pipe", w, h, 5, 3, False, False, False, 0)
+    ref = halart.HalaRenderer("ref", w, h, 5, 3, False, False, False, 0)
+    for x in (r, ref):
+        x.set_scene(scene); x.commit()
+    r.comm_init_rank(halart.HalaRenderer.comm_unique_id(), 0, 1)
+    want = []
+    spps = (1, 3, 2, 4)
+    for spp in spps:
+        ref.reset_accumulation(); ref.update_batch(spp)
+        want.append(ref.read_image(ref.ACCUM))
+    r.reset_accumulation(); r.update_batch(spps[0])
+    for k in range(4):
+        r.tile_allgather_begin((r.ACCUM,))  # (finishes gather k - 1,) snapshots frame k, starts its gather; the host is not blocked
+        r.render()
+        if k + 1 < 4:                        # frame k + 1 goes to the renderer's stream while gather k may still be running
+            r.reset_accumulation(); r.update_batch(spps[k + 1])
+        r.tile_allgather_finish()
+        r.wait_idle()
+        assert np.array_equal(_gathered(r, r.ACCUM, (h, w, 4)), want[k]), k
+    r.close(); ref.close()
+
+
+@pytest.mark.gpu
+def test_tile_gather_over_torch_distributed_rccl(halart):
+    """what bench.py --gpus N does per rank, with the ranks this box has (one): torch.distributed (backend nccl = RCCL) only carries
+    rank 0's ncclUniqueId; TileGather then drives the library's own communicator"""
     import torch
     import torch.distributed as dist
     from hala_renderer_amd.dist import TileGather
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(_free_port())
+    torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         r = halart.HalaRenderer("rccl", 96, 64, 4, 2, False, False, False, 0)
@@ -91,48 +156,11 @@ def test_rccl_all_gather_aliases_library_memory(halart):
         r.commit()
         g = TileGather(r, 0, aovs=(r.ACCUM,))
         r.update_batch(2)
-        g.gather()
-        got = g.bufs[0][2].cpu().numpy().reshape(64, 96, 4)
-        assert np.array_equal(got, r.read_image(r.ACCUM))
+        g.begin(); r.render(); g.finish()
+        r.wait_idle()
+        assert np.array_equal(_gathered(r, r.ACCUM, (64, 96, 4)), r.read_image(r.ACCUM))
+        g.close()
         r.close()
-    finally:
-        dist.destroy_process_group()
-
-
-@pytest.mark.gpu
-def test_rccl_pipelined_gather_is_stream_ordered(halart):
-    """the RCCL form of begin()/finish() never blocks the host: frame k + 1 is enqueued on the renderer's stream before frame k's
-    gather is finished; the receive buffer must still hold frame k (snapshot taken before the tiles are overwritten) — one rank,
-    which is what this box has"""
-    import torch
-    import torch.distributed as dist
-    from hala_renderer_amd.dist import TileGather
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(_free_port())
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    try:
-        w, h = 480, 270
-        scene = scenes.cornell_box(aspect=w / h)
-        r = halart.HalaRenderer("rccl-pipe", w, h, 5, 3, False, False, False, 0)
-        ref = halart.HalaRenderer("ref", w, h, 5, 3, False, False, False, 0)
-        for x in (r, ref):
-            x.set_scene(scene); x.commit()
-        g = TileGather(r, 0, aovs=(r.ACCUM,))
-        want = []
-        for spp in (1, 3, 2, 4):
-            ref.reset_accumulation(); ref.update_batch(spp)
-            want.append(ref.read_image(ref.ACCUM))
-        spps = (1, 3, 2, 4)
-        r.reset_accumulation(); r.update_batch(spps[0])
-        for k in range(4):
-            g.begin()                      # (finishes gather k - 1,) snapshots frame k, starts its gather; the host is not blocked
-            r.render()
-            if k + 1 < 4:                  # frame k + 1 goes to the renderer's stream while gather k may still be running
-                r.reset_accumulation(); r.update_batch(spps[k + 1])
-            g.finish()
-            torch.cuda.synchronize()
-            assert np.array_equal(g.bufs[0][2].cpu().numpy().reshape(h, w, 4), want[k]), k
-        r.close(); ref.close()
     finally:
         dist.destroy_process_group()
 

@@ -259,6 +259,14 @@ def test_rtprog_trace_rays_and_indirect(halart, oracle):
     torch.cuda.synchronize()
     desc = halart.HalaRayTracingProgramDesc(raygen_shader_file_paths=["builtin"], hit_shader_file_paths=[halart.HalaRayTracingHitShaderDesc("builtin")], push_constant_size=4)
     prog = halart.HalaRayTracingProgram(r, desc, "t")
+    with pytest.raises(halart.HalaRendererError, match="not bound"):
+        prog.trace_rays(64, 32, 1)
+    with pytest.raises(halart.HalaRendererError, match="exceeds push_constant_size"):
+        prog.push_constants(2, b"\0\0\0\0")
+    with pytest.raises(halart.HalaRendererError, match="raygen shader list is empty"):
+        halart.HalaRayTracingProgram(r, '{"raygen_shader_file_paths": [], "hit_shader_file_paths": []}', "e")
+    with pytest.raises(halart.HalaRendererError, match="missing field"):
+        halart.HalaRayTracingProgram(r, '{"hit_shader_file_paths": []}', "e")
     prog.bind(d_rays.data_ptr(), d_hits.data_ptr())
     prog.trace_rays(64, 32, 1)
     r.wait_idle()
@@ -271,6 +279,11 @@ def test_rtprog_trace_rays_and_indirect(halart, oracle):
     r.wait_idle()
     got = np.frombuffer(d_hits.cpu().numpy().tobytes(), dtype=H._abi.HIT_DTYPE)
     assert np.array_equal(got["t"], osc.trace(rays, 1)["t"])
+    prog.push_constants_f32(0, [0.0])  # bits 0: closest hit again
+    prog.trace_rays(64, 32, 1)
+    r.wait_idle()
+    assert d_hits.cpu().numpy().tobytes() == want.tobytes()
+    prog.close()
     r.close()
 
 
