@@ -51,7 +51,25 @@ def media(write=True):
     return imgs, st
 
 
+def config0(write=True):
+    """BASELINE configs[0] (Cornell 512x512, 1 spp): hash of the colour PFM the reference's save_images would write"""
+    import hashlib
+    import json
+    from hala_renderer_amd import workloads
+    cfg = workloads.baseline_config(0)
+    imgs, st = O.OracleScene(cfg["scene"]).render(512, 512, frames=1, max_depth=cfg["max_depth"], rr_depth=cfg["rr_depth"])
+    out = {"what": "BASELINE configs[0]: Cornell box 512x512, 1 spp, frame_index 0, max_depth 5, rr_depth 3 — sha256 of the _color.pfm bytes (oracle render; tests/test_baseline_configs.py regenerates and compares)",
+           "color_pfm_sha256": hashlib.sha256(O.pfm_bytes(imgs[0])).hexdigest(), "rays": [int(st.rays_closest), int(st.rays_shadow)],
+           "mean_radiance": float(imgs[0][..., :3].mean())}
+    if write:
+        json.dump(out, open(os.path.join(HERE, "config0_cornell_512x512_1spp.json"), "w"), indent=1)
+    return out
+
+
 def main():
+    if "--only-config0" in sys.argv:
+        print(config0())
+        return
     if "--only-media" in sys.argv:  # added later than the others: written alone so that their files keep their bytes
         media()
         print("media fixture written to", HERE)

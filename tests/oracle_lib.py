@@ -129,9 +129,13 @@ def pfm_bytes(rgba):
 
 
 class OracleScene:
-    def __init__(self, scene: H.HalaScene, envmap=None):
-        holder = scene.to_desc()
-        self._h = C.c_void_p(lib().orc_scene_create(holder.ptr()))
+    def __init__(self, scene, envmap=None):
+        """scene: a hala_renderer_amd.HalaScene, or a NativeScene (what the library's own glTF loader produced)"""
+        if hasattr(scene, "desc_ptr"):
+            self._h = C.c_void_p(lib().orc_scene_create(scene.desc_ptr()))
+        else:
+            holder = scene.to_desc()
+            self._h = C.c_void_p(lib().orc_scene_create(holder.ptr()))
         if not self._h:
             raise RuntimeError("orc_scene_create failed")
         self.has_env = False
