@@ -347,11 +347,14 @@ k_trace_shadow(SceneView sv, Queues q, PathState ps, Control* __restrict__ ctl, 
 // ---------------------------------------------------------------------------------------------------------
 // PRIMARY (depth 0): queue entry i IS path slot i, its ray is re-evaluated from the camera instead of being read, and
 // the path state starts from its constants (throughput 1, radiance 0) — this kernel initialises every per-path record.
-template <bool PRIMARY>
 #ifndef RT_SHADE_WAVES
 #define RT_SHADE_WAVES 4
 #endif
-__global__ void __launch_bounds__(kShadeThreads, RT_SHADE_WAVES) k_shade(FrameConst fc, SceneView sv, Queues q, PathState ps, Control* __restrict__ ctl, uint32_t depth) {
+#ifndef RT_SHADE_WAVES_SIMPLE
+#define RT_SHADE_WAVES_SIMPLE 6  // 80 VGPRs, no scratch (8 waves: 32-44 B of scratch per lane and slower; profiles/r02_experiments.txt)
+#endif
+template <bool PRIMARY, bool SIMPLE>
+__global__ void __launch_bounds__(kShadeThreads, SIMPLE ? RT_SHADE_WAVES_SIMPLE : RT_SHADE_WAVES) k_shade(FrameConst fc, SceneView sv, Queues q, PathState ps, Control* __restrict__ ctl, uint32_t depth) {
   __shared__ BlockCompact s_compact;
   const uint32_t n = PRIMARY ? fc.slot_count : ctl->n_active[depth];
   // the traversal of this bounce is over and the next users (shadow pass of this bounce, closest-hit pass of the next)
@@ -463,7 +466,7 @@ __global__ void __launch_bounds__(kShadeThreads, RT_SHADE_WAVES) k_shade(FrameCo
         ps.normal[slot] = P3{0.0f, 0.0f, 0.0f};
       }
     } else {
-      const Surface sf = make_surface(sv, fc.pixel_spread, o, d, hv.x, hv.y, hv.z, hit_prim);
+      const Surface sf = make_surface<SIMPLE>(sv, fc.pixel_spread, o, d, hv.x, hv.y, hv.z, hit_prim);
       if (PRIMARY) {
         ps.albedo[slot] = P3{sf.mat.base.x, sf.mat.base.y, sf.mat.base.z};
         ps.normal[slot] = P3{sf.ns.x, sf.ns.y, sf.ns.z};
@@ -730,8 +733,13 @@ void launch_trace_primary(const LaunchCfg& lc, const SceneView& sv, const FrameC
 }
 void launch_shade(const FrameConst& fc, const SceneView& sv, const Queues& q, const PathState& ps, Control* ctl, uint32_t depth, hipStream_t s) {
   const dim3 grid(blocks_for(fc.slot_count, kShadeThreads)), block(kShadeThreads);
-  if (depth == 0u) hipLaunchKernelGGL(k_shade<true>, grid, block, 0, s, fc, sv, q, ps, ctl, depth);
-  else hipLaunchKernelGGL(k_shade<false>, grid, block, 0, s, fc, sv, q, ps, ctl, depth);
+  if (sv.simple_materials) {
+    if (depth == 0u) hipLaunchKernelGGL((k_shade<true, true>), grid, block, 0, s, fc, sv, q, ps, ctl, depth);
+    else hipLaunchKernelGGL((k_shade<false, true>), grid, block, 0, s, fc, sv, q, ps, ctl, depth);
+  } else {
+    if (depth == 0u) hipLaunchKernelGGL((k_shade<true, false>), grid, block, 0, s, fc, sv, q, ps, ctl, depth);
+    else hipLaunchKernelGGL((k_shade<false, false>), grid, block, 0, s, fc, sv, q, ps, ctl, depth);
+  }
 }
 void launch_resolve(const FrameConst& fc, const PathState& ps, float4* accum, float4* albedo, float4* normal, float4* final_img, hipStream_t s) {
   hipLaunchKernelGGL(k_resolve, dim3(blocks_for(fc.pixel_slots, 256)), dim3(256), 0, s, fc, ps, accum, albedo, normal, final_img);

@@ -497,6 +497,9 @@ RT_DI f3 transform_vector(const float* m, f3 p) {
   return mk3(__fmaf_rn(m[8], p.z, __fmaf_rn(m[4], p.y, m[0] * p.x)), __fmaf_rn(m[9], p.z, __fmaf_rn(m[5], p.y, m[1] * p.x)),
              __fmaf_rn(m[10], p.z, __fmaf_rn(m[6], p.y, m[2] * p.x)));
 }
+// SIMPLE: the scene's materials are all untextured, opaque DIFFUSE ones without a medium (the host checks: SceneView::simple_materials);
+// the compiler then drops the texture, Disney and medium code from the kernel variant — half the registers, twice the waves.
+template <bool SIMPLE>
 RT_DI Surface make_surface(const SceneView& sv, float pixel_spread, f3 o, f3 d, float t, float u, float v, uint32_t prim) {
   Surface sf;
   // line 1 of the 128-B shading record: geometric normal, vertex normals, instance, material
@@ -513,15 +516,15 @@ RT_DI Surface make_surface(const SceneView& sv, float pixel_spread, f3 o, f3 d, 
   const hala_gpu_material& m = sv.materials[material];
   sf.mat.base = ld3(m.base_color);
   sf.mat.emission = ld3(m.emission);
-  sf.mat.ax = m.ax; sf.mat.ay = m.ay; sf.mat.type = m.type;
+  sf.mat.ax = m.ax; sf.mat.ay = m.ay; sf.mat.type = SIMPLE ? 0u : m.type;
   sf.mat.metallic = m.metallic; sf.mat.roughness = m.roughness; sf.mat.specular_tint = m.specular_tint;
   sf.mat.sheen = m.sheen; sf.mat.sheen_tint = m.sheen_tint; sf.mat.clearcoat = m.clearcoat;
   sf.mat.clearcoat_roughness = m.clearcoat_roughness; sf.mat.ior = m.ior;
-  sf.mat.trans = 0.0f; sf.mat.eta = m.ior; sf.mat.opacity = m.opacity;
+  sf.mat.trans = 0.0f; sf.mat.eta = m.ior; sf.mat.opacity = SIMPLE ? 1.0f : m.opacity;
   // texture maps (set 2; u32::MAX = none, gltf_loader.rs:346-353)
   const uint32_t nt = sv.texture_count;
-  const bool has_base = m.base_color_map_index < nt, has_nrm = m.normal_map_index < nt;
-  const bool has_mr = m.metallic_roughness_map_index < nt, has_em = m.emission_map_index < nt;
+  const bool has_base = !SIMPLE && m.base_color_map_index < nt, has_nrm = !SIMPLE && m.normal_map_index < nt;
+  const bool has_mr = !SIMPLE && m.metallic_roughness_map_index < nt, has_em = !SIMPLE && m.emission_map_index < nt;
   if (has_base || has_nrm || has_mr || has_em) {
     // line 2: texture coordinates and tangents (in flight together with the texture descriptors)
     const float4 s4 = sp[4], s5 = sp[5], s6 = sp[6], s7 = sp[7];
@@ -576,7 +579,7 @@ RT_DI Surface make_surface(const SceneView& sv, float pixel_spread, f3 o, f3 d, 
       }
     }
   }
-  if (m.type == 1u) sf.mat.trans = m.specular_transmission * (1.0f - sf.mat.metallic);  // after the metallic map
+  if (!SIMPLE && m.type == 1u) sf.mat.trans = m.specular_transmission * (1.0f - sf.mat.metallic);  // after the metallic map
   if (dot3(sf.ns, sf.ng) < 0.0f) sf.ng = -sf.ng;
   sf.absorb = splat3(1.0f); sf.glow = splat3(0.0f);
   sf.sigma = 0.0f; sf.hg = 0.0f; sf.scol = splat3(1.0f);
@@ -585,7 +588,8 @@ RT_DI Surface make_surface(const SceneView& sv, float pixel_spread, f3 o, f3 d, 
     sf.mat.eta = 1.0f / sf.mat.ior;
     // §7.1e: the segment ran through the object's medium (closed, non-nested objects: no per-path medium state needed)
     const float dt = m.medium_density * t;
-    if (m.medium_type == 1u)       // ABSORB: Beer-Lambert with sigma = density * (1 - colour)
+    if (SIMPLE) {
+    } else if (m.medium_type == 1u)       // ABSORB: Beer-Lambert with sigma = density * (1 - colour)
       sf.absorb = mk3(exp_neg_poly(-(dt * (1.0f - m.medium_color[0]))), exp_neg_poly(-(dt * (1.0f - m.medium_color[1]))),
                       exp_neg_poly(-(dt * (1.0f - m.medium_color[2]))));
     else if (m.medium_type == 3u)  // EMISSIVE: colour * density per unit length
