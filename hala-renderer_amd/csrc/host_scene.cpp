@@ -106,6 +106,7 @@ std::string HostScene::assign(const hala_scene_desc* d) {
           o[3] = (float)b3 / 255.0f;
         }
       } else return "Unsupported image format.";
+      for (size_t i = 0; i < n && !out.has_alpha; ++i) out.has_alpha = out.rgba[4 * i + 3] < 1.0f;
       images.push_back(std::move(out));
     }
     uint32_t prev_key = 0;

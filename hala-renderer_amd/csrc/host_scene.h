@@ -33,6 +33,7 @@ struct HostPrimitive {
 struct HostImage32F {  // one cpu::HalaImageData decoded to linear RGBA32F (level 0 of its mip chain)
   uint32_t width = 0, height = 0;
   std::vector<float> rgba;
+  bool has_alpha = false;  // some texel has alpha < 1: a base-colour map that cuts its surface out (RENDER_SPEC 7.1d)
 };
 
 struct HostScene {

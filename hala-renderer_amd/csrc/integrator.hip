@@ -124,7 +124,7 @@ RT_DI uint32_t work_take(WorkCounters* wc, WorkCursor& c, uint32_t n, uint32_t w
 // (and the queue is not dry) the wave dequeues exactly that many rays and hands them to its idle lanes by ballot rank
 // — consecutive queue entries go to consecutive idle lanes, so refill loads stay as coalesced as the holes allow.
 // Source: load(i, &o, &d, &tmin, &tmax) fetches queue entry i (false: no ray there); done(i, trav, payload) consumes the result.
-template <bool ANY, bool COUNT, bool STAGED, class Source>
+template <bool ANY, bool COUNT, bool STAGED, bool ALPHA, class Source>
 RT_DI void persistent_trace(const SceneView& sv, const TraverseLds& lds, uint2* spill, WorkCounters* work, uint32_t n, uint32_t refill,
                             Source& src, StepCounters& sc) {
   WorkCursor cur = work_begin(n);
@@ -166,9 +166,9 @@ RT_DI void persistent_trace(const SceneView& sv, const TraverseLds& lds, uint2* 
           const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane_id()) - 1ull));
           if (rank < got) {
             idx = base + rank;
-            f3 o, d; float tmin, tmax;
-            if (src.load(idx, &o, &d, &tmin, &tmax, &pay)) {  // false: the source had no ray for this entry and has dealt with it
-              trav_begin(t, make_ray(o, d, tmin), tmax);
+            f3 o, d; float tmin, tmax; uint32_t key = 0u;
+            if (src.load(idx, &o, &d, &tmin, &tmax, &key, &pay)) {  // false: the source had no ray for this entry and has dealt with it
+              trav_begin(t, make_ray(o, d, tmin), tmax, key);
               has = true;
             }
           }
@@ -180,9 +180,9 @@ RT_DI void persistent_trace(const SceneView& sv, const TraverseLds& lds, uint2* 
       if (COUNT && lane_id() == 0u) sc.wave_steps++;  // lane 0 runs every iteration of this wave-uniform loop
       // every lane calls it: the large-scene variant deals the wave's leaf work out over all 64 lanes (traverse.h)
 #ifdef RT_NO_DEFER
-      if (trav_step<ANY, COUNT, STAGED>(sv, lds, spill, t, has, sc)) { src.done(idx, t, pay); has = false; }
+      if (trav_step<ANY, COUNT, STAGED, ALPHA>(sv, lds, spill, t, has, sc)) { src.done(idx, t, pay); has = false; }
 #else
-      if (trav_step<ANY, COUNT, STAGED>(sv, lds, spill, t, has, sc)) { fin = true; has = false; }
+      if (trav_step<ANY, COUNT, STAGED, ALPHA>(sv, lds, spill, t, has, sc)) { fin = true; has = false; }
 #endif
       const uint32_t nidle = (uint32_t)__popcll(__ballot(!has));
       if (nidle == 64u || (more && nidle >= refill)) break;
@@ -201,10 +201,11 @@ struct BatchSource {
   // scattered entries at scattered times: ordinary stores, so that L2 puts the 16-B pieces of a line together before it goes to
   // memory (nontemporal 16-B pieces reached the fabric at 1.8-2.1x their bytes: profiles/r01_m_pmc_config2.txt, r02_a_pmc_config4).
   bool streaming;
-  RT_DI bool load(uint32_t i, f3* o, f3* d, float* tmin, float* tmax, Payload*) const {
+  RT_DI bool load(uint32_t i, f3* o, f3* d, float* tmin, float* tmax, uint32_t* key, Payload*) const {
     const float4* rp = reinterpret_cast<const float4*>(rays + i);
     const float4 ro = rp[0], rd = rp[1];
     *o = mk3(ro.x, ro.y, ro.z); *d = mk3(rd.x, rd.y, rd.z); *tmin = queue ? 0.0f : ro.w; *tmax = queue ? kTMax : rd.w;
+    if (any) *key = pcg_hash(i ^ kAnyKeyBatch);  // RENDER_SPEC 7.1d: the key of ray i of a batch
     return true;
   }
   RT_DI void done(uint32_t i, const Trav& t, const Payload&) const {
@@ -234,7 +235,7 @@ struct CameraSource {
   const SceneView& sv;
   hala_hit* hits;
   bool streaming;
-  RT_DI bool load(uint32_t i, f3* o, f3* d, float* tmin, float* tmax, Payload*) const {
+  RT_DI bool load(uint32_t i, f3* o, f3* d, float* tmin, float* tmax, uint32_t*, Payload*) const {
     uint32_t rng;
     *tmin = 0.0f; *tmax = kTMax;
     if (primary_ray(fc, sv, i, o, d, &rng)) return true;
@@ -260,7 +261,7 @@ struct ShadowSource {
   // atomics per unoccluded ray did the same and cost 57 of the launch's 160 us on the headline config: profiles/r01_h_experiments.txt.)
   // PREFETCH = false (the 6-waves-per-SIMD kernels of large scenes, where three more live registers spill): the add is done by
   // fire-and-forget float atomics instead — at most one per radiance word per launch, so exactly the same single IEEE add.
-  RT_DI bool load(uint32_t i, f3* o, f3* d, float* tmin, float* tmax, Payload* p) const {
+  RT_DI bool load(uint32_t i, f3* o, f3* d, float* tmin, float* tmax, uint32_t* key, Payload* p) const {
     const float4* e = reinterpret_cast<const float4*>(entries + i);
     const float4 ro = e[0], rd = e[1];
     p->cs = e[2];
@@ -268,7 +269,8 @@ struct ShadowSource {
       const float* l = reinterpret_cast<const float*>(radiance + __float_as_uint(p->cs.w));
       p->lx = l[0]; p->ly = l[1]; p->lz = l[2];
     }
-    *o = mk3(ro.x, ro.y, ro.z); *d = mk3(rd.x, rd.y, rd.z); *tmin = ro.w; *tmax = rd.w;
+    // a connection starts at its origin (tmin = 0): the field carries its any-hit key (RENDER_SPEC 7.1d)
+    *o = mk3(ro.x, ro.y, ro.z); *d = mk3(rd.x, rd.y, rd.z); *tmin = 0.0f; *tmax = rd.w; *key = __float_as_uint(ro.w);
     return true;
   }
   RT_DI void done(uint32_t, const Trav& t, const Payload& p) const {
@@ -293,7 +295,7 @@ RT_DI void flush_counters(Control* ctl, int kind, const StepCounters& sc) {
 // ---------------------------------------------------------------------------------------------------------
 // K5a: persistent closest-hit traversal over a compact ray queue (coalesced 32-B ray reads, 16-B hit writes)
 // ---------------------------------------------------------------------------------------------------------
-template <bool ANY, bool COUNT, bool STAGED>
+template <bool ANY, bool COUNT, bool STAGED, bool ALPHA>
 __global__ void __launch_bounds__(kTraverseThreads, STAGED ? kTraverseWavesPerSimdStaged : kTraverseWavesPerSimd)
 k_trace_batch(SceneView sv, const hala_ray* __restrict__ rays, hala_hit* __restrict__ hits, const uint32_t* __restrict__ n_ptr,
               uint32_t n_imm, WorkCounters* __restrict__ work, uint2* __restrict__ spill_base, Control* __restrict__ ctl, int account,
@@ -306,7 +308,7 @@ k_trace_batch(SceneView sv, const hala_ray* __restrict__ rays, hala_hit* __restr
     if (ANY) ctl->rays_shadow += n; else ctl->rays_closest += n;
   }
   BatchSource src{rays, hits, ANY, account != 0, STAGED && refill == 64u};
-  persistent_trace<ANY, COUNT, STAGED>(sv, lds, spill, work, n, refill, src, sc);
+  persistent_trace<ANY, COUNT, STAGED, ALPHA>(sv, lds, spill, work, n, refill, src, sc);
   if (COUNT) flush_counters(ctl, ANY ? 1 : 0, sc);
 }
 
@@ -321,7 +323,7 @@ k_trace_primary(SceneView sv, FrameConst fc, hala_hit* __restrict__ hits, WorkCo
   StepCounters sc;
   if (blockIdx.x == 0 && threadIdx.x == 0) ctl->rays_closest += n_account;
   CameraSource src{fc, sv, hits, STAGED && refill == 64u};
-  persistent_trace<false, COUNT, STAGED>(sv, lds, spill, work, fc.slot_count, refill, src, sc);
+  persistent_trace<false, COUNT, STAGED, false>(sv, lds, spill, work, fc.slot_count, refill, src, sc);
   if (COUNT) flush_counters(ctl, 0, sc);
 }
 
@@ -329,7 +331,7 @@ k_trace_primary(SceneView sv, FrameConst fc, hala_hit* __restrict__ hits, WorkCo
 // K5c: shadow traversal of the NEE connections of one bounce; unoccluded contributions are added to the
 // path's radiance in the fixed order light, environment (RENDER_SPEC §6)
 // ---------------------------------------------------------------------------------------------------------
-template <bool COUNT, bool STAGED>
+template <bool COUNT, bool STAGED, bool ALPHA>
 __global__ void __launch_bounds__(kTraverseThreads, STAGED ? kTraverseWavesPerSimdStaged : kTraverseWavesPerSimd)
 k_trace_shadow(SceneView sv, Queues q, PathState ps, Control* __restrict__ ctl, uint32_t depth, uint32_t kind, uint2* __restrict__ spill_base,
                uint32_t refill) {
@@ -338,7 +340,7 @@ k_trace_shadow(SceneView sv, Queues q, PathState ps, Control* __restrict__ ctl, 
   uint2* spill = spill_base ? spill_base + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * kStackSpill : nullptr;
   StepCounters sc;
   ShadowSource<STAGED> src{q.shadow[kind], ps.radiance};
-  persistent_trace<true, COUNT, STAGED>(sv, lds, spill, &ctl->work_shadow[kind], n, refill, src, sc);
+  persistent_trace<true, COUNT, STAGED, ALPHA>(sv, lds, spill, &ctl->work_shadow[kind], n, refill, src, sc);
   if (COUNT) flush_counters(ctl, 1, sc);
 }
 
@@ -538,7 +540,7 @@ __global__ void __launch_bounds__(kShadeThreads, SIMPLE ? RT_SHADE_WAVES_SIMPLE 
               contrib = fb * ls.le * (cosl * w / pl);
             }
             const f3 tc = T * contrib;
-            conn[0][0] = make_float4(so.x, so.y, so.z, 0.0f);
+            conn[0][0] = make_float4(so.x, so.y, so.z, __uint_as_float(pcg_hash(rng ^ kAnyKeyLight)));  // tmin is 0: the field carries the any-hit key (7.1d)
             conn[0][1] = make_float4(ls.wi.x, ls.wi.y, ls.wi.z, tmax);
             conn[0][2] = make_float4(tc.x, tc.y, tc.z, __uint_as_float(slot));
             keep[1] = true;
@@ -558,7 +560,7 @@ __global__ void __launch_bounds__(kShadeThreads, SIMPLE ? RT_SHADE_WAVES_SIMPLE 
             const float w = power_heuristic(pdf_e, pdf_b);
             const f3 col = env_map_eval(fc, sv, wi);
             const f3 tc = T * (fb * col * (cosl * w / pdf_e));
-            conn[1][0] = make_float4(so.x, so.y, so.z, 0.0f);
+            conn[1][0] = make_float4(so.x, so.y, so.z, __uint_as_float(pcg_hash(rng ^ kAnyKeyEnv)));
             conn[1][1] = make_float4(wi.x, wi.y, wi.z, kTMax);
             conn[1][2] = make_float4(tc.x, tc.y, tc.z, __uint_as_float(slot));
             keep[2] = true;
@@ -672,10 +674,10 @@ uint32_t traverse_stack_spill_levels() { return kStackSpill; }
 uint32_t traverse_max_leaf(bool staged) { return staged ? 8u : (uint32_t)kLeafSlots; }
 uint32_t traverse_blocks_per_cu(size_t dynamic_lds_bytes, bool staged) {
   int a = 0, b = 0;
-  const hipError_t ea = staged ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_batch<false, false, true>, kTraverseThreads, dynamic_lds_bytes)
-                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_batch<false, false, false>, kTraverseThreads, dynamic_lds_bytes);
-  const hipError_t eb = staged ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_trace_shadow<false, true>, kTraverseThreads, dynamic_lds_bytes)
-                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_trace_shadow<false, false>, kTraverseThreads, dynamic_lds_bytes);
+  const hipError_t ea = staged ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_batch<false, false, true, false>, kTraverseThreads, dynamic_lds_bytes)
+                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_batch<false, false, false, false>, kTraverseThreads, dynamic_lds_bytes);
+  const hipError_t eb = staged ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_trace_shadow<false, true, false>, kTraverseThreads, dynamic_lds_bytes)
+                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_trace_shadow<false, false, false>, kTraverseThreads, dynamic_lds_bytes);
   if (ea != hipSuccess || eb != hipSuccess) return 0;
   return (uint32_t)std::max(0, std::min(a, b));
 }
@@ -684,39 +686,45 @@ static size_t traverse_smem(const SceneView& sv) {
 }
 
 // the traversal kernels are compiled per (any-hit, counting, BVH staged in LDS); all three are launch-time constants
-template <bool ANY, bool COUNT, bool STAGED>
+template <bool ANY, bool COUNT, bool STAGED, bool ALPHA>
 static void launch_trace_batch_t(const LaunchCfg& lc, const SceneView& sv, const hala_ray* rays, hala_hit* hits, const uint32_t* n_ptr,
                                  uint32_t n_imm, WorkCounters* work, Control* ctl, int acc, size_t smem, hipStream_t s) {
-  hipLaunchKernelGGL((k_trace_batch<ANY, COUNT, STAGED>), dim3(lc.persistent_blocks), dim3(kTraverseThreads), smem, s, sv, rays, hits, n_ptr, n_imm,
+  hipLaunchKernelGGL((k_trace_batch<ANY, COUNT, STAGED, ALPHA>), dim3(lc.persistent_blocks), dim3(kTraverseThreads), smem, s, sv, rays, hits, n_ptr, n_imm,
                      work, lc.spill, ctl, acc, lc.refill);
 }
+// the traversal kernels are compiled per (any-hit, counting, BVH staged in LDS) and, for the any-hit ones, per "the scene has translucent
+// materials" (RENDER_SPEC 7.1d: the ALPHA variants carry the texture fetch that decides whether a flagged triangle blocks); all launch-time constants
 void launch_trace_batch(const LaunchCfg& lc, const SceneView& sv, const hala_ray* rays, hala_hit* hits, const uint32_t* n_ptr,
                         uint32_t n_imm, WorkCounters* work, Control* ctl, bool any, bool count, bool account, hipStream_t s) {
   const int acc = account ? 1 : 0;
   using Fn = void (*)(const LaunchCfg&, const SceneView&, const hala_ray*, hala_hit*, const uint32_t*, uint32_t, WorkCounters*, Control*, int, size_t,
                       hipStream_t);
-  static const Fn table[8] = {launch_trace_batch_t<false, false, false>, launch_trace_batch_t<false, false, true>,
-                              launch_trace_batch_t<false, true, false>,  launch_trace_batch_t<false, true, true>,
-                              launch_trace_batch_t<true, false, false>,  launch_trace_batch_t<true, false, true>,
-                              launch_trace_batch_t<true, true, false>,   launch_trace_batch_t<true, true, true>};
+  static const Fn table[12] = {launch_trace_batch_t<false, false, false, false>, launch_trace_batch_t<false, false, true, false>,
+                               launch_trace_batch_t<false, true, false, false>,  launch_trace_batch_t<false, true, true, false>,
+                               launch_trace_batch_t<true, false, false, false>,  launch_trace_batch_t<true, false, true, false>,
+                               launch_trace_batch_t<true, true, false, false>,   launch_trace_batch_t<true, true, true, false>,
+                               launch_trace_batch_t<true, false, false, true>,   launch_trace_batch_t<true, false, true, true>,
+                               launch_trace_batch_t<true, true, false, true>,    launch_trace_batch_t<true, true, true, true>};
   SceneView sva = sv;
   if (any) sva.tris = sv.tris_any;  // RENDER_SPEC 7.1d
-  table[(any ? 4 : 0) | (count ? 2 : 0) | (sv.staged ? 1 : 0)](lc, sva, rays, hits, n_ptr, n_imm, work, ctl, acc, traverse_smem(sv), s);
+  const int base = any ? (sv.any_translucent ? 8 : 4) : 0;
+  table[base | (count ? 2 : 0) | (sv.staged ? 1 : 0)](lc, sva, rays, hits, n_ptr, n_imm, work, ctl, acc, traverse_smem(sv), s);
 }
 
+template <bool COUNT, bool STAGED, bool ALPHA>
+static void launch_trace_shadow_t(const LaunchCfg& lc, const SceneView& sv, const Queues& q, const PathState& ps, Control* ctl, uint32_t depth, uint32_t kind,
+                                  size_t smem, hipStream_t s) {
+  hipLaunchKernelGGL((k_trace_shadow<COUNT, STAGED, ALPHA>), dim3(lc.persistent_blocks), dim3(kTraverseThreads), smem, s, sv, q, ps, ctl, depth, kind, lc.spill, lc.refill);
+}
 void launch_trace_shadow(const LaunchCfg& lc, const SceneView& sv0, const Queues& q, const PathState& ps, Control* ctl, uint32_t depth,
                          uint32_t kind, bool count, hipStream_t s) {
-  const size_t smem = traverse_smem(sv0);
   SceneView sv = sv0;
-  sv.tris = sv0.tris_any;  // RENDER_SPEC 7.1d: shadow rays traverse the copy in which invisible surfaces are degenerate
-  dim3 grid(lc.persistent_blocks), block(kTraverseThreads);
-  if (sv.staged) {
-    if (count) hipLaunchKernelGGL((k_trace_shadow<true, true>), grid, block, smem, s, sv, q, ps, ctl, depth, kind, lc.spill, lc.refill);
-    else hipLaunchKernelGGL((k_trace_shadow<false, true>), grid, block, smem, s, sv, q, ps, ctl, depth, kind, lc.spill, lc.refill);
-  } else {
-    if (count) hipLaunchKernelGGL((k_trace_shadow<true, false>), grid, block, smem, s, sv, q, ps, ctl, depth, kind, lc.spill, lc.refill);
-    else hipLaunchKernelGGL((k_trace_shadow<false, false>), grid, block, smem, s, sv, q, ps, ctl, depth, kind, lc.spill, lc.refill);
-  }
+  sv.tris = sv0.tris_any;  // RENDER_SPEC 7.1d: shadow rays traverse the copy in which invisible surfaces are degenerate and translucent ones flagged
+  using Fn = void (*)(const LaunchCfg&, const SceneView&, const Queues&, const PathState&, Control*, uint32_t, uint32_t, size_t, hipStream_t);
+  static const Fn table[8] = {launch_trace_shadow_t<false, false, false>, launch_trace_shadow_t<false, true, false>, launch_trace_shadow_t<true, false, false>,
+                              launch_trace_shadow_t<true, true, false>,   launch_trace_shadow_t<false, false, true>, launch_trace_shadow_t<false, true, true>,
+                              launch_trace_shadow_t<true, false, true>,   launch_trace_shadow_t<true, true, true>};
+  table[(sv.any_translucent ? 4 : 0) | (count ? 2 : 0) | (sv.staged ? 1 : 0)](lc, sv, q, ps, ctl, depth, kind, traverse_smem(sv0), s);
 }
 
 void launch_trace_primary(const LaunchCfg& lc, const SceneView& sv, const FrameConst& fc, hala_hit* hits, WorkCounters* work, Control* ctl,

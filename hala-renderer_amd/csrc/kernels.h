@@ -44,8 +44,9 @@ struct BvhBuffers {
   // outputs (device, allocated by the caller)
   Tri* tris_by_id;         // [tri_count]
   Tri* tris;               // [tri_count] BVH order
-  Tri* tris_any = nullptr; // [tri_count] BVH order, triangles of opacity-0 materials degenerate; null: the scene has none
-  const hala_gpu_material* materials = nullptr;  // for tris_any
+  Tri* tris_any = nullptr; // [tri_count] BVH order: triangles of invisible materials degenerate, of translucent ones flagged (RENDER_SPEC 7.1d);
+                           // null: the scene has neither
+  const uint8_t* material_any_class = nullptr;  // per material: 0 blocks always, 1 invisible, 2 translucent (for tris_any)
   uint32_t material_count = 0;
   ShadeTri* shade_tris;    // [tri_count] global-id order
   uint32_t* tri_instance;  // [tri_count]

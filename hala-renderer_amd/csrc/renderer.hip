@@ -172,7 +172,10 @@ struct hala_rt_renderer {
   int ring_pos = 0;
   bool vertices_dirty = false;  // hala_rt_update_vertices since the last refit
   bool materials_dirty_any = false;  // a material edit touched an opacity-0 material (old or new)
-  bool any_invisible = false;   // the scene has materials of opacity 0: the any-hit launches traverse d_tris_any (RENDER_SPEC 7.1d)
+  bool any_invisible = false;   // the scene has invisible or translucent materials: the any-hit launches traverse d_tris_any (RENDER_SPEC 7.1d)
+  bool any_translucent = false; // ... translucent ones: the ALPHA variants of the any-hit kernels
+  DeviceArray<uint8_t> d_material_any_class;
+  std::vector<uint8_t> material_any_class;
   uint32_t launch_event_period = 1;  // per-launch timing events on every n-th update (hala_rt_set_launch_timing_period)
   unsigned long long update_counter = 0;
   hala_rt_statistics stats{};
@@ -222,7 +225,7 @@ struct hala_rt_renderer {
     sv.nodes = d_nodes.ptr; sv.tris = d_tris.ptr; sv.tris_any = any_invisible ? d_tris_any.ptr : d_tris.ptr; sv.tris_by_id = d_tris_by_id.ptr; sv.shade_tris = d_shade_tris.ptr; sv.tri_instance = d_tri_instance.ptr;
     sv.inst_first_tri = d_inst_first_tri.ptr; sv.primitives = d_instances.ptr; sv.materials = d_materials.ptr; sv.material_kind = d_material_kind.ptr;
     sv.lights = d_lights.ptr; sv.cameras = d_cameras.ptr;
-    sv.textures = d_textures.ptr; sv.tex_arena = d_tex_arena.ptr; sv.texture_count = (uint32_t)host_textures.size(); sv.shade_sort = shade_sort ? 1u : 0u; sv.simple_materials = simple_materials ? 1u : 0u;
+    sv.textures = d_textures.ptr; sv.tex_arena = d_tex_arena.ptr; sv.texture_count = (uint32_t)host_textures.size(); sv.shade_sort = shade_sort ? 1u : 0u; sv.simple_materials = simple_materials ? 1u : 0u; sv.any_translucent = any_translucent ? 1u : 0u;
     sv.env_pixels = reinterpret_cast<const float*>(d_env.ptr); sv.env_marginal = d_marginal.ptr; sv.env_conditional = d_conditional.ptr;
     sv.node_count = bvh.node_count; sv.tri_count = bvh.tri_count; sv.lds_nodes = lds_nodes; sv.lds_tris = lds_tris;
     sv.ray_eps = ray_eps;
@@ -502,11 +505,21 @@ int configure_traversal(hala_rt_renderer* r) {
 
 // RENDER_SPEC 7.1d: scenes with opacity-0 materials get a second copy of the BVH-order triangles for the any-hit launches
 int attach_any_triangles(hala_rt_renderer* r) {
-  r->any_invisible = false;
-  for (const auto& m : r->hs.materials) r->any_invisible = r->any_invisible || m.opacity == 0.0f;
+  const HostScene& hs = r->hs;
+  std::vector<uint8_t> cls(hs.gpu_materials.size());
+  r->any_invisible = false; r->any_translucent = false;
+  for (size_t i = 0; i < cls.size(); ++i) {
+    const hala_gpu_material& m = hs.gpu_materials[i];
+    const bool cutout = m.base_color_map_index < hs.texture_image.size() && hs.images[hs.texture_image[m.base_color_map_index]].has_alpha;
+    cls[i] = any_class_of(m, cutout);
+    r->any_invisible = r->any_invisible || cls[i] != 0;
+    r->any_translucent = r->any_translucent || cls[i] == 2;
+  }
+  r->material_any_class = cls;
+  RT_HIP(r->d_material_any_class.upload(cls.data(), cls.size(), r->stream));
   if (r->any_invisible) RT_HIP(r->d_tris_any.resize(r->hs.triangle_count));
   r->bvh.tris_any = r->any_invisible ? r->d_tris_any.ptr : nullptr;
-  r->bvh.materials = r->d_materials.ptr;
+  r->bvh.material_any_class = r->d_material_any_class.ptr;
   r->bvh.material_count = (uint32_t)r->hs.gpu_materials.size();
   return HALA_OK;
 }
@@ -1249,7 +1262,9 @@ int hala_rt_refit(hala_rt_renderer* r) {
   r->bvh.primitives = r->d_instances.ptr; r->bvh.inst_first_tri = r->d_inst_first_tri.ptr;
   // only cameras / lights moved (the interactive case: a camera node): the geometry and its tree stand as they are
   const bool had_invisible = r->any_invisible;
+  const std::vector<uint8_t> classes_before = r->material_any_class;
   if (attach_any_triangles(r) != HALA_OK) return HALA_ERR;
+  if (classes_before != r->material_any_class) r->materials_dirty_any = true;  // the any-hit copy of the triangles must be rewritten
   // (a material edit can change which triangles the shadow rays see: their copy is rewritten by the refit pass)
   bool geometry_moved = r->vertices_dirty || r->materials_dirty_any || had_invisible != r->any_invisible || before.size() != r->hs.instances.size();
   r->materials_dirty_any = false;

@@ -486,6 +486,28 @@ RT_DI float tex_lod(const SceneView& sv, uint32_t tex, float lod_base) {
   return lod_base + 0.5f * log2_approx((float)td.width * (float)td.height);
 }
 
+// RENDER_SPEC 7.1d: what decides whether a translucent triangle blocks an any-hit ray: the material's opacity times the alpha of its
+// base-colour map (bilinear fetch of level 0 at the hit's interpolated texture coordinates)
+RT_DI float hit_alpha(const SceneView& sv, uint32_t prim, float u, float v) {
+  const float4* sp = reinterpret_cast<const float4*>(sv.shade_tris + prim);
+  const uint32_t material = __float_as_uint(sp[1].w);
+  const hala_gpu_material& m = sv.materials[material];
+  float alpha = m.opacity;
+  const uint32_t tex = m.base_color_map_index;
+  if (tex < sv.texture_count) {
+    const float4 s4 = sp[4], s5 = sp[5];
+    const float w0 = 1.0f - u - v;
+    const float tu = __fmaf_rn(s5.x, v, __fmaf_rn(s4.z, u, s4.x * w0));
+    const float tv = __fmaf_rn(s5.y, v, __fmaf_rn(s4.w, u, s4.y * w0));
+    alpha = alpha * tex_bilinear(sv, sv.textures[tex], 0u, tu, tv).w;
+  }
+  return alpha;
+}
+RT_DI bool any_hit_blocks(const SceneView& sv, uint32_t key, uint32_t prim, float u, float v) {
+  const float x = (float)(pcg_hash(key + prim * 0x9E3779B1u) >> 8) * (1.0f / 16777216.0f);
+  return x < hit_alpha(sv, prim, u, v);
+}
+
 struct Surface {
   f3 P, ns, ng;
   MatView mat;

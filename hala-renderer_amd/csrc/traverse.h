@@ -126,9 +126,10 @@ struct Trav {
   HitRec best;
   uint32_t cur;
   int sp;
+  uint32_t key;  // any-hit rays: decides which translucent triangles block this ray (RENDER_SPEC 7.1d)
 };
-RT_DI void trav_begin(Trav& t, const RayPre& r, float tmax) {
-  t.r = r; t.tmax = tmax;
+RT_DI void trav_begin(Trav& t, const RayPre& r, float tmax, uint32_t key) {
+  t.r = r; t.tmax = tmax; t.key = key;
   t.best.t = tmax; t.best.u = 0.0f; t.best.v = 0.0f; t.best.prim = kAbsent;
   t.cur = 0; t.sp = 0;
 }
@@ -176,8 +177,8 @@ RT_DI void tri_test2(const RayPre& r, float4 a0, float4 b0, float4 c0, float4 a1
 // LDS-staged scenes: closest-hit / any-hit test of one leaf (count <= 8 triangles from `first`, storage order; fetched and tested
 // two at a time on the packed FP32 pipe: a leaf costs ceil(count/2) LDS round trips and ceil(count/2) packed tests; 4 waves/SIMD,
 // 128 VGPRs).  ANY: true on the first accepted triangle.
-template <bool ANY>
-RT_DI bool leaf_test_staged(const TraverseLds& lds, const RayPre& r, float tmax, HitRec& best, uint32_t first, uint32_t count) {
+template <bool ANY, bool ALPHA>
+RT_DI bool leaf_test_staged(const SceneView& sv, const TraverseLds& lds, const RayPre& r, float tmax, uint32_t key, HitRec& best, uint32_t first, uint32_t count) {
   for (uint32_t i = 0; i < count; i += 2u) {
     const bool two = i + 1u < count;
     const RT_LDS f32x4* p = lds.tris + (size_t)(first + i) * 3;
@@ -191,7 +192,10 @@ RT_DI bool leaf_test_staged(const TraverseLds& lds, const RayPre& r, float tmax,
       if (!ok[j] || (j == 1 && !two)) continue;
       const uint32_t id = __float_as_uint(j ? a1.w : a0.w);
       if (ANY) {
-        if (tt[j] > r.tmin && tt[j] < tmax) { best.t = tt[j]; best.u = uu[j]; best.v = vv[j]; best.prim = id; return true; }
+        if (tt[j] > r.tmin && tt[j] < tmax) {
+          if (ALPHA && __float_as_uint(j ? b1.w : b0.w) != 0u && !any_hit_blocks(sv, key, id, uu[j], vv[j])) continue;  // translucent: let through
+          best.t = tt[j]; best.u = uu[j]; best.v = vv[j]; best.prim = id; return true;
+        }
       } else if (tt[j] > r.tmin && (tt[j] < best.t || (tt[j] == best.t && id < best.prim))) {
         best.t = tt[j]; best.u = uu[j]; best.v = vv[j]; best.prim = id;
       }
@@ -224,7 +228,7 @@ RT_DI float lane_read(uint32_t src_lane_x4, float v) {  // v of lane src_lane_x4
 //   owner                         -> reads its slot back.
 // A per-lane leaf loop ran at 4-6 of 64 lanes on the 1 M-triangle scene (1.4-1.6 passes of <= 2 sequential triangle tests per wave
 // step, each with its own dependent fetch); dealt out, a wave step has ONE pass of one triangle test at ~4x the lanes.
-template <bool ANY, bool COUNT, bool STAGED>
+template <bool ANY, bool COUNT, bool STAGED, bool ALPHA>
 RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, Trav& t, bool has, StepCounters& sc) {
   constexpr int kS = stack_lds<STAGED>();
   RT_LDS u32x2* stack = lds.stack + threadIdx.x;
@@ -312,7 +316,7 @@ RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, 
         sc.leaf_lanes++;
         if ((uint32_t)__ffsll((long long)m) - 1u == (threadIdx.x & 63u)) sc.leaf_passes++;
       }
-      if (leaf_test_staged<ANY>(lds, r, t.tmax, best, ref[k] & 0x0fffffffu, ((ref[k] >> 28) & 7u) + 1u)) { found = true; break; }
+      if (leaf_test_staged<ANY, ALPHA>(sv, lds, r, t.tmax, t.key, best, ref[k] & 0x0fffffffu, ((ref[k] >> 28) & 7u) + 1u)) { found = true; break; }
     }
   } else {
     const uint32_t lane = threadIdx.x & 63u;
@@ -342,6 +346,7 @@ RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, 
         const f3 d = mk3(lane_read(src, r.d.x), lane_read(src, r.d.y), lane_read(src, r.d.z));
         const float tmin = lane_read(src, r.tmin);
         const float tlim = ANY ? lane_read(src, t.tmax) : 0.0f;
+        const uint32_t okey_any = (ANY && ALPHA) ? __float_as_uint(lane_read(src, __uint_as_float(t.key))) : 0u;
         if (COUNT) {
           const unsigned long long m = __ballot(valid);
           if (valid) sc.leaf_lanes++;
@@ -356,7 +361,9 @@ RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, 
           asm volatile("" ::"v"(a.w));  // the id travels with v0 (one dwordx4), not as a dependent dword load inside the hit branch
           float tt;
           if (tri_test_od(o, d, a, b, c, &tt, &tu, &tv) && tt > tmin) {
-            if (ANY) { if (tt < tlim) *(RT_LDS uint32_t*)okey = 0u; }  // any accepted triangle: the owner's prim field leaves kAbsent
+            if (ANY) {  // any blocking triangle: the owner's prim field leaves kAbsent
+              if (tt < tlim && !(ALPHA && __float_as_uint(b.w) != 0u && !any_hit_blocks(sv, okey_any, __float_as_uint(a.w), tu, tv))) *(RT_LDS uint32_t*)okey = 0u;
+            }
             else {
               mine = ((unsigned long long)__float_as_uint(tt) << 32) | (unsigned long long)__float_as_uint(a.w);
               __hip_atomic_fetch_min(okey, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);

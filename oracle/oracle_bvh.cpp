@@ -226,6 +226,7 @@ extern "C" orc_scene* orc_scene_create(const orc_scene_desc* desc) {
     uint32_t m = std::max(im.width, im.height), p2 = 1, lg = 0;
     while (p2 < m) { p2 <<= 1; ++lg; }
     img.mips = std::min<uint32_t>(lg + 1, 16);  // gpu_uploader.rs:366
+    for (size_t i = 0; i < n; ++i) img.has_alpha = img.has_alpha || l0[4 * i + 3] < 1.0f;  // RENDER_SPEC 7.1d (NaN: not a cut-out)
     img.levels.push_back(std::move(l0));
     for (uint32_t l = 1; l < img.mips; ++l) {
       const uint32_t sw = std::max(1u, im.width >> (l - 1)), sh = std::max(1u, im.height >> (l - 1));
@@ -319,8 +320,14 @@ static inline bool tri_test(const RayPre& r, const Tri& tr, float* t, float* u, 
   return true;
 }
 
+// RENDER_SPEC 7.1d: a flagged (translucent) triangle blocks an any-hit ray iff hash(key, triangle) < opacity x alpha at the hit
+bool any_hit_blocks(const AnyCtx* ax, const Tri& tr, float u, float v) {
+  if (!tr.pad1 || !ax) return true;
+  const float x = (float)(pcg_hash(ax->key + tr.id * 0x9E3779B1u) >> 8) * (1.0f / 16777216.0f);
+  return x < hit_alpha(ax->s, tr.id, u, v);
+}
 template <bool ANY>
-static inline bool traverse(const Node* nodes, const Tri* tris, const RayPre& r, float tmax, Hit* best, Counters* c) {
+static inline bool traverse(const Node* nodes, const Tri* tris, const RayPre& r, float tmax, const AnyCtx* ax, Hit* best, Counters* c) {
   best->t = tmax; best->prim = ORC_NONE; best->u = 0.0f; best->v = 0.0f;
   uint32_t stack[1024]; int sp = 0;
   uint32_t cur = 0;
@@ -349,7 +356,7 @@ static inline bool traverse(const Node* nodes, const Tri* tris, const RayPre& r,
           float t, u, v;
           if (!tri_test(r, tr, &t, &u, &v)) continue;
           if (ANY) {
-            if (t > r.tmin && t < tmax) { best->t = t; best->prim = tr.id; best->u = u; best->v = v; return true; }
+            if (t > r.tmin && t < tmax && any_hit_blocks(ax, tr, u, v)) { best->t = t; best->prim = tr.id; best->u = u; best->v = v; return true; }
           } else {
             if (t > r.tmin && (t < best->t || (t == best->t && tr.id < best->prim))) { best->t = t; best->u = u; best->v = v; best->prim = tr.id; }
           }
@@ -372,13 +379,13 @@ static inline float bits_f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 static inline uint32_t f_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 
 template <bool ANY>
-static inline bool leaf_test(const Tri* tris, const RayPre& r, float tmax, Hit* best, uint32_t first, uint32_t count) {
+static inline bool leaf_test(const Tri* tris, const RayPre& r, float tmax, const AnyCtx* ax, Hit* best, uint32_t first, uint32_t count) {
   for (uint32_t i = 0; i < count; ++i) {
     const Tri& tr = tris[first + i];
     float t, u, v;
     if (!tri_test(r, tr, &t, &u, &v)) continue;
     if (ANY) {
-      if (t > r.tmin && t < tmax) { best->t = t; best->prim = tr.id; best->u = u; best->v = v; return true; }
+      if (t > r.tmin && t < tmax && any_hit_blocks(ax, tr, u, v)) { best->t = t; best->prim = tr.id; best->u = u; best->v = v; return true; }
     } else if (t > r.tmin && (t < best->t || (t == best->t && tr.id < best->prim))) {
       best->t = t; best->u = u; best->v = v; best->prim = tr.id;
     }
@@ -404,7 +411,7 @@ static inline float key_tn(uint32_t key) { return bits_f(key & ~3u); }
 constexpr size_t kSmallTreeBytes = 40 * 1024;  // RENDER_SPEC 4.4b: node_count * 64 + triangle_count * 48 <= this -> sequential leaf culling
 static inline bool is_small_tree(size_t node_count, size_t tri_count) { return node_count * 64 + tri_count * 48 <= kSmallTreeBytes; }
 template <bool ANY>
-static inline bool traverse4(const Node4* nodes, const Tri* tris, bool small_tree, const RayPre& r, float tmax, Hit* best, Counters* c) {
+static inline bool traverse4(const Node4* nodes, const Tri* tris, bool small_tree, const RayPre& r, float tmax, const AnyCtx* ax, Hit* best, Counters* c) {
   best->t = tmax; best->prim = ORC_NONE; best->u = 0.0f; best->v = 0.0f;
   struct Entry { uint32_t key, ref; };
   Entry stack[1024]; int sp = 0;
@@ -451,7 +458,7 @@ static inline bool traverse4(const Node4* nodes, const Tri* tris, bool small_tre
       if (!(key_tn(e[i].key) <= (small_tree ? best->t : reach))) continue;
       uint32_t count = ((rf >> 28) & 7u) + 1u;
       if (c) c->tris += count;
-      if (!occluded && leaf_test<ANY>(tris, r, tmax, best, rf & 0x0fffffffu, count)) occluded = true;
+      if (!occluded && leaf_test<ANY>(tris, r, tmax, ax, best, rf & 0x0fffffffu, count)) occluded = true;
       if (occluded && small_tree) return true;
     }
     if (occluded) return true;
@@ -468,40 +475,49 @@ static inline bool traverse4(const Node4* nodes, const Tri* tris, bool small_tre
 Hit trace_closest(const Node* nodes, const Tri* tris, V3 o, V3 d, float tmin, float tmax, Counters* c) {
   RayPre r = make_ray(o, d, tmin);
   Hit h;
-  if (!traverse<false>(nodes, tris, r, tmax, &h, c)) { h.t = -1.0f; h.u = 0.0f; h.v = 0.0f; h.prim = ORC_NONE; }
+  if (!traverse<false>(nodes, tris, r, tmax, nullptr, &h, c)) { h.t = -1.0f; h.u = 0.0f; h.v = 0.0f; h.prim = ORC_NONE; }
   return h;
 }
-bool trace_any(const Node* nodes, const Tri* tris, V3 o, V3 d, float tmin, float tmax, Counters* c) {
+bool trace_any(const Node* nodes, const Tri* tris, V3 o, V3 d, float tmin, float tmax, const AnyCtx* ax, Counters* c) {
   RayPre r = make_ray(o, d, tmin);
   Hit h;
-  return traverse<true>(nodes, tris, r, tmax, &h, c);
+  return traverse<true>(nodes, tris, r, tmax, ax, &h, c);
 }
 Hit scene_trace_closest(const orc_scene* s, V3 o, V3 d, float tmin, float tmax, Counters* c) {
   if (s->ext_nodes.empty()) return trace_closest(s->nodes.data(), s->tris.data(), o, d, tmin, tmax, c);
   RayPre r = make_ray(o, d, tmin);
   Hit h;
-  if (!traverse4<false>(s->ext_nodes.data(), s->ext_tris.data(), is_small_tree(s->ext_nodes.size(), s->ext_tris.size()), r, tmax, &h, c)) { h.t = -1.0f; h.u = 0.0f; h.v = 0.0f; h.prim = ORC_NONE; }
+  if (!traverse4<false>(s->ext_nodes.data(), s->ext_tris.data(), is_small_tree(s->ext_nodes.size(), s->ext_tris.size()), r, tmax, nullptr, &h, c)) { h.t = -1.0f; h.u = 0.0f; h.v = 0.0f; h.prim = ORC_NONE; }
   return h;
 }
-// RENDER_SPEC 7.1d: shadow rays do not see surfaces of opacity exactly 0
-bool invisible(const orc_scene* s, uint32_t tri_id) {
-  const uint32_t mi = s->instances[s->tri_instance[tri_id]].material_index;
-  return mi < s->materials.size() && s->materials[mi].opacity == 0.0f;
+// RENDER_SPEC 7.1d: how an any-hit ray treats the triangles of a material
+int any_class(const orc_scene* s, uint32_t mi) {
+  if (mi >= s->materials.size()) return 0;
+  const orc_gpu_material& m = s->materials[mi];
+  if (m.opacity == 0.0f) return 1;
+  if (m.opacity < 1.0f) return 2;
+  if (m.base_color_map_index < s->texture_image.size() && s->images[s->texture_image[m.base_color_map_index]].has_alpha) return 2;
+  return 0;
 }
+bool invisible(const orc_scene* s, uint32_t tri_id) { return any_class(s, s->instances[s->tri_instance[tri_id]].material_index) == 1; }
 void make_any_triangles(const orc_scene* s, const std::vector<Tri>& in, std::vector<Tri>* out) {
   out->clear();
   bool some = false;
-  for (const auto& m : s->materials) some = some || m.opacity == 0.0f;
+  for (uint32_t mi = 0; mi < s->materials.size(); ++mi) some = some || any_class(s, mi) != 0;
   if (!some) return;
   *out = in;
-  for (Tri& t : *out)
-    if (invisible(s, t.id)) { t.e1[0] = t.e1[1] = t.e1[2] = 0.0f; t.e2[0] = t.e2[1] = t.e2[2] = 0.0f; }
+  for (Tri& t : *out) {
+    const int k = any_class(s, s->instances[s->tri_instance[t.id]].material_index);
+    if (k == 1) { t.e1[0] = t.e1[1] = t.e1[2] = 0.0f; t.e2[0] = t.e2[1] = t.e2[2] = 0.0f; }
+    t.pad1 = k == 2 ? 1u : 0u;
+  }
 }
-bool scene_trace_any(const orc_scene* s, V3 o, V3 d, float tmin, float tmax, Counters* c) {
-  if (s->ext_nodes.empty()) return trace_any(s->nodes.data(), (s->tris_any.empty() ? s->tris : s->tris_any).data(), o, d, tmin, tmax, c);
+bool scene_trace_any(const orc_scene* s, V3 o, V3 d, float tmin, float tmax, uint32_t key, Counters* c) {
+  const AnyCtx ax{s, key};
+  if (s->ext_nodes.empty()) return trace_any(s->nodes.data(), (s->tris_any.empty() ? s->tris : s->tris_any).data(), o, d, tmin, tmax, &ax, c);
   RayPre r = make_ray(o, d, tmin);
   Hit h;
-  return traverse4<true>(s->ext_nodes.data(), (s->ext_tris_any.empty() ? s->ext_tris : s->ext_tris_any).data(), is_small_tree(s->ext_nodes.size(), s->ext_tris.size()), r, tmax, &h, c);
+  return traverse4<true>(s->ext_nodes.data(), (s->ext_tris_any.empty() ? s->ext_tris : s->ext_tris_any).data(), is_small_tree(s->ext_nodes.size(), s->ext_tris.size()), r, tmax, &ax, &h, c);
 }
 }  // namespace orc
 
@@ -514,7 +530,7 @@ extern "C" void orc_scene_use_bvh4(orc_scene* s, const void* nodes64, uint32_t n
   orc::make_any_triangles(s, s->ext_tris, &s->ext_tris_any);
 }
 
-static void trace_batch(const Node* nodes, const Tri* tris, const orc_ray* rays, orc_hit* hits, uint32_t count, int mode, uint64_t* counters) {
+static void trace_batch(const orc_scene* s, const Node* nodes, const Tri* tris, const orc_ray* rays, orc_hit* hits, uint32_t count, int mode, uint64_t* counters) {
   uint64_t cn = 0, ct = 0;
 #pragma omp parallel for schedule(dynamic, 4096) reduction(+ : cn, ct)
   for (int64_t i = 0; i < (int64_t)count; ++i) {
@@ -525,7 +541,8 @@ static void trace_batch(const Node* nodes, const Tri* tris, const orc_ray* rays,
       Hit h = trace_closest(nodes, tris, o, d, r.tmin, r.tmax, &c);
       hits[i].t = h.t; hits[i].u = h.u; hits[i].v = h.v; hits[i].prim = h.prim;
     } else {
-      bool occ = trace_any(nodes, tris, o, d, r.tmin, r.tmax, &c);
+      const AnyCtx ax{s, pcg_hash((uint32_t)i ^ kAnyKeyBatch)};  // RENDER_SPEC 7.1d: the key of ray i of a batch
+      bool occ = trace_any(nodes, tris, o, d, r.tmin, r.tmax, &ax, &c);
       hits[i].t = occ ? 1.0f : -1.0f; hits[i].u = 0.0f; hits[i].v = 0.0f; hits[i].prim = ORC_NONE;
     }
     cn += c.nodes; ct += c.tris;
@@ -534,7 +551,7 @@ static void trace_batch(const Node* nodes, const Tri* tris, const orc_ray* rays,
 }
 
 extern "C" void orc_trace_rays(const orc_scene* s, const orc_ray* rays, orc_hit* hits, uint32_t count, int mode, uint64_t* counters) {
-  trace_batch(s->nodes.data(), (mode == 1 && !s->tris_any.empty() ? s->tris_any : s->tris).data(), rays, hits, count, mode, counters);
+  trace_batch(s, s->nodes.data(), (mode == 1 && !s->tris_any.empty() ? s->tris_any : s->tris).data(), rays, hits, count, mode, counters);
 }
 extern "C" void orc_trace_rays_on_bvh4(const void* nodes64, uint32_t node_count, const void* tris48, uint32_t tri_count, const orc_ray* rays,
                                        orc_hit* hits, uint32_t count, int mode, uint64_t* counters) {
@@ -549,10 +566,10 @@ extern "C" void orc_trace_rays_on_bvh4(const void* nodes64, uint32_t node_count,
     RayPre r = make_ray(v3(ry.origin[0], ry.origin[1], ry.origin[2]), v3(ry.direction[0], ry.direction[1], ry.direction[2]), ry.tmin);
     Hit h;
     if (mode == 0) {
-      if (traverse4<false>(nodes, tris, small_tree, r, ry.tmax, &h, &c)) hits[i] = orc_hit{h.t, h.u, h.v, h.prim};
+      if (traverse4<false>(nodes, tris, small_tree, r, ry.tmax, nullptr, &h, &c)) hits[i] = orc_hit{h.t, h.u, h.v, h.prim};
       else hits[i] = orc_hit{-1.0f, 0.0f, 0.0f, ORC_NONE};
     } else {
-      hits[i] = orc_hit{traverse4<true>(nodes, tris, small_tree, r, ry.tmax, &h, &c) ? 1.0f : -1.0f, 0.0f, 0.0f, ORC_NONE};
+      hits[i] = orc_hit{traverse4<true>(nodes, tris, small_tree, r, ry.tmax, nullptr, &h, &c) ? 1.0f : -1.0f, 0.0f, 0.0f, ORC_NONE};
     }
     cn += c.nodes; ct += c.tris;
   }
@@ -569,7 +586,12 @@ extern "C" void orc_trace_rays_brute(const orc_scene* s, const orc_ray* rays, or
     for (const Tri& tr : s->tris_by_id) {
       float t, u, v;
       if (!tri_test(r, tr, &t, &u, &v)) continue;
-      if (mode == 1) { if (t > r.tmin && t < ry.tmax && !orc::invisible(s, tr.id)) { any = true; break; } }  // RENDER_SPEC 7.1d
+      if (mode == 1) {  // RENDER_SPEC 7.1d
+        const int k = orc::any_class(s, s->instances[s->tri_instance[tr.id]].material_index);
+        Tri flagged = tr; flagged.pad1 = k == 2 ? 1u : 0u;
+        const AnyCtx ax{s, pcg_hash((uint32_t)i ^ kAnyKeyBatch)};
+        if (t > r.tmin && t < ry.tmax && k != 1 && any_hit_blocks(&ax, flagged, u, v)) { any = true; break; }
+      }
       else if (t > r.tmin && (t < best.t || (t == best.t && tr.id < best.prim))) best = Hit{t, u, v, tr.id};
     }
     if (mode == 1) hits[i] = orc_hit{any ? 1.0f : -1.0f, 0.0f, 0.0f, ORC_NONE};

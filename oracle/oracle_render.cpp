@@ -488,6 +488,29 @@ static inline V3 transform_vector(const float* m, V3 p) {
   return v3(fmaf(m[8], p.z, fmaf(m[4], p.y, m[0] * p.x)), fmaf(m[9], p.z, fmaf(m[5], p.y, m[1] * p.x)), fmaf(m[10], p.z, fmaf(m[6], p.y, m[2] * p.x)));
 }
 
+// RENDER_SPEC 7.1d: what decides whether a translucent triangle blocks an any-hit ray: the material's opacity times the alpha of its
+// base-colour map, read with the bilinear fetch of level 0 at the hit's interpolated texture coordinates
+}  // namespace
+namespace orc {
+float hit_alpha(const orc_scene* s, uint32_t prim, float u, float v) {
+  const Instance& inst = s->instances[s->tri_instance[prim]];
+  const orc_gpu_material& m = s->materials[inst.material_index];
+  float alpha = m.opacity;
+  if (m.base_color_map_index < s->texture_image.size()) {
+    const uint32_t lt = prim - inst.first_triangle;
+    const orc_vertex& a = inst.vertices[inst.indices[3 * lt]];
+    const orc_vertex& b = inst.vertices[inst.indices[3 * lt + 1]];
+    const orc_vertex& c = inst.vertices[inst.indices[3 * lt + 2]];
+    const float w0 = 1.0f - u - v;
+    const float tu = fmaf(c.tex_coord[0], v, fmaf(b.tex_coord[0], u, a.tex_coord[0] * w0));
+    const float tv = fmaf(c.tex_coord[1], v, fmaf(b.tex_coord[1], u, a.tex_coord[1] * w0));
+    alpha = alpha * tex_bilinear(s->images[s->texture_image[m.base_color_map_index]], 0, tu, tv).w;
+  }
+  return alpha;
+}
+}  // namespace orc
+namespace {
+
 static Surface make_surface(const orc_scene* s, float pixel_spread, V3 o, V3 d, const Hit& h) {
   Surface sf;
   const Tri& tr = s->tris_by_id[h.prim];
@@ -667,7 +690,7 @@ static PixelOut trace_path(const Frame& f, uint32_t px, uint32_t py, uint32_t fr
           V3 so = madd3(sf.ng, side, sf.P);
           float tmax = ls.dist >= kTMax ? kTMax : maxf(ls.dist - 2.0f * s->ray_eps, 0.0f);
           st->rays_shadow++;
-          bool occ = scene_trace_any(s, so, ls.wi, 0.0f, tmax, ctr);
+          bool occ = scene_trace_any(s, so, ls.wi, 0.0f, tmax, pcg_hash(rng ^ kAnyKeyLight), ctr);  // §7.1d: the connection's key
           if (!occ) {
             float cosl = fabsf(dot3(sf.ns, ls.wi));
             V3 contrib;
@@ -693,7 +716,7 @@ static PixelOut trace_path(const Frame& f, uint32_t px, uint32_t py, uint32_t fr
           float side = dot3(wi, sf.ng) >= 0.0f ? s->ray_eps : -s->ray_eps;
           V3 so = madd3(sf.ng, side, sf.P);
           st->rays_shadow++;
-          bool occ = scene_trace_any(s, so, wi, 0.0f, kTMax, ctr);
+          bool occ = scene_trace_any(s, so, wi, 0.0f, kTMax, pcg_hash(rng ^ kAnyKeyEnv), ctr);
           if (!occ) {
             float cosl = fabsf(dot3(sf.ns, wi));
             float w = power_heuristic(pdf_e, pdf_b);

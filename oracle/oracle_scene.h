@@ -49,6 +49,7 @@ struct Instance {
 struct Image {
   uint32_t width = 0, height = 0, mips = 0;
   std::vector<std::vector<float>> levels;  // RGBA32F per level
+  bool has_alpha = false;                  // some texel of level 0 has alpha < 1 (RENDER_SPEC 7.1d: cut-out materials)
 };
 
 struct EnvMap {
@@ -67,7 +68,8 @@ struct orc_scene {
   std::vector<float> tri_verts9;       // world-space v0,v1,v2 per global id (RENDER_SPEC §3)
   std::vector<orc::Tri> tris;          // BVH order
   std::vector<orc::Tri> tris_any;      // RENDER_SPEC 7.1d: what the any-hit traversals see — the triangles of opacity-0 materials made
-                                       // degenerate (e1 = e2 = 0: never hit); empty when the scene has none (then `tris` serves both)
+                                       // degenerate (e1 = e2 = 0: never hit), those of translucent materials flagged (pad1 = 1);
+                                       // empty when the scene has neither (then `tris` serves both)
   std::vector<orc::Node> nodes;
   float bounds_min[3], bounds_max[3];
   float ray_eps;
@@ -90,12 +92,20 @@ struct Counters { uint64_t nodes = 0, tris = 0; };
 struct Hit { float t, u, v; uint32_t prim; };
 // RENDER_SPEC §4: closest / any traversal over (nodes, tris).
 Hit trace_closest(const Node* nodes, const Tri* tris, V3 o, V3 d, float tmin, float tmax, Counters* c);
-bool trace_any(const Node* nodes, const Tri* tris, V3 o, V3 d, float tmin, float tmax, Counters* c);
-// RENDER_SPEC 7.1d: `in` with the triangles of opacity-0 materials made degenerate (empty when the scene has none)
+// RENDER_SPEC 7.1d, any-hit rays: 0 = every hit blocks, 1 = invisible (opacity exactly 0), 2 = translucent (blocks with probability
+// opacity x base-colour-map alpha, decided per (ray key, triangle))
+int any_class(const orc_scene* s, uint32_t material_index);
 bool invisible(const orc_scene* s, uint32_t tri_id);
+// `in` with the triangles of invisible materials made degenerate and those of translucent ones flagged (empty when the scene has neither)
 void make_any_triangles(const orc_scene* s, const std::vector<Tri>& in, std::vector<Tri>* out);
+// what an any-hit ray needs to decide whether a flagged triangle blocks it
+struct AnyCtx { const orc_scene* s; uint32_t key; };
+float hit_alpha(const orc_scene* s, uint32_t prim, float u, float v);  // opacity x base-colour-map alpha (bilinear, level 0) at a hit
+bool any_hit_blocks(const AnyCtx* ax, const Tri& tr, float u, float v);
+bool trace_any(const Node* nodes, const Tri* tris, V3 o, V3 d, float tmin, float tmax, const AnyCtx* ax, Counters* c);
 // the same on the scene's tree of choice: the product's 4-wide tree if one was handed over, else the oracle's own BVH2
 Hit scene_trace_closest(const orc_scene* s, V3 o, V3 d, float tmin, float tmax, Counters* c);
-bool scene_trace_any(const orc_scene* s, V3 o, V3 d, float tmin, float tmax, Counters* c);
+bool scene_trace_any(const orc_scene* s, V3 o, V3 d, float tmin, float tmax, uint32_t key, Counters* c);
+constexpr uint32_t kAnyKeyLight = 0xA511E9B3u, kAnyKeyEnv = 0x63D83595u, kAnyKeyBatch = 0x5BD1E995u;
 V3 tonemap_select(V3 color, int enable_tonemap, int enable_aces, int use_simple_aces);
 }  // namespace orc

@@ -942,6 +942,49 @@ def test_invisible_surfaces_and_shadow_rays(halart, oracle):
     r.close()
 
 
+@pytest.mark.parametrize("big", [False, True])
+def test_translucent_shadow_rays_bit_exact(halart, oracle, big):
+    """RENDER_SPEC 7.1d, connections: sheets of opacity 0.6 with a cut-out (0 / 1 alpha checker) base-colour map between a quad light,
+    an env map and a floor.  Whether a sheet blocks a connection is decided per (connection key, triangle) from opacity x alpha at the
+    hit, so the image does not depend on the traversal: the LDS-staged kernels (each lane tests its own leaves) and the large-scene
+    kernels (`big`: a 5 120-triangle blob pushes the tree past the LDS budget; the wave tests leaves cooperatively)
+    must both equal the oracle bit for bit — images, any-hit ray batches, ray totals — also after a material edit + refit changes
+    which triangles are translucent."""
+    from test_oracle_render import sheet_over_floor_scene
+    s = sheet_over_floor_scene(opacity=0.6, alpha_checker=True, sheets=3)
+    if big:
+        blob = scenes.blob_mesh(subdivisions=4)
+        blob.material_index = 0
+        s.meshes.append(H.HalaMesh([blob]))
+        m = np.eye(4, dtype=np.float32); m[:3, :3] *= 0.5; m[:3, 3] = (1.5, 0.6, -1.0)
+        s.nodes.append(H.HalaNode(name="blob", mesh_index=len(s.meshes) - 1, local_transform=m))
+    env = scenes.sky_sun_envmap(64, 32, sun_gain=50.0)
+    r = make_renderer(halart, s, 64, 64, max_depth=4, rr_depth=2, env=env)
+    assert (r.bvh_info().lds_node_count == 0) == big
+    osc = oracle.OracleScene(s, envmap=env)
+    rays = random_rays(8000, np.array((-5, 0.05, -5.0)), np.array((5, 4, 5.0)), 7)
+    for mode in (0, 1):
+        assert r.trace_rays_host(rays, mode).tobytes() == osc.trace(rays, mode).tobytes(), mode
+    blocked = (r.trace_rays_host(rays, 1)["t"] > 0).sum()
+    assert 0 < blocked < (r.trace_rays_host(rays, 0)["prim"] != 0xFFFFFFFF).sum()  # some rays pass the sheets they hit
+    r.update(); r.update_batch(3); r.render()
+    imgs, st = osc.render(64, 64, frames=4, max_depth=4, rr_depth=2)
+    assert_images_equal(r, imgs)
+    stg = r.statistics()
+    assert (stg.rays_closest_total, stg.rays_shadow_total) == (st.rays_closest, st.rays_shadow)
+    # the sheets become ordinary opaque surfaces (no map, opacity 1): class 2 -> 0, the any-hit copy of the triangles is rewritten
+    solid = H.HalaMaterial(type=0, base_color=(1.0, 1.0, 1.0), roughness=0.5)
+    r.update_material(1, solid); r.refit()
+    s.materials[1] = solid
+    osc2 = oracle.OracleScene(s, envmap=env)
+    assert r.trace_rays_host(rays, 1).tobytes() == osc2.trace(rays, 1).tobytes()
+    r.update_batch(2); r.render()
+    imgs2, _ = osc2.render(64, 64, frames=2, max_depth=4, rr_depth=2)
+    assert_images_equal(r, imgs2)
+    assert float(np.abs(imgs2[0][..., :3] - imgs[0][..., :3]).mean()) > 1e-3
+    r.close()
+
+
 @pytest.mark.parametrize("boundary", ["glass", "invisible"])
 def test_render_scattering_medium_bit_exact(halart, oracle, boundary):
     """RENDER_SPEC 7.1f: free-flight sampling (polynomial log), Henyey-Greenstein scattering, no NEE at scattering vertices (the

@@ -457,3 +457,65 @@ def test_invisible_surfaces_do_not_block_shadow_rays(oracle):
     down = rays.copy(); down["origin"] = (0.0, 3.9, 0.0); down["direction"] = (0.0, -1.0, 0.0); down["tmin"] = 0.0; down["tmax"] = 3.8
     assert (fog.trace(down[:4], 1)["t"] < 0).all()       # straight through the ball: unoccluded for a shadow ray ...
     assert (fog.trace(down[:4], 0)["prim"] != 0xFFFFFFFF).all()  # ... while a closest-hit ray finds the boundary
+
+
+def sheet_over_floor_scene(opacity=1.0, alpha_checker=False, sheets=1):
+    """a quad light above a floor with `sheets` large horizontal sheets between them: material opacity `opacity`, optionally a
+    base-colour map whose alpha is a 16x16 checker of 0 / 1 (a cut-out); the camera sits below the sheets and looks at the floor"""
+    s = H.HalaScene()
+    floor = scenes._merge_quads([((-6, 0, 6), (6, 0, 6), (6, 0, -6), (-6, 0, -6))])
+    floor.material_index = 0
+    quads = [((-6, 2.0 + 0.2 * k, -6), (6, 2.0 + 0.2 * k, -6), (6, 2.0 + 0.2 * k, 6), (-6, 2.0 + 0.2 * k, 6)) for k in range(sheets)]
+    sheet = scenes._merge_quads(quads)
+    sheet.material_index = 1
+    s.materials = [H.HalaMaterial(type=0, base_color=(0.8, 0.8, 0.8), roughness=0.5),
+                   H.HalaMaterial(type=0, base_color=(1.0, 1.0, 1.0), roughness=0.5, opacity=opacity)]
+    if alpha_checker:
+        n = 64
+        yy, xx = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+        px = np.full((n, n, 4), 255, dtype=np.uint8)
+        px[..., 3] = np.where(((yy // 4) + (xx // 4)) % 2 == 0, 255, 0)
+        s.image_data = [H.HalaImageData(1, n, n, px)]  # HALA_FORMAT_R8G8B8A8_SRGB
+        s.image2data_mapping = {0: 0}; s.texture2image_mapping = {0: 0}
+        s.materials[1].base_color_map_index = 0
+    s.meshes = [H.HalaMesh([floor]), H.HalaMesh([sheet])]
+    s.nodes = [H.HalaNode(name="floor", mesh_index=0), H.HalaNode(name="sheet", mesh_index=1)]
+    lm = np.eye(4, dtype=f32); lm[:3, :3] = np.array([[1, 0, 0], [0, 0, -1], [0, 1, 0]], dtype=f32); lm[:3, 3] = (0.0, 4.0, 0.0)
+    s.nodes.append(H.HalaNode(name="light", light_index=0, local_transform=lm))
+    s.lights = [H.HalaLight(color=(1.0, 1.0, 1.0), intensity=20.0, light_type=3, params=(1.0, 1.0))]
+    s.nodes.append(H.HalaNode(name="cam", camera_index=0, local_transform=scenes.look_at_node_transform((0, 1.5, 2.5), (0, 0, 0))))
+    s.cameras = [H.HalaPerspectiveCamera(aspect=1.0, yfov=0.5)]
+    return s
+
+
+def test_translucent_surfaces_shadow_in_proportion(oracle):
+    """§7.1d, connections: a sheet of opacity a between light and floor lets a connection through with probability 1 - a (decided per
+    (connection key, triangle): independent of the traversal), so the directly lit floor is (1 - a) times as bright; two sheets
+    multiply; a base-colour map whose alpha is a half-covered 0 / 1 checker acts like opacity 1/2; opacity 1 is black, 0 unshadowed.
+    max_depth 1: direct light only; the camera sits below the sheets."""
+    kw = dict(frames=48, max_depth=1, rr_depth=64, ground=(0, 0, 0, 1), sky=(0, 0, 0, 1))
+
+    def lit(**scene_kw):
+        return float(oracle.OracleScene(sheet_over_floor_scene(**scene_kw)).render(32, 32, **kw)[0][0][8:24, 8:24, :3].mean())
+
+    ref = lit(opacity=0.0)
+    assert ref > 0.05
+    assert lit(opacity=1.0) == 0.0
+    for a in (0.25, 0.5, 0.8):
+        assert abs(lit(opacity=a) / ref - (1.0 - a)) < 0.04, a
+    assert abs(lit(opacity=0.5, sheets=2) / ref - 0.25) < 0.03
+    assert abs(lit(opacity=1.0, alpha_checker=True) / ref - 0.5) < 0.05
+    assert abs(lit(opacity=0.5, alpha_checker=True) / ref - 0.75) < 0.05
+
+
+def test_translucent_any_hit_is_traversal_independent(oracle):
+    """the blocking decision is a function of (ray key, triangle, alpha at the hit) only: the BVH traversal, whatever order it visits
+    the sheets in, agrees with brute force over all triangles, ray for ray"""
+    s = sheet_over_floor_scene(opacity=0.6, alpha_checker=True, sheets=5)
+    osc = oracle.OracleScene(s)
+    rays = random_rays(6000, np.array((-5, 0.05, -5.0)), np.array((5, 4, 5.0)), 5)
+    a, b = osc.trace(rays, 1), osc.trace(rays, 1, brute=True)
+    assert a.tobytes() == b.tobytes()
+    occluded = float((a["t"] > 0).mean())
+    solid = oracle.OracleScene(sheet_over_floor_scene(opacity=1.0, sheets=5)).trace(rays, 1)
+    assert 0.1 < occluded < float((solid["t"] > 0).mean())  # some connections get through five 0.3-opaque sheets
