@@ -173,11 +173,11 @@ def kernel_report(dt_stats, counts, staged):
                 "avg_launch_ms": round(avg, 5), "launches": int(launches), "rays_per_launch": round(rpl, 1),
                 "grays_per_s_in_kernel": round(rays / max(ms, 1e-9) / 1e6, 3), "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4)}
 
-    out["batch"] = entry(f"rt::k_trace_batch<false, false, {st}>", "closest-hit traversal of the bounce-ray queues (depth >= 1): 32 B ray read + 16 B hit write per ray",
+    out["batch"] = entry(f"rt::k_trace_batch<false, false, {st}, false>", "closest-hit traversal of the bounce-ray queues (depth >= 1): 32 B ray read + 16 B hit write per ray",
                          48.0, nodes_b, tris_b, ms_b, l_b, rays_b)
     out["primary"] = entry(f"rt::k_trace_primary<false, {st}>", "depth 0: camera rays generated in the lanes that trace them, 16 B hit write per ray",
                            16.0, nodes_p, tris_p, d("traverse_primary_ms_total"), d("traverse_primary_launches"), d("rays_primary_timed"))
-    out["shadow"] = entry(f"rt::k_trace_shadow<false, {st}>", "any-hit traversal of the NEE connections: 48 B entry + 12 B radiance read per connection (+ 12 B add when unoccluded)",
+    out["shadow"] = entry(f"rt::k_trace_shadow<false, {st}, false>", "any-hit traversal of the NEE connections: 48 B entry + 12 B radiance read per connection (+ 12 B add when unoccluded)",
                           60.0, nodes_s, tris_s, d("traverse_shadow_ms_total"), d("traverse_shadow_launches"), d("rays_shadow_timed"))
     simt = {}
     for kind in ("closest", "shadow"):

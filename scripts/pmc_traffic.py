@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bench import source_hash  # noqa: E402
 
-prefix = sys.argv[4] if len(sys.argv) > 4 else "k_trace_batch<false, false, false>"
+prefix = sys.argv[4] if len(sys.argv) > 4 else "k_trace_batch<false, false, false, false>"
 d = json.load(open(sys.argv[1] + "/summary.json"))
 key = next(k for k in d if k.startswith(prefix))
 v = d[key]
