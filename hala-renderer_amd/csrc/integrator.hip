@@ -345,6 +345,33 @@ k_trace_shadow(SceneView sv, Queues q, PathState ps, Control* __restrict__ ctl, 
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// K5c + K5a in one launch: the last shadow pass of bounce d and the closest-hit traversal of bounce d + 1.  They are independent (the
+// shadow pass only adds to radiance, the closest-hit pass only reads the ray queue shade(d) wrote) and every persistent launch ends in
+// a tail of a few long rays during which most of the chip idles — a fixed cost that weighs more the smaller the launch (late bounces,
+// a rank's share of a strong-scaled frame).  Here a wave that finds the shadow queue dry moves straight on to the bounce rays: one tail
+// instead of two.  (Two launches side by side on two streams do not achieve this: each takes the chip from the other all the time,
+// profiles/r02_experiments.txt.)  Not used by updates that carry per-launch timing events or counting kernels.
+// ---------------------------------------------------------------------------------------------------------
+template <bool STAGED, bool ALPHA>
+__global__ void __launch_bounds__(kTraverseThreads, STAGED ? kTraverseWavesPerSimdStaged : kTraverseWavesPerSimd)
+k_trace_shadow_then_batch(SceneView sv, const Tri* __restrict__ tris_any, Queues q, PathState ps, Control* __restrict__ ctl, uint32_t depth,
+                          uint32_t kind, const hala_ray* __restrict__ rays, hala_hit* __restrict__ hits, uint2* __restrict__ spill_base, uint32_t refill) {
+  const TraverseLds lds = stage_bvh<STAGED>(sv, g_smem);
+  uint2* spill = spill_base ? spill_base + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * kStackSpill : nullptr;
+  StepCounters sc;
+  {
+    SceneView sva = sv;
+    sva.tris = tris_any;  // RENDER_SPEC 7.1d (STAGED: the launcher only fuses when both passes traverse the same triangles)
+    ShadowSource<STAGED> src{q.shadow[kind], ps.radiance};
+    persistent_trace<true, false, STAGED, ALPHA>(sva, lds, spill, &ctl->work_shadow[kind], ctl->n_shadow[kind][depth], refill, src, sc);
+  }
+  const uint32_t n = ctl->n_active[depth + 1u];
+  if (blockIdx.x == 0 && threadIdx.x == 0) ctl->rays_closest += n;
+  BatchSource src{rays, hits, false, true, STAGED && refill == 64u};
+  persistent_trace<false, false, STAGED, false>(sv, lds, spill, &ctl->work_closest, n, refill, src, sc);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // shade: closest-hit + miss + light/env NEE + BSDF sampling + Russian roulette for one bounce (RENDER_SPEC §6)
 // ---------------------------------------------------------------------------------------------------------
 // PRIMARY (depth 0): queue entry i IS path slot i, its ray is re-evaluated from the camera instead of being read, and
@@ -725,6 +752,24 @@ void launch_trace_shadow(const LaunchCfg& lc, const SceneView& sv0, const Queues
                               launch_trace_shadow_t<true, true, false>,   launch_trace_shadow_t<false, false, true>, launch_trace_shadow_t<false, true, true>,
                               launch_trace_shadow_t<true, false, true>,   launch_trace_shadow_t<true, true, true>};
   table[(sv.any_translucent ? 4 : 0) | (count ? 2 : 0) | (sv.staged ? 1 : 0)](lc, sv, q, ps, ctl, depth, kind, traverse_smem(sv0), s);
+}
+
+// the fused launch; false: the caller must issue the two launches separately (an LDS-staged scene whose any-hit rays traverse a
+// different triangle copy than its closest-hit rays: only one of them is staged)
+bool launch_trace_shadow_then_batch(const LaunchCfg& lc, const SceneView& sv, const Queues& q, const PathState& ps, Control* ctl, uint32_t depth,
+                                    uint32_t kind, hipStream_t s) {
+  if (sv.staged && sv.tris_any != sv.tris) return false;
+  const size_t smem = traverse_smem(sv);
+  const dim3 grid(lc.persistent_blocks), block(kTraverseThreads);
+  const hala_ray* rays = q.rays[(depth + 1u) & 1u];
+  if (sv.staged) {
+    if (sv.any_translucent) hipLaunchKernelGGL((k_trace_shadow_then_batch<true, true>), grid, block, smem, s, sv, sv.tris_any, q, ps, ctl, depth, kind, rays, q.hits, lc.spill, lc.refill);
+    else hipLaunchKernelGGL((k_trace_shadow_then_batch<true, false>), grid, block, smem, s, sv, sv.tris_any, q, ps, ctl, depth, kind, rays, q.hits, lc.spill, lc.refill);
+  } else {
+    if (sv.any_translucent) hipLaunchKernelGGL((k_trace_shadow_then_batch<false, true>), grid, block, smem, s, sv, sv.tris_any, q, ps, ctl, depth, kind, rays, q.hits, lc.spill, lc.refill);
+    else hipLaunchKernelGGL((k_trace_shadow_then_batch<false, false>), grid, block, smem, s, sv, sv.tris_any, q, ps, ctl, depth, kind, rays, q.hits, lc.spill, lc.refill);
+  }
+  return true;
 }
 
 void launch_trace_primary(const LaunchCfg& lc, const SceneView& sv, const FrameConst& fc, hala_hit* hits, WorkCounters* work, Control* ctl,

@@ -136,11 +136,9 @@ struct hala_rt_renderer {
   bool staged = false;  // whole BVH staged in LDS by the traversal kernels
   uint32_t leaf_max_built = 0;
   float ray_eps = 0.0f;
-  DeviceArray<uint2> d_spill, d_spill_shadow;
-  LaunchCfg lcfg{}, lcfg_shadow{};  // the shadow launches of bounce d run beside the closest-hit launch of bounce d + 1: own spill area
-  hipStream_t shadow_stream = nullptr;
-  std::vector<hipEvent_t> ev_shaded, ev_shadowed;  // per bounce: shade(d) done (main stream) / shadow passes of d done (shadow stream)
-  bool overlap_shadow = true;
+  DeviceArray<uint2> d_spill;
+  LaunchCfg lcfg{};
+  bool fuse_passes = true;  // untimed updates: shadow pass of bounce d + closest-hit pass of bounce d + 1 in one launch
 
   bool has_env = false;
   uint32_t env_w = 0, env_h = 0;
@@ -210,9 +208,6 @@ struct hala_rt_renderer {
     if (gather_stream) { (void)hipStreamSynchronize(gather_stream); (void)hipStreamDestroy(gather_stream); }
     for (hipEvent_t e : {ev_rendered, ev_staged, ev_gathered}) if (e) (void)hipEventDestroy(e);
     if (comm && comm_owned) (void)ncclCommDestroy(comm);
-    if (shadow_stream) { (void)hipStreamSynchronize(shadow_stream); (void)hipStreamDestroy(shadow_stream); }
-    for (auto e : ev_shaded) (void)hipEventDestroy(e);
-    for (auto e : ev_shadowed) (void)hipEventDestroy(e);
     // images first, then everything else (src/rt_renderer.rs:620-633)
     for (auto& i : img_local) i.release();
     for (auto& i : img_full) i.release();
@@ -493,11 +488,8 @@ int configure_traversal(hala_rt_renderer* r) {
     if (r->bvh.stack_need > traverse_stack_lds_levels(r->staged) + traverse_stack_spill_levels())
       RT_FAIL("The BVH is deeper than the traversal stack supports (" + std::to_string(r->bvh.max_depth) + " levels, " + std::to_string(r->bvh.stack_need) + " stack entries).");
     RT_HIP(r->d_spill.resize((size_t)r->lcfg.persistent_blocks * 256 * traverse_stack_spill_levels()));
-    RT_HIP(r->d_spill_shadow.resize((size_t)r->lcfg.persistent_blocks * 256 * traverse_stack_spill_levels()));
     r->lcfg.spill = r->d_spill.ptr;
   }
-  r->lcfg_shadow = r->lcfg;
-  if (r->lcfg.spill) r->lcfg_shadow.spill = r->d_spill_shadow.ptr;
   const float ex = r->bvh.scene_max[0] - r->bvh.scene_min[0], ey = r->bvh.scene_max[1] - r->bvh.scene_min[1], ez = r->bvh.scene_max[2] - r->bvh.scene_min[2];
   r->ray_eps = std::sqrt(std::fmaf(ez, ez, std::fmaf(ey, ey, ex * ex))) * 1e-5f;  // RENDER_SPEC §3
   return HALA_OK;
@@ -612,8 +604,7 @@ int hala_rt_create(const char* name, uint32_t width, uint32_t height, int device
   RT_HIP(hipGetDeviceProperties(&prop, device_ordinal));
   r->cu_count = (uint32_t)prop.multiProcessorCount;
   RT_HIP(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
-  RT_HIP(hipStreamCreateWithFlags(&r->shadow_stream, hipStreamNonBlocking));
-  if (const char* ev = getenv("HALART_OVERLAP")) r->overlap_shadow = atoi(ev) != 0;  // A/B knob
+  if (const char* ev = getenv("HALART_FUSE")) r->fuse_passes = atoi(ev) != 0;  // A/B knob
   compute_tiling(r.get());
   // create_storage_images (src/rt_renderer.rs:818-917): final, accum, albedo, normal
   if (alloc_frame_buffers(r.get()) != HALA_OK) return HALA_ERR;
@@ -786,19 +777,11 @@ static int update_impl(hala_rt_renderer* r, uint32_t frames) {
   // packet on the stream, i.e. a few microseconds between two launches
   const bool timed = r->launch_event_period == 1u || (r->launch_event_period > 1u && (r->update_counter % r->launch_event_period) == 0u);
   r->update_counter++;
-  // The shadow passes of bounce d only add to the paths' radiance; the closest-hit traversal of bounce d + 1 only reads the ray queue
-  // shade(d) wrote: they run side by side on two streams (a persistent launch ends in a tail of a few long rays — the other launch's
-  // workgroups fill the compute units it vacates), and shade(d + 1) waits for both.  Updates that carry per-launch timing events or
-  // counting kernels stay serial on the main stream, so every measured launch has the chip to itself.
-  const bool overlap = r->overlap_shadow && !timed && !r->counting && (u.num_of_lights > 0 || u.env_type == 1u);
-  hipStream_t ss = overlap ? r->shadow_stream : s;
-  if (overlap) {
-    while (r->ev_shaded.size() < r->max_depth) {
-      hipEvent_t a = nullptr, b = nullptr;
-      RT_HIP(hipEventCreateWithFlags(&a, hipEventDisableTiming)); RT_HIP(hipEventCreateWithFlags(&b, hipEventDisableTiming));
-      r->ev_shaded.push_back(a); r->ev_shadowed.push_back(b);
-    }
-  }
+  // The last shadow pass of bounce d and the closest-hit traversal of bounce d + 1 are independent: untimed updates issue them as ONE
+  // persistent launch (k_trace_shadow_then_batch: one tail of long rays instead of two).  Updates that carry per-launch timing events or
+  // counting kernels keep one launch per pass, so that every measured launch is one kernel symbol with the chip to itself.
+  const bool fuse = r->fuse_passes && !timed && !r->counting && (u.num_of_lights > 0 || u.env_type == 1u);
+  bool traced = false;  // the closest-hit pass of this depth already ran inside the previous depth's fused launch
   for (uint32_t depth = 0; depth < r->max_depth; ++depth) {
     if (timed) { hipEvent_t a = r->next_event(te); RT_HIP(hipEventRecord(a, s)); }
     // depth 0: the camera rays are generated inside the traversal kernel, there is no ray-generation pass
@@ -806,19 +789,26 @@ static int update_impl(hala_rt_renderer* r, uint32_t frames) {
       launch_trace_primary(r->lcfg, sv, fc, q.hits, &ctl->work_closest, ctl, r->real_pixels * samples, r->counting, s);
       if (r->counting) RT_HIP(hipMemcpyAsync(ctl->primary_steps, ctl->steps[0], 16, hipMemcpyDeviceToDevice, s));
     }
-    else launch_trace_batch(r->lcfg, sv, q.rays[depth & 1u], q.hits, &ctl->n_active[depth], 0, &ctl->work_closest, ctl, false, r->counting, true, s);
+    else if (!traced) launch_trace_batch(r->lcfg, sv, q.rays[depth & 1u], q.hits, &ctl->n_active[depth], 0, &ctl->work_closest, ctl, false, r->counting, true, s);
+    traced = false;
     if (timed) { hipEvent_t b = r->next_event(te); RT_HIP(hipEventRecord(b, s)); }
-    if (overlap && depth > 0) RT_HIP(hipStreamWaitEvent(s, r->ev_shadowed[depth - 1], 0));  // shade(d) re-arms the work counters and adds to radiance
     launch_shade(fc, sv, q, ps, ctl, depth, s);
     if (timed) { hipEvent_t c = r->next_event(te); RT_HIP(hipEventRecord(c, s)); }
-    if (overlap) { RT_HIP(hipEventRecord(r->ev_shaded[depth], s)); RT_HIP(hipStreamWaitEvent(ss, r->ev_shaded[depth], 0)); }
     // light connections first, environment connections second: contributions land in spec order (RENDER_SPEC §6)
-    if (u.num_of_lights > 0) { launch_trace_shadow(r->lcfg_shadow, sv, q, ps, ctl, depth, 0, r->counting, ss); te.shadow_launches += timed ? 1u : 0u; }
-    if (u.env_type == 1u) { launch_trace_shadow(r->lcfg_shadow, sv, q, ps, ctl, depth, 1, r->counting, ss); te.shadow_launches += timed ? 1u : 0u; }
-    if (overlap) RT_HIP(hipEventRecord(r->ev_shadowed[depth], ss));
+    const uint32_t last_kind = u.env_type == 1u ? 1u : 0u;
+    const bool fuse_here = fuse && depth + 1u < r->max_depth;
+    if (u.num_of_lights > 0) {
+      if (fuse_here && last_kind == 0u && launch_trace_shadow_then_batch(r->lcfg, sv, q, ps, ctl, depth, 0, s)) traced = true;
+      else launch_trace_shadow(r->lcfg, sv, q, ps, ctl, depth, 0, r->counting, s);
+      te.shadow_launches += timed ? 1u : 0u;
+    }
+    if (u.env_type == 1u) {
+      if (fuse_here && launch_trace_shadow_then_batch(r->lcfg, sv, q, ps, ctl, depth, 1, s)) traced = true;
+      else launch_trace_shadow(r->lcfg, sv, q, ps, ctl, depth, 1, r->counting, s);
+      te.shadow_launches += timed ? 1u : 0u;
+    }
     if (timed) { hipEvent_t d = r->next_event(te); RT_HIP(hipEventRecord(d, s)); }
   }
-  if (overlap) RT_HIP(hipStreamWaitEvent(s, r->ev_shadowed[r->max_depth - 1], 0));
   launch_resolve(fc, ps, r->img_local[0].ptr, r->img_local[1].ptr, r->img_local[2].ptr, r->img_local[3].ptr, s);
   RT_HIP(hipMemcpyAsync(te.host_counts, &ctl->rays_closest, 14 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
   RT_HIP(hipEventRecord(te.frame_end, s));
