@@ -237,9 +237,6 @@ RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, 
   int sp = t.sp;
   uint32_t ref[4] = {kAbsent, kAbsent, kAbsent, kAbsent}, key[4] = {kMissKey, kMissKey, kMissKey, kMissKey};
   uint32_t next = kAbsent, next_key = 0, nl = 0;
-#ifdef RT_PREFETCH_NEXT
-  uint32_t pf = 0;
-#endif
   if (has) {
     float4 q0, q1, q2, q3;
     if (STAGED) { const RT_LDS f32x4* p = lds.nodes + (size_t)t.cur * 4; q0 = ld4(p); q1 = ld4(p + 1); q2 = ld4(p + 2); q3 = ld4(p + 3); }
@@ -287,10 +284,6 @@ RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, 
       }
       next = ref[k]; next_key = key[k];
     }
-#ifdef RT_PREFETCH_NEXT
-    // touch the node that will most likely be visited next: its line travels to this CU's L1 while the wave tests leaves
-    if (!STAGED && next != kAbsent) pf = reinterpret_cast<const volatile uint32_t*>(sv.nodes + next)[0];
-#endif
     // the leaves in reach as the node is entered (§4.4b): a sorted prefix.  Large trees: ALL of them are tested, none is culled by a
     // sibling's hit; small (LDS-staged) trees: the lane tests them one after the other, nearest first, while they stay in reach
 #pragma unroll
@@ -397,9 +390,6 @@ RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, 
   }
   t.cur = next;
   t.sp = sp;
-#ifdef RT_PREFETCH_NEXT
-  asm volatile("" ::"v"(pf));
-#endif
   return false;
 }
 
