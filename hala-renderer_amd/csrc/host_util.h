@@ -1,5 +1,6 @@
 // host_util.h — small host-side helpers of libhalart.so: error channel, RAII device buffers.
 #pragma once
+#include <rocprofiler-sdk-roctx/roctx.h>
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -73,3 +74,11 @@ struct JsonValue {
 std::string json_parse(const char* text, JsonValue* out);
 
 }  // namespace rt
+
+// roctx range around a host-side phase (rocprofv3 --marker-trace shows commit / update / refit / tile_allgather on the timeline)
+struct RtRange {
+  explicit RtRange(const char* name) { roctxRangePushA(name); }
+  ~RtRange() { roctxRangePop(); }
+  RtRange(const RtRange&) = delete;
+  RtRange& operator=(const RtRange&) = delete;
+};

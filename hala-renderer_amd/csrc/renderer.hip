@@ -665,6 +665,7 @@ int hala_rt_load_blue_noise_pixels(hala_rt_renderer* r, const uint8_t* rgba8, ui
 }
 
 int hala_rt_set_scene(hala_rt_renderer* r, const hala_scene_desc* scene) {
+  RtRange range("halart::set_scene");
   if (ensure_device(r) != HALA_OK) return HALA_ERR;
   RT_HIP(hipStreamSynchronize(r->stream));
   r->has_scene = false; r->committed = false;  // "Release the old scene in the GPU." (src/rt_renderer.rs:1164)
@@ -717,6 +718,7 @@ void hala_rt_set_env_intensity(hala_rt_renderer* r, float v) { if (r) r->env_int
 void hala_rt_set_exposure_value(hala_rt_renderer* r, float v) { if (r) r->exposure = v; }
 
 int hala_rt_commit(hala_rt_renderer* r) {
+  RtRange range("halart::commit");
   if (ensure_device(r) != HALA_OK) return HALA_ERR;
   if (!r->has_scene) RT_FAIL("The scene in GPU is none!");  // src/rt_renderer.rs:138
   if (r->hs.cameras.empty()) RT_FAIL("The scene has no camera.");
@@ -731,6 +733,7 @@ int hala_rt_commit(hala_rt_renderer* r) {
 // incremented first (pre_update, src/renderer.rs:278) and a frame whose number exceeds max_frames is skipped
 // (src/rt_renderer.rs:394-396); the frames that do render share one kernel sequence with `samples` paths per pixel.
 static int update_impl(hala_rt_renderer* r, uint32_t frames) {
+  RtRange range("halart::update");
   if (ensure_device(r) != HALA_OK) return HALA_ERR;
   if (!r->committed) RT_FAIL("The pipeline is none!");  // src/rt_renderer.rs:443
   const uint64_t first = r->total_frames;  // frame_index of the first frame of this batch = total_frames - 1 after its increment
@@ -860,6 +863,7 @@ int hala_rt_read_image(hala_rt_renderer* r, int which, float* dst) {
 }
 
 int hala_rt_save_images(hala_rt_renderer* r, const char* path) {
+  RtRange range("halart::save_images");
   if (ensure_device(r) != HALA_OK) return HALA_ERR;
   if (!path || !*path) RT_FAIL("The file name is none!");  // src/rt_renderer.rs:1234
   std::string p(path);
@@ -1091,6 +1095,7 @@ int hala_rt_comm_destroy(hala_rt_renderer* r) {
 // finish(k - 1) -> [side stream waits for the renderer's stream: frame k is complete] -> staging <- tiles -> [renderer's stream waits
 // for that copy: frame k + 1 may overwrite the tiles] -> ncclAllGather(receive <- staging) on the side stream.  Nothing blocks the host.
 int hala_rt_tile_allgather_begin(hala_rt_renderer* r, uint32_t aov_mask) {
+  RtRange range("halart::tile_allgather_begin");
   if (ensure_device(r) != HALA_OK) return HALA_ERR;
   if (!r->comm) RT_FAIL("The renderer has no communicator: call hala_rt_comm_init_rank or hala_rt_comm_attach first.");
   if (aov_mask == 0u || aov_mask > 15u) RT_FAIL("Invalid AOV mask.");
@@ -1116,6 +1121,7 @@ int hala_rt_tile_allgather_begin(hala_rt_renderer* r, uint32_t aov_mask) {
 // de-interleave on the side stream (beside the rendering of the next frame), then whatever the renderer's stream does next — and
 // whoever waits for it — sees the row-major images complete
 int hala_rt_tile_allgather_finish(hala_rt_renderer* r) {
+  RtRange range("halart::tile_allgather_finish");
   if (ensure_device(r) != HALA_OK) return HALA_ERR;
   if (!r->gather_pending) return HALA_OK;
   const uint32_t mask = r->gather_pending;
@@ -1241,6 +1247,7 @@ int hala_rt_update_material(hala_rt_renderer* r, uint32_t material_index, const 
   return HALA_OK;
 }
 int hala_rt_refit(hala_rt_renderer* r) {
+  RtRange range("halart::refit");
   if (ensure_device(r) != HALA_OK) return HALA_ERR;
   if (!r->committed) RT_FAIL("The top level acceleration structure is none!");
   RT_HIP(hipStreamSynchronize(r->stream));

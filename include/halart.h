@@ -297,7 +297,9 @@ int hala_rt_push_hit_shaders_with_file(hala_rt_renderer* r, const char* closest_
                                        const char* debug_name);
 
 /* load_blue_noise_texture (src/rt_renderer.rs:1117-1156).  Optional here (mandatory at commit in the
- * reference, :319): the built-in integrator draws its samples from a counter-based RNG. */
+ * reference, :319).  The image is decoded, validated and uploaded like the reference does, and then IGNORED:
+ * the built-in integrator draws every sample from a counter-based hash RNG keyed by (pixel id, frame index)
+ * (docs/RENDER_SPEC.md 2.3), which is what makes a pixel's value independent of tiling, batching and ranks. */
 int hala_rt_load_blue_noise_texture(hala_rt_renderer* r, const char* path); /* PNG / baseline JPEG, like HalaImageData::new_with_file */
 int hala_rt_load_blue_noise_pixels(hala_rt_renderer* r, const uint8_t* rgba8, uint32_t width,
                                    uint32_t height);
