@@ -279,7 +279,8 @@ __global__ void __launch_bounds__(256) k_leaf_boxes(const Box6* __restrict__ tri
     const bool gone = cls == 1u;
     float4* da = reinterpret_cast<float4*>(tris_any + k);
     da[0] = src[0];
-    da[1] = gone ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : make_float4(src[1].x, src[1].y, src[1].z, __uint_as_float(cls == 2u ? 1u : 0u));
+    const uint32_t flag = cls == 2u ? 1u : (cls == 3u ? 2u : (cls == 4u ? 3u : 0u));  // bit 0: translucent, bit 1: boundary of a medium (7.1g)
+    da[1] = gone ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : make_float4(src[1].x, src[1].y, src[1].z, __uint_as_float(flag));
     da[2] = gone ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : src[2];
   }
 }

@@ -105,7 +105,7 @@ struct SceneView {
   const float* env_marginal;     // set 0 binding 7[0]
   const float* env_conditional;  // set 0 binding 7[1]
   uint32_t node_count, tri_count, lds_nodes, lds_tris;
-  uint32_t any_translucent;   // 1: some material is translucent (RENDER_SPEC 7.1d): the any-hit launches run their ALPHA variants
+  uint32_t any_translucent;   // 1: some material is translucent or bounds a medium (RENDER_SPEC 7.1d / 7.1g): the any-hit launches run their ALPHA variants
   uint32_t simple_materials;  // 1: every material is an untextured, opaque DIFFUSE one without a medium (the SIMPLE shade kernels apply)
   float ray_eps;
   uint32_t staged;  // 1: the whole BVH fits the LDS budget (lds_nodes == node_count, lds_tris == tri_count) and is staged per workgroup
@@ -126,12 +126,14 @@ inline uint8_t shade_kind_of(const hala_gpu_material& m, uint32_t texture_count)
   return (uint8_t)(kShadeKindFirst + (m.type == 1u ? 2u : 0u) + (tex ? 1u : 0u));
 }
 
-// RENDER_SPEC 7.1d: how an any-hit ray treats the triangles of a material: 0 = every hit blocks, 1 = invisible (opacity exactly 0),
-// 2 = translucent (blocks with probability opacity x base-colour-map alpha, decided per (ray key, triangle))
+// RENDER_SPEC 7.1d / 7.1g: how an any-hit ray treats the triangles of a material: 0 = every hit blocks, 1 = invisible (opacity exactly 0,
+// no medium behind it), 2 = translucent (blocks with probability opacity x base-colour-map alpha, decided per (ray key, triangle)),
+// 3 = invisible boundary of a medium (never blocks, adds to the ray's optical depth), 4 = translucent boundary of a medium
 inline uint8_t any_class_of(const hala_gpu_material& m, bool base_map_has_alpha) {
-  if (m.opacity == 0.0f) return 1;
-  if (m.opacity < 1.0f) return 2;
-  return base_map_has_alpha ? 2 : 0;
+  const bool medium = m.medium_type == 1u || m.medium_type == 2u;
+  if (m.opacity == 0.0f) return medium ? 3 : 1;
+  if (m.opacity < 1.0f || base_map_has_alpha) return medium ? 4 : 2;
+  return 0;
 }
 constexpr uint32_t kAnyKeyLight = 0xA511E9B3u, kAnyKeyEnv = 0x63D83595u, kAnyKeyBatch = 0x5BD1E995u;
 

@@ -249,7 +249,7 @@ struct CameraSource {
     else reinterpret_cast<float4*>(hits)[i] = out;
   }
 };
-template <bool PREFETCH>
+template <bool PREFETCH, bool ALPHA>
 struct ShadowSource {
   // contribution.xyz | pixel slot, fetched with the ray (one coalesced 48-B record), and the path's radiance as it stands
   struct Payload { float4 cs; float lx, ly, lz; };
@@ -275,9 +275,14 @@ struct ShadowSource {
   }
   RT_DI void done(uint32_t, const Trav& t, const Payload& p) const {
     if (t.best.prim != kAbsent) return;  // occluded
+    float cx = p.cs.x, cy = p.cs.y, cz = p.cs.z;
+    if (ALPHA && (t.tau[0] | t.tau[1] | t.tau[2])) {  // RENDER_SPEC 7.1g: what the media the connection crossed leave of it
+      const f3 tr = any_transmittance(t.tau);
+      if (tr.x != 1.0f || tr.y != 1.0f || tr.z != 1.0f) { cx = cx * tr.x; cy = cy * tr.y; cz = cz * tr.z; }
+    }
     float* l = reinterpret_cast<float*>(radiance + __float_as_uint(p.cs.w));
-    if (PREFETCH) { l[0] = p.lx + p.cs.x; l[1] = p.ly + p.cs.y; l[2] = p.lz + p.cs.z; }
-    else { atomicAdd(l + 0, p.cs.x); atomicAdd(l + 1, p.cs.y); atomicAdd(l + 2, p.cs.z); }
+    if (PREFETCH) { l[0] = p.lx + cx; l[1] = p.ly + cy; l[2] = p.lz + cz; }
+    else { atomicAdd(l + 0, cx); atomicAdd(l + 1, cy); atomicAdd(l + 2, cz); }
   }
 };
 
@@ -339,7 +344,7 @@ k_trace_shadow(SceneView sv, Queues q, PathState ps, Control* __restrict__ ctl, 
   const uint32_t n = ctl->n_shadow[kind][depth];
   uint2* spill = spill_base ? spill_base + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * kStackSpill : nullptr;
   StepCounters sc;
-  ShadowSource<STAGED> src{q.shadow[kind], ps.radiance};
+  ShadowSource<STAGED, ALPHA> src{q.shadow[kind], ps.radiance};
   persistent_trace<true, COUNT, STAGED, ALPHA>(sv, lds, spill, &ctl->work_shadow[kind], n, refill, src, sc);
   if (COUNT) flush_counters(ctl, 1, sc);
 }
@@ -362,7 +367,7 @@ k_trace_shadow_then_batch(SceneView sv, const Tri* __restrict__ tris_any, Queues
   {
     SceneView sva = sv;
     sva.tris = tris_any;  // RENDER_SPEC 7.1d (STAGED: the launcher only fuses when both passes traverse the same triangles)
-    ShadowSource<STAGED> src{q.shadow[kind], ps.radiance};
+    ShadowSource<STAGED, ALPHA> src{q.shadow[kind], ps.radiance};
     persistent_trace<true, false, STAGED, ALPHA>(sva, lds, spill, &ctl->work_shadow[kind], ctl->n_shadow[kind][depth], refill, src, sc);
   }
   const uint32_t n = ctl->n_active[depth + 1u];

@@ -505,7 +505,7 @@ int attach_any_triangles(hala_rt_renderer* r) {
     const bool cutout = m.base_color_map_index < hs.texture_image.size() && hs.images[hs.texture_image[m.base_color_map_index]].has_alpha;
     cls[i] = any_class_of(m, cutout);
     r->any_invisible = r->any_invisible || cls[i] != 0;
-    r->any_translucent = r->any_translucent || cls[i] == 2;
+    r->any_translucent = r->any_translucent || cls[i] >= 2;
   }
   r->material_any_class = cls;
   RT_HIP(r->d_material_any_class.upload(cls.data(), cls.size(), r->stream));

@@ -503,9 +503,38 @@ RT_DI float hit_alpha(const SceneView& sv, uint32_t prim, float u, float v) {
   }
   return alpha;
 }
-RT_DI bool any_hit_blocks(const SceneView& sv, uint32_t key, uint32_t prim, float u, float v) {
-  const float x = (float)(pcg_hash(key + prim * 0x9E3779B1u) >> 8) * (1.0f / 16777216.0f);
-  return x < hit_alpha(sv, prim, u, v);
+// RENDER_SPEC 7.1d / 7.1g: what a flagged triangle of the any-hit copy does to an any-hit ray that hits it inside (tmin, tmax) at distance t
+// with Moeller-Trumbore determinant det.  flag bit 0: translucent — blocks iff hash(key, triangle) < opacity x alpha at the hit; bit 1:
+// boundary of a medium — a ray that gets through adds +sigma t to its optical depth where it leaves the object (hit from behind:
+// det < 0), -sigma t where it enters, per channel, in 2^-16 units with wrap-around integer arithmetic: the sums do not depend on the
+// order of the crossings.  Returns true if the triangle blocks; q = what to add to the ray's optical depth.
+RT_DI bool any_hit_event(const SceneView& sv, uint32_t key, uint32_t prim, uint32_t flag, float t, float det, float u, float v, uint32_t q[3]) {
+  q[0] = q[1] = q[2] = 0u;
+  if (flag & 1u) {
+    const float x = (float)(pcg_hash(key + prim * 0x9E3779B1u) >> 8) * (1.0f / 16777216.0f);
+    if (x < hit_alpha(sv, prim, u, v)) return true;
+  }
+  if (flag & 2u) {
+    const uint32_t material = __float_as_uint(reinterpret_cast<const float4*>(sv.shade_tris + prim)[1].w);
+    const hala_gpu_material& m = sv.materials[material];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float sigma = m.medium_type == 1u ? m.medium_density * (1.0f - m.medium_color[c]) : m.medium_density;
+      const uint32_t v32 = (uint32_t)(int32_t)floorf(minf(t * sigma, 4096.0f) * 65536.0f + 0.5f);
+      q[c] = det < 0.0f ? v32 : 0u - v32;
+    }
+  }
+  return false;
+}
+// what an unblocked connection keeps after the media it crossed: exp_neg(-max(tau, 0) / 65536) per channel
+RT_DI f3 any_transmittance(const uint32_t tau[3]) {
+  float r[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int32_t qv = (int32_t)tau[c];
+    r[c] = qv > 0 ? exp_neg_poly(-((float)qv * (1.0f / 65536.0f))) : 1.0f;
+  }
+  return mk3(r[0], r[1], r[2]);
 }
 
 struct Surface {

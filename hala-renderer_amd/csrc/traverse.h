@@ -99,7 +99,7 @@ RT_DI RayPre make_ray(f3 o, f3 d, float tmin) {
 // has the same t, u, v bit for bit; a rejected one is rejected by the same comparisons, evaluated at the end).  No branch sits
 // between the three 16-B loads of the triangle and their uses, so the loads leave together — with early-outs hipcc sank the load of
 // v0 below the `det == 0` branch: two dependent memory round trips per triangle.
-RT_DI bool tri_test_od(f3 o, f3 d, float4 a, float4 b, float4 c, float* t, float* u, float* v) {
+RT_DI bool tri_test_od(f3 o, f3 d, float4 a, float4 b, float4 c, float* t, float* u, float* v, float* det_out) {
   const f3 e1 = mk3(b.x, b.y, b.z), e2 = mk3(c.x, c.y, c.z);
   const f3 p = cross3(d, e2);
   const float det = dot3(e1, p);
@@ -108,7 +108,7 @@ RT_DI bool tri_test_od(f3 o, f3 d, float4 a, float4 b, float4 c, float* t, float
   const float uu = dot3(tv, p) * inv;
   const f3 q = cross3(tv, e1);
   const float vv = dot3(d, q) * inv;
-  *t = dot3(e2, q) * inv; *u = uu; *v = vv;
+  *t = dot3(e2, q) * inv; *u = uu; *v = vv; *det_out = det;
   return det != 0.0f && uu >= 0.0f && uu <= 1.0f && vv >= 0.0f && uu + vv <= 1.0f;
 }
 
@@ -127,9 +127,10 @@ struct Trav {
   uint32_t cur;
   int sp;
   uint32_t key;  // any-hit rays: decides which translucent triangles block this ray (RENDER_SPEC 7.1d)
+  uint32_t tau[3];  // any-hit rays: optical depth of the media crossed so far, 2^-16 units, wrap-around sums (RENDER_SPEC 7.1g)
 };
 RT_DI void trav_begin(Trav& t, const RayPre& r, float tmax, uint32_t key) {
-  t.r = r; t.tmax = tmax; t.key = key;
+  t.r = r; t.tmax = tmax; t.key = key; t.tau[0] = t.tau[1] = t.tau[2] = 0u;
   t.best.t = tmax; t.best.u = 0.0f; t.best.v = 0.0f; t.best.prim = kAbsent;
   t.cur = 0; t.sp = 0;
 }
@@ -154,7 +155,7 @@ RT_DI v2f pk2(float a, float b) { return v2f{a, b}; }
 RT_DI v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 RT_DI v2f pk_dot3(v2f ax, v2f ay, v2f az, v2f bx, v2f by, v2f bz) { return pk_fma(az, bz, pk_fma(ay, by, ax * bx)); }
 RT_DI void tri_test2(const RayPre& r, float4 a0, float4 b0, float4 c0, float4 a1, float4 b1, float4 c1, bool ok[2], float t[2], float u[2],
-                     float v[2]) {
+                     float v[2], float dt[2]) {
   const v2f dx = pk2(r.d.x, r.d.x), dy = pk2(r.d.y, r.d.y), dz = pk2(r.d.z, r.d.z);
   const v2f e1x = pk2(b0.x, b1.x), e1y = pk2(b0.y, b1.y), e1z = pk2(b0.z, b1.z);
   const v2f e2x = pk2(c0.x, c1.x), e2y = pk2(c0.y, c1.y), e2z = pk2(c0.z, c1.z);
@@ -171,29 +172,33 @@ RT_DI void tri_test2(const RayPre& r, float4 a0, float4 b0, float4 c0, float4 a1
   const v2f uv = uu + vv;
   ok[0] = det.x != 0.0f && uu.x >= 0.0f && uu.x <= 1.0f && vv.x >= 0.0f && uv.x <= 1.0f;
   ok[1] = det.y != 0.0f && uu.y >= 0.0f && uu.y <= 1.0f && vv.y >= 0.0f && uv.y <= 1.0f;
-  t[0] = tt.x; t[1] = tt.y; u[0] = uu.x; u[1] = uu.y; v[0] = vv.x; v[1] = vv.y;
+  t[0] = tt.x; t[1] = tt.y; u[0] = uu.x; u[1] = uu.y; v[0] = vv.x; v[1] = vv.y; dt[0] = det.x; dt[1] = det.y;
 }
 
 // LDS-staged scenes: closest-hit / any-hit test of one leaf (count <= 8 triangles from `first`, storage order; fetched and tested
 // two at a time on the packed FP32 pipe: a leaf costs ceil(count/2) LDS round trips and ceil(count/2) packed tests; 4 waves/SIMD,
 // 128 VGPRs).  ANY: true on the first accepted triangle.
 template <bool ANY, bool ALPHA>
-RT_DI bool leaf_test_staged(const SceneView& sv, const TraverseLds& lds, const RayPre& r, float tmax, uint32_t key, HitRec& best, uint32_t first, uint32_t count) {
+RT_DI bool leaf_test_staged(const SceneView& sv, const TraverseLds& lds, const RayPre& r, float tmax, uint32_t key, uint32_t tau[3], HitRec& best, uint32_t first,
+                            uint32_t count) {
   for (uint32_t i = 0; i < count; i += 2u) {
     const bool two = i + 1u < count;
     const RT_LDS f32x4* p = lds.tris + (size_t)(first + i) * 3;
     const float4 a0 = ld4(p), b0 = ld4(p + 1), c0 = ld4(p + 2);
     float4 a1 = a0, b1 = b0, c1 = c0;  // a single triangle is tested against itself in the second component (result unused)
     if (two) { a1 = ld4(p + 3); b1 = ld4(p + 4); c1 = ld4(p + 5); }
-    bool ok[2]; float tt[2], uu[2], vv[2];
-    tri_test2(r, a0, b0, c0, a1, b1, c1, ok, tt, uu, vv);
+    bool ok[2]; float tt[2], uu[2], vv[2], dd[2];
+    tri_test2(r, a0, b0, c0, a1, b1, c1, ok, tt, uu, vv, dd);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       if (!ok[j] || (j == 1 && !two)) continue;
       const uint32_t id = __float_as_uint(j ? a1.w : a0.w);
       if (ANY) {
         if (tt[j] > r.tmin && tt[j] < tmax) {
-          if (ALPHA && __float_as_uint(j ? b1.w : b0.w) != 0u && !any_hit_blocks(sv, key, id, uu[j], vv[j])) continue;  // translucent: let through
+          if (ALPHA && __float_as_uint(j ? b1.w : b0.w) != 0u) {  // translucent and / or the boundary of a medium (7.1d, 7.1g)
+            uint32_t q[3];
+            if (!any_hit_event(sv, key, id, __float_as_uint(j ? b1.w : b0.w), tt[j], dd[j], uu[j], vv[j], q)) { tau[0] += q[0]; tau[1] += q[1]; tau[2] += q[2]; continue; }
+          }
           best.t = tt[j]; best.u = uu[j]; best.v = vv[j]; best.prim = id; return true;
         }
       } else if (tt[j] > r.tmin && (tt[j] < best.t || (tt[j] == best.t && id < best.prim))) {
@@ -309,7 +314,7 @@ RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, 
         sc.leaf_lanes++;
         if ((uint32_t)__ffsll((long long)m) - 1u == (threadIdx.x & 63u)) sc.leaf_passes++;
       }
-      if (leaf_test_staged<ANY, ALPHA>(sv, lds, r, t.tmax, t.key, best, ref[k] & 0x0fffffffu, ((ref[k] >> 28) & 7u) + 1u)) { found = true; break; }
+      if (leaf_test_staged<ANY, ALPHA>(sv, lds, r, t.tmax, t.key, t.tau, best, ref[k] & 0x0fffffffu, ((ref[k] >> 28) & 7u) + 1u)) { found = true; break; }
     }
   } else {
     const uint32_t lane = threadIdx.x & 63u;
@@ -322,7 +327,8 @@ RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, 
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         if ((uint32_t)k < nl) items[pre + (uint32_t)k] = u32x2{ref[k], lane};
-      if (nl) slots[lane] = u32x4{best.prim, __float_as_uint(best.t), __float_as_uint(best.u), __float_as_uint(best.v)};
+      if (nl) slots[lane] = (ANY && ALPHA) ? u32x4{best.prim, 0u, 0u, 0u}  // any-hit: blocked flag | optical depth gathered in this step
+                                           : u32x4{best.prim, __float_as_uint(best.t), __float_as_uint(best.u), __float_as_uint(best.v)};
       // One wave, one instruction stream: its LDS operations execute in program order, so a lane sees what another lane of the wave
       // wrote by an earlier instruction.  The fences only keep the COMPILER from moving or forwarding LDS accesses across the phases.
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -352,10 +358,23 @@ RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, 
           const float4* p = tris + (size_t)((leaf & 0x0fffffffu) + j) * 3;
           const float4 a = p[0], b = p[1], c = p[2];
           asm volatile("" ::"v"(a.w));  // the id travels with v0 (one dwordx4), not as a dependent dword load inside the hit branch
-          float tt;
-          if (tri_test_od(o, d, a, b, c, &tt, &tu, &tv) && tt > tmin) {
+          float tt, det;
+          if (tri_test_od(o, d, a, b, c, &tt, &tu, &tv, &det) && tt > tmin) {
             if (ANY) {  // any blocking triangle: the owner's prim field leaves kAbsent
-              if (tt < tlim && !(ALPHA && __float_as_uint(b.w) != 0u && !any_hit_blocks(sv, okey_any, __float_as_uint(a.w), tu, tv))) *(RT_LDS uint32_t*)okey = 0u;
+              if (tt < tlim) {
+                bool blocks = true;
+                if (ALPHA && __float_as_uint(b.w) != 0u) {  // translucent and / or the boundary of a medium (7.1d, 7.1g)
+                  uint32_t q[3];
+                  blocks = any_hit_event(sv, okey_any, __float_as_uint(a.w), __float_as_uint(b.w), tt, det, tu, tv, q);
+                  if (!blocks && (q[0] | q[1] | q[2])) {
+                    RT_LDS uint32_t* ot = (RT_LDS uint32_t*)okey;
+                    __hip_atomic_fetch_add(ot + 1, q[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    __hip_atomic_fetch_add(ot + 2, q[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    __hip_atomic_fetch_add(ot + 3, q[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                  }
+                }
+                if (blocks) *(RT_LDS uint32_t*)okey = 0u;
+              }
             }
             else {
               mine = ((unsigned long long)__float_as_uint(tt) << 32) | (unsigned long long)__float_as_uint(a.w);
@@ -372,8 +391,10 @@ RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, 
       }
       if (nl) {
         const u32x4 w4 = slots[lane];
-        if (ANY) found = w4.x != kAbsent;
-        else { best.prim = w4.x; best.t = __uint_as_float(w4.y); best.u = __uint_as_float(w4.z); best.v = __uint_as_float(w4.w); }
+        if (ANY) {
+          found = w4.x != kAbsent;
+          if (ALPHA) { t.tau[0] += w4.y; t.tau[1] += w4.z; t.tau[2] += w4.w; }
+        } else { best.prim = w4.x; best.t = __uint_as_float(w4.y); best.u = __uint_as_float(w4.z); best.v = __uint_as_float(w4.w); }
       }
     }
     if (!has) return false;

@@ -304,10 +304,11 @@ static inline bool box_test(const RayPre& r, const float* mn, const float* mx, f
   return tn <= tf * 1.0000004f;
 }
 // Möller–Trumbore with the fma placement of spec_math.h. Returns true if (u,v) is inside and fills t,u,v.
-static inline bool tri_test(const RayPre& r, const Tri& tr, float* t, float* u, float* v) {
+static inline bool tri_test(const RayPre& r, const Tri& tr, float* t, float* u, float* v, float* det_out = nullptr) {
   V3 e1 = v3(tr.e1[0], tr.e1[1], tr.e1[2]), e2 = v3(tr.e2[0], tr.e2[1], tr.e2[2]);
   V3 p = cross3(r.d, e2);
   float det = dot3(e1, p);
+  if (det_out) *det_out = det;
   if (det == 0.0f) return false;
   float inv = 1.0f / det;
   V3 tv = r.o - v3(tr.v0[0], tr.v0[1], tr.v0[2]);
@@ -320,14 +321,35 @@ static inline bool tri_test(const RayPre& r, const Tri& tr, float* t, float* u, 
   return true;
 }
 
-// RENDER_SPEC 7.1d: a flagged (translucent) triangle blocks an any-hit ray iff hash(key, triangle) < opacity x alpha at the hit
-bool any_hit_blocks(const AnyCtx* ax, const Tri& tr, float u, float v) {
+// RENDER_SPEC 7.1d / 7.1g: what a triangle of the any-hit copy does to an any-hit ray that hits it inside (tmin, tmax).  Flags (word 7 of the
+// record): 0 blocks; 1 translucent: blocks iff hash(key, triangle) < opacity x alpha at the hit; 2 invisible boundary of a medium: never
+// blocks, adds to the optical depth; 3 translucent boundary of a medium: 1, then 2 when the ray gets through.
+bool any_hit_event(AnyCtx* ax, const Tri& tr, float t, float det, float u, float v) {
   if (!tr.pad1 || !ax) return true;
-  const float x = (float)(pcg_hash(ax->key + tr.id * 0x9E3779B1u) >> 8) * (1.0f / 16777216.0f);
-  return x < hit_alpha(ax->s, tr.id, u, v);
+  if (tr.pad1 & 1u) {
+    const float x = (float)(pcg_hash(ax->key + tr.id * 0x9E3779B1u) >> 8) * (1.0f / 16777216.0f);
+    if (x < hit_alpha(ax->s, tr.id, u, v)) return true;
+  }
+  if (tr.pad1 & 2u) {  // 7.1g: +sigma t where the ray leaves the object (hit from behind: det < 0), -sigma t where it enters
+    const orc_gpu_material& m = ax->s->materials[ax->s->instances[ax->s->tri_instance[tr.id]].material_index];
+    for (int c = 0; c < 3; ++c) {
+      const float sigma = m.medium_type == 1u ? m.medium_density * (1.0f - m.medium_color[c]) : m.medium_density;
+      const uint32_t q = (uint32_t)(int32_t)floorf(minf(t * sigma, 4096.0f) * 65536.0f + 0.5f);
+      ax->tau[c] = det < 0.0f ? ax->tau[c] + q : ax->tau[c] - q;
+    }
+  }
+  return false;
+}
+V3 any_transmittance(const AnyCtx& ax) {
+  float r[3];
+  for (int c = 0; c < 3; ++c) {
+    const int32_t q = (int32_t)ax.tau[c];
+    r[c] = q > 0 ? exp_neg_poly(-((float)q * (1.0f / 65536.0f))) : 1.0f;
+  }
+  return v3(r[0], r[1], r[2]);
 }
 template <bool ANY>
-static inline bool traverse(const Node* nodes, const Tri* tris, const RayPre& r, float tmax, const AnyCtx* ax, Hit* best, Counters* c) {
+static inline bool traverse(const Node* nodes, const Tri* tris, const RayPre& r, float tmax, AnyCtx* ax, Hit* best, Counters* c) {
   best->t = tmax; best->prim = ORC_NONE; best->u = 0.0f; best->v = 0.0f;
   uint32_t stack[1024]; int sp = 0;
   uint32_t cur = 0;
@@ -353,10 +375,10 @@ static inline bool traverse(const Node* nodes, const Tri* tris, const RayPre& r,
         if (c) c->tris += count;
         for (uint32_t i = 0; i < count; ++i) {
           const Tri& tr = tris[child + i];
-          float t, u, v;
-          if (!tri_test(r, tr, &t, &u, &v)) continue;
+          float t, u, v, det;
+          if (!tri_test(r, tr, &t, &u, &v, &det)) continue;
           if (ANY) {
-            if (t > r.tmin && t < tmax && any_hit_blocks(ax, tr, u, v)) { best->t = t; best->prim = tr.id; best->u = u; best->v = v; return true; }
+            if (t > r.tmin && t < tmax && any_hit_event(ax, tr, t, det, u, v)) { best->t = t; best->prim = tr.id; best->u = u; best->v = v; return true; }
           } else {
             if (t > r.tmin && (t < best->t || (t == best->t && tr.id < best->prim))) { best->t = t; best->u = u; best->v = v; best->prim = tr.id; }
           }
@@ -379,13 +401,13 @@ static inline float bits_f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 static inline uint32_t f_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 
 template <bool ANY>
-static inline bool leaf_test(const Tri* tris, const RayPre& r, float tmax, const AnyCtx* ax, Hit* best, uint32_t first, uint32_t count) {
+static inline bool leaf_test(const Tri* tris, const RayPre& r, float tmax, AnyCtx* ax, Hit* best, uint32_t first, uint32_t count) {
   for (uint32_t i = 0; i < count; ++i) {
     const Tri& tr = tris[first + i];
-    float t, u, v;
-    if (!tri_test(r, tr, &t, &u, &v)) continue;
+    float t, u, v, det;
+    if (!tri_test(r, tr, &t, &u, &v, &det)) continue;
     if (ANY) {
-      if (t > r.tmin && t < tmax && any_hit_blocks(ax, tr, u, v)) { best->t = t; best->prim = tr.id; best->u = u; best->v = v; return true; }
+      if (t > r.tmin && t < tmax && any_hit_event(ax, tr, t, det, u, v)) { best->t = t; best->prim = tr.id; best->u = u; best->v = v; return true; }
     } else if (t > r.tmin && (t < best->t || (t == best->t && tr.id < best->prim))) {
       best->t = t; best->u = u; best->v = v; best->prim = tr.id;
     }
@@ -411,7 +433,7 @@ static inline float key_tn(uint32_t key) { return bits_f(key & ~3u); }
 constexpr size_t kSmallTreeBytes = 40 * 1024;  // RENDER_SPEC 4.4b: node_count * 64 + triangle_count * 48 <= this -> sequential leaf culling
 static inline bool is_small_tree(size_t node_count, size_t tri_count) { return node_count * 64 + tri_count * 48 <= kSmallTreeBytes; }
 template <bool ANY>
-static inline bool traverse4(const Node4* nodes, const Tri* tris, bool small_tree, const RayPre& r, float tmax, const AnyCtx* ax, Hit* best, Counters* c) {
+static inline bool traverse4(const Node4* nodes, const Tri* tris, bool small_tree, const RayPre& r, float tmax, AnyCtx* ax, Hit* best, Counters* c) {
   best->t = tmax; best->prim = ORC_NONE; best->u = 0.0f; best->v = 0.0f;
   struct Entry { uint32_t key, ref; };
   Entry stack[1024]; int sp = 0;
@@ -478,7 +500,7 @@ Hit trace_closest(const Node* nodes, const Tri* tris, V3 o, V3 d, float tmin, fl
   if (!traverse<false>(nodes, tris, r, tmax, nullptr, &h, c)) { h.t = -1.0f; h.u = 0.0f; h.v = 0.0f; h.prim = ORC_NONE; }
   return h;
 }
-bool trace_any(const Node* nodes, const Tri* tris, V3 o, V3 d, float tmin, float tmax, const AnyCtx* ax, Counters* c) {
+bool trace_any(const Node* nodes, const Tri* tris, V3 o, V3 d, float tmin, float tmax, AnyCtx* ax, Counters* c) {
   RayPre r = make_ray(o, d, tmin);
   Hit h;
   return traverse<true>(nodes, tris, r, tmax, ax, &h, c);
@@ -490,13 +512,14 @@ Hit scene_trace_closest(const orc_scene* s, V3 o, V3 d, float tmin, float tmax, 
   if (!traverse4<false>(s->ext_nodes.data(), s->ext_tris.data(), is_small_tree(s->ext_nodes.size(), s->ext_tris.size()), r, tmax, nullptr, &h, c)) { h.t = -1.0f; h.u = 0.0f; h.v = 0.0f; h.prim = ORC_NONE; }
   return h;
 }
-// RENDER_SPEC 7.1d: how an any-hit ray treats the triangles of a material
+// RENDER_SPEC 7.1d / 7.1g: how an any-hit ray treats the triangles of a material
 int any_class(const orc_scene* s, uint32_t mi) {
   if (mi >= s->materials.size()) return 0;
   const orc_gpu_material& m = s->materials[mi];
-  if (m.opacity == 0.0f) return 1;
-  if (m.opacity < 1.0f) return 2;
-  if (m.base_color_map_index < s->texture_image.size() && s->images[s->texture_image[m.base_color_map_index]].has_alpha) return 2;
+  const bool medium = m.medium_type == 1u || m.medium_type == 2u;
+  if (m.opacity == 0.0f) return medium ? 3 : 1;
+  const bool cutout = m.base_color_map_index < s->texture_image.size() && s->images[s->texture_image[m.base_color_map_index]].has_alpha;
+  if (m.opacity < 1.0f || cutout) return medium ? 4 : 2;
   return 0;
 }
 bool invisible(const orc_scene* s, uint32_t tri_id) { return any_class(s, s->instances[s->tri_instance[tri_id]].material_index) == 1; }
@@ -509,15 +532,20 @@ void make_any_triangles(const orc_scene* s, const std::vector<Tri>& in, std::vec
   for (Tri& t : *out) {
     const int k = any_class(s, s->instances[s->tri_instance[t.id]].material_index);
     if (k == 1) { t.e1[0] = t.e1[1] = t.e1[2] = 0.0f; t.e2[0] = t.e2[1] = t.e2[2] = 0.0f; }
-    t.pad1 = k == 2 ? 1u : 0u;
+    t.pad1 = k == 2 ? 1u : (k == 3 ? 2u : (k == 4 ? 3u : 0u));
   }
 }
-bool scene_trace_any(const orc_scene* s, V3 o, V3 d, float tmin, float tmax, uint32_t key, Counters* c) {
-  const AnyCtx ax{s, key};
-  if (s->ext_nodes.empty()) return trace_any(s->nodes.data(), (s->tris_any.empty() ? s->tris : s->tris_any).data(), o, d, tmin, tmax, &ax, c);
-  RayPre r = make_ray(o, d, tmin);
-  Hit h;
-  return traverse4<true>(s->ext_nodes.data(), (s->ext_tris_any.empty() ? s->ext_tris : s->ext_tris_any).data(), is_small_tree(s->ext_nodes.size(), s->ext_tris.size()), r, tmax, &ax, &h, c);
+bool scene_trace_any(const orc_scene* s, V3 o, V3 d, float tmin, float tmax, uint32_t key, Counters* c, V3* trans) {
+  AnyCtx ax{s, key, {0u, 0u, 0u}};
+  bool occ;
+  if (s->ext_nodes.empty()) occ = trace_any(s->nodes.data(), (s->tris_any.empty() ? s->tris : s->tris_any).data(), o, d, tmin, tmax, &ax, c);
+  else {
+    RayPre r = make_ray(o, d, tmin);
+    Hit h;
+    occ = traverse4<true>(s->ext_nodes.data(), (s->ext_tris_any.empty() ? s->ext_tris : s->ext_tris_any).data(), is_small_tree(s->ext_nodes.size(), s->ext_tris.size()), r, tmax, &ax, &h, c);
+  }
+  if (trans) *trans = any_transmittance(ax);
+  return occ;
 }
 }  // namespace orc
 
@@ -541,7 +569,7 @@ static void trace_batch(const orc_scene* s, const Node* nodes, const Tri* tris, 
       Hit h = trace_closest(nodes, tris, o, d, r.tmin, r.tmax, &c);
       hits[i].t = h.t; hits[i].u = h.u; hits[i].v = h.v; hits[i].prim = h.prim;
     } else {
-      const AnyCtx ax{s, pcg_hash((uint32_t)i ^ kAnyKeyBatch)};  // RENDER_SPEC 7.1d: the key of ray i of a batch
+      AnyCtx ax{s, pcg_hash((uint32_t)i ^ kAnyKeyBatch), {0u, 0u, 0u}};  // RENDER_SPEC 7.1d: the key of ray i of a batch
       bool occ = trace_any(nodes, tris, o, d, r.tmin, r.tmax, &ax, &c);
       hits[i].t = occ ? 1.0f : -1.0f; hits[i].u = 0.0f; hits[i].v = 0.0f; hits[i].prim = ORC_NONE;
     }
@@ -588,9 +616,9 @@ extern "C" void orc_trace_rays_brute(const orc_scene* s, const orc_ray* rays, or
       if (!tri_test(r, tr, &t, &u, &v)) continue;
       if (mode == 1) {  // RENDER_SPEC 7.1d
         const int k = orc::any_class(s, s->instances[s->tri_instance[tr.id]].material_index);
-        Tri flagged = tr; flagged.pad1 = k == 2 ? 1u : 0u;
-        const AnyCtx ax{s, pcg_hash((uint32_t)i ^ kAnyKeyBatch)};
-        if (t > r.tmin && t < ry.tmax && k != 1 && any_hit_blocks(&ax, flagged, u, v)) { any = true; break; }
+        Tri flagged = tr; flagged.pad1 = k == 2 ? 1u : (k == 3 ? 2u : (k == 4 ? 3u : 0u));
+        AnyCtx ax{s, pcg_hash((uint32_t)i ^ kAnyKeyBatch), {0u, 0u, 0u}};
+        if (t > r.tmin && t < ry.tmax && k != 1 && any_hit_event(&ax, flagged, t, 1.0f, u, v)) { any = true; break; }
       }
       else if (t > r.tmin && (t < best.t || (t == best.t && tr.id < best.prim))) best = Hit{t, u, v, tr.id};
     }

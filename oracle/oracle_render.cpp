@@ -690,7 +690,8 @@ static PixelOut trace_path(const Frame& f, uint32_t px, uint32_t py, uint32_t fr
           V3 so = madd3(sf.ng, side, sf.P);
           float tmax = ls.dist >= kTMax ? kTMax : maxf(ls.dist - 2.0f * s->ray_eps, 0.0f);
           st->rays_shadow++;
-          bool occ = scene_trace_any(s, so, ls.wi, 0.0f, tmax, pcg_hash(rng ^ kAnyKeyLight), ctr);  // §7.1d: the connection's key
+          V3 trans;
+          bool occ = scene_trace_any(s, so, ls.wi, 0.0f, tmax, pcg_hash(rng ^ kAnyKeyLight), ctr, &trans);  // §7.1d: the connection's key
           if (!occ) {
             float cosl = fabsf(dot3(sf.ns, ls.wi));
             V3 contrib;
@@ -700,7 +701,9 @@ static PixelOut trace_path(const Frame& f, uint32_t px, uint32_t py, uint32_t fr
               float w = power_heuristic(pl, pdf_b);
               contrib = fb * ls.le * (cosl * w / pl);
             }
-            L = L + T * contrib;
+            V3 tc = T * contrib;
+            if (trans.x != 1.0f || trans.y != 1.0f || trans.z != 1.0f) tc = tc * trans;  // §7.1g: what the media the connection crossed leave of it
+            L = L + tc;
           }
         }
       }
@@ -716,12 +719,15 @@ static PixelOut trace_path(const Frame& f, uint32_t px, uint32_t py, uint32_t fr
           float side = dot3(wi, sf.ng) >= 0.0f ? s->ray_eps : -s->ray_eps;
           V3 so = madd3(sf.ng, side, sf.P);
           st->rays_shadow++;
-          bool occ = scene_trace_any(s, so, wi, 0.0f, kTMax, pcg_hash(rng ^ kAnyKeyEnv), ctr);
+          V3 trans;
+          bool occ = scene_trace_any(s, so, wi, 0.0f, kTMax, pcg_hash(rng ^ kAnyKeyEnv), ctr, &trans);
           if (!occ) {
             float cosl = fabsf(dot3(sf.ns, wi));
             float w = power_heuristic(pdf_e, pdf_b);
             V3 col = env_map_eval(f, wi);
-            L = L + T * (fb * col * (cosl * w / pdf_e));
+            V3 tc = T * (fb * col * (cosl * w / pdf_e));
+            if (trans.x != 1.0f || trans.y != 1.0f || trans.z != 1.0f) tc = tc * trans;
+            L = L + tc;
           }
         }
       }

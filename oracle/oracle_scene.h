@@ -92,20 +92,25 @@ struct Counters { uint64_t nodes = 0, tris = 0; };
 struct Hit { float t, u, v; uint32_t prim; };
 // RENDER_SPEC §4: closest / any traversal over (nodes, tris).
 Hit trace_closest(const Node* nodes, const Tri* tris, V3 o, V3 d, float tmin, float tmax, Counters* c);
-// RENDER_SPEC 7.1d, any-hit rays: 0 = every hit blocks, 1 = invisible (opacity exactly 0), 2 = translucent (blocks with probability
-// opacity x base-colour-map alpha, decided per (ray key, triangle))
+// RENDER_SPEC 7.1d / 7.1g, any-hit rays: 0 = every hit blocks, 1 = invisible (opacity exactly 0, no medium behind it), 2 = translucent
+// (blocks with probability opacity x base-colour-map alpha, decided per (ray key, triangle)), 3 = invisible boundary of a medium (never
+// blocks, adds to the ray's optical depth), 4 = translucent boundary of a medium (2, and 3 when it lets the ray through)
 int any_class(const orc_scene* s, uint32_t material_index);
 bool invisible(const orc_scene* s, uint32_t tri_id);
 // `in` with the triangles of invisible materials made degenerate and those of translucent ones flagged (empty when the scene has neither)
 void make_any_triangles(const orc_scene* s, const std::vector<Tri>& in, std::vector<Tri>* out);
 // what an any-hit ray needs to decide whether a flagged triangle blocks it
-struct AnyCtx { const orc_scene* s; uint32_t key; };
+// tau: the ray's optical depth per channel in 2^-16 units, summed with 32-bit wrap-around arithmetic (order-independent; 7.1g)
+struct AnyCtx { const orc_scene* s; uint32_t key; uint32_t tau[3]; };
 float hit_alpha(const orc_scene* s, uint32_t prim, float u, float v);  // opacity x base-colour-map alpha (bilinear, level 0) at a hit
-bool any_hit_blocks(const AnyCtx* ax, const Tri& tr, float u, float v);
-bool trace_any(const Node* nodes, const Tri* tris, V3 o, V3 d, float tmin, float tmax, const AnyCtx* ax, Counters* c);
+// a triangle of the any-hit copy was hit inside (tmin, tmax) at distance t with Moeller-Trumbore determinant det: true = it blocks the ray
+bool any_hit_event(AnyCtx* ax, const Tri& tr, float t, float det, float u, float v);
+bool trace_any(const Node* nodes, const Tri* tris, V3 o, V3 d, float tmin, float tmax, AnyCtx* ax, Counters* c);
+V3 any_transmittance(const AnyCtx& ax);  // exp_neg(-max(tau, 0) / 65536) per channel
 // the same on the scene's tree of choice: the product's 4-wide tree if one was handed over, else the oracle's own BVH2
 Hit scene_trace_closest(const orc_scene* s, V3 o, V3 d, float tmin, float tmax, Counters* c);
-bool scene_trace_any(const orc_scene* s, V3 o, V3 d, float tmin, float tmax, uint32_t key, Counters* c);
+// trans (may be null): what an unblocked ray keeps after the media it crossed (7.1g)
+bool scene_trace_any(const orc_scene* s, V3 o, V3 d, float tmin, float tmax, uint32_t key, Counters* c, V3* trans = nullptr);
 constexpr uint32_t kAnyKeyLight = 0xA511E9B3u, kAnyKeyEnv = 0x63D83595u, kAnyKeyBatch = 0x5BD1E995u;
 V3 tonemap_select(V3 color, int enable_tonemap, int enable_aces, int use_simple_aces);
 }  // namespace orc

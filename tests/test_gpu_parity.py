@@ -985,6 +985,45 @@ def test_translucent_shadow_rays_bit_exact(halart, oracle, big):
     r.close()
 
 
+@pytest.mark.parametrize("big", [False, True])
+@pytest.mark.parametrize("opacity", [0.0, 0.5])
+def test_media_on_connections_bit_exact(halart, oracle, big, opacity):
+    """RENDER_SPEC 7.1g: connections that cross a slab of absorbing medium (behind an invisible or a half-opaque boundary) and a ball of
+    scattering fog keep exp(-optical depth) of their contribution; the optical depth is an order-independent fixed-point sum over the
+    boundary crossings, so the LDS-staged kernels, the wave-cooperative large-scene kernels (`big`) and the oracle agree bit for bit"""
+    from test_oracle_render import slab_over_floor_scene
+    s = slab_over_floor_scene(medium=H.HalaMedium(1, (0.2, 0.5, 0.8), 2.0, 0.0), opacity=opacity)
+    fog = scenes.blob_mesh(subdivisions=2, amplitude=0.0)
+    fog.material_index = len(s.materials)
+    s.materials.append(H.HalaMaterial(type=0, base_color=(1.0, 1.0, 1.0), roughness=0.5, opacity=0.0, medium=H.HalaMedium(2, (0.95, 0.9, 0.8), 0.8, 0.3)))
+    s.meshes.append(H.HalaMesh([fog]))
+    m = np.eye(4, dtype=np.float32); m[:3, :3] *= 0.7; m[:3, 3] = (0.8, 1.0, -0.3)
+    s.nodes.append(H.HalaNode(name="fog", mesh_index=len(s.meshes) - 1, local_transform=m))
+    if big:
+        blob = scenes.blob_mesh(subdivisions=4)
+        blob.material_index = 0
+        s.meshes.append(H.HalaMesh([blob]))
+        m2 = np.eye(4, dtype=np.float32); m2[:3, :3] *= 0.4; m2[:3, 3] = (-1.2, 0.5, -0.8)
+        s.nodes.append(H.HalaNode(name="blob", mesh_index=len(s.meshes) - 1, local_transform=m2))
+    env = scenes.sky_sun_envmap(64, 32, sun_gain=50.0)
+    r = make_renderer(halart, s, 64, 64, max_depth=5, rr_depth=2, env=env)
+    assert (r.bvh_info().lds_node_count == 0) == big
+    osc = oracle.OracleScene(s, envmap=env)
+    rays = random_rays(6000, np.array((-5, 0.05, -5.0)), np.array((5, 4, 5.0)), 9)
+    for mode in (0, 1):
+        assert r.trace_rays_host(rays, mode).tobytes() == osc.trace(rays, mode).tobytes(), mode
+    r.update(); r.update_batch(3); r.render()
+    imgs, st = osc.render(64, 64, frames=4, max_depth=5, rr_depth=2)
+    assert_images_equal(r, imgs)
+    stg = r.statistics()
+    assert (stg.rays_closest_total, stg.rays_shadow_total) == (st.rays_closest, st.rays_shadow)
+    # without the media the frame is visibly brighter under the slab
+    s.materials[1].medium = H.HalaMedium()
+    plain, _ = oracle.OracleScene(s, envmap=env).render(64, 64, frames=4, max_depth=5, rr_depth=2)
+    assert float(plain[0][..., :3].mean()) > float(imgs[0][..., :3].mean()) * 1.02
+    r.close()
+
+
 @pytest.mark.parametrize("boundary", ["glass", "invisible"])
 def test_render_scattering_medium_bit_exact(halart, oracle, boundary):
     """RENDER_SPEC 7.1f: free-flight sampling (polynomial log), Henyey-Greenstein scattering, no NEE at scattering vertices (the
