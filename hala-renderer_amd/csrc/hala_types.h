@@ -106,6 +106,7 @@ struct SceneView {
   const float* env_conditional;  // set 0 binding 7[1]
   uint32_t node_count, tri_count, lds_nodes, lds_tris;
   uint32_t any_translucent;   // 1: some material is translucent or bounds a medium (RENDER_SPEC 7.1d / 7.1g): the any-hit launches run their ALPHA variants
+  uint32_t scatter_media;     // 1: some material holds a scattering medium (RENDER_SPEC 7.1f): the SCATTER shade kernels apply
   uint32_t simple_materials;  // 1: every material is an untextured, opaque DIFFUSE one without a medium (the SIMPLE shade kernels apply)
   float ray_eps;
   uint32_t staged;  // 1: the whole BVH fits the LDS budget (lds_nodes == node_count, lds_tris == tri_count) and is staged per workgroup

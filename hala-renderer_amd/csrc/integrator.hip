@@ -387,7 +387,8 @@ k_trace_shadow_then_batch(SceneView sv, const Tri* __restrict__ tris_any, Queues
 #ifndef RT_SHADE_WAVES_SIMPLE
 #define RT_SHADE_WAVES_SIMPLE 6  // 80 VGPRs, no scratch (8 waves: 32-44 B of scratch per lane and slower; profiles/r02_experiments.txt)
 #endif
-template <bool PRIMARY, bool SIMPLE>
+// SCATTER: some material holds a scattering medium (§7.1f): only then does the kernel carry the free-flight / phase-function code
+template <bool PRIMARY, bool SIMPLE, bool SCATTER>
 __global__ void __launch_bounds__(kShadeThreads, SIMPLE ? RT_SHADE_WAVES_SIMPLE : RT_SHADE_WAVES) k_shade(FrameConst fc, SceneView sv, Queues q, PathState ps, Control* __restrict__ ctl, uint32_t depth) {
   __shared__ BlockCompact s_compact;
   const uint32_t n = PRIMARY ? fc.slot_count : ctl->n_active[depth];
@@ -458,7 +459,7 @@ __global__ void __launch_bounds__(kShadeThreads, SIMPLE ? RT_SHADE_WAVES_SIMPLE 
   if (real) {
     // L: what this bounce adds to the path's radiance (at most one term: light hit | environment | emission)
     f3 T = splat3(1.0f), L = splat3(0.0f);
-    float prev_pdf = 0.0f;
+    float prev_pdf = kNoNeePdf;  // no vertex has sampled a direction yet: an emitter reached through skipped (7.1d) surfaces counts in full
     if (!PRIMARY) {  // the whole state of a live path is its queue entry: coalesced reads, no gather by slot
       const float4* rp = reinterpret_cast<const float4*>(q.rays[in] + i);
       const float4 ro = rp[0], rd = rp[1], st = q.state[in][i];
@@ -516,23 +517,15 @@ __global__ void __launch_bounds__(kShadeThreads, SIMPLE ? RT_SHADE_WAVES_SIMPLE 
       }
       T = T * sf.absorb;
       bool through = false, scattered = false;
-      if (sf.sigma > 0.0f) {  // §7.1f: free flight through a scattering medium; the surface is only reached if the flight outlasts the segment
+      f3 pm = sf.P;        // the vertex the path is at: the surface point, or the scattering point inside the medium
+      float hg_g = 0.0f;
+      if (SCATTER && sf.sigma > 0.0f) {  // §7.1f: free flight through a scattering medium; the surface is only reached if the flight outlasts the segment
         const float rs = rng_next(rng);
         const float dist = -log_poly(1.0f - rs) / sf.sigma;
         if (dist < hv.x) {
-          const float r1 = rng_next(rng), r2 = rng_next(rng);
-          const f3 wi = hg_sample(d, sf.hg, r1, r2);
           T = T * sf.scol;
-          prev_pdf = kNoNeePdf;  // no next-event estimation at a scattering vertex: an emitter reached next counts in full
-          bool alive = true;
-          if (depth >= fc.u.rr_depth) {
-            const float qq = minf(max3f(T), 0.95f);
-            const float rr = rng_next(rng);
-            if (!(rr < qq)) alive = false; else T = T * (1.0f / qq);
-          }
-          if (depth + 1u >= fc.u.max_depth) alive = false;
-          keep[0] = alive;
-          if (alive) { no = madd3(d, dist, o); nd = wi; }
+          pm = madd3(d, dist, o);  // no offset: the point is inside the object
+          hg_g = sf.hg;
           scattered = true;
         }
       }
@@ -540,8 +533,7 @@ __global__ void __launch_bounds__(kShadeThreads, SIMPLE ? RT_SHADE_WAVES_SIMPLE 
         const float ro = rng_next(rng);
         through = !(ro < sf.mat.opacity);
       }
-      if (scattered) {
-      } else if (through) {
+      if (through) {
         const bool alive = depth + 1u < fc.u.max_depth;
         keep[0] = alive;
         if (alive) {
@@ -549,21 +541,26 @@ __global__ void __launch_bounds__(kShadeThreads, SIMPLE ? RT_SHADE_WAVES_SIMPLE 
           nd = d;
         }
       } else {
-      const f3 em = sf.mat.emission;
-      if (em.x > 0.0f || em.y > 0.0f || em.z > 0.0f) L = L + T * em;
+      // a vertex with next-event estimation: a surface (BSDF, cosine, offset origin) or — §7.1f — a scattering point (Henyey-Greenstein
+      // phase function: value = pdf, no cosine, the connection starts at the point itself and is attenuated on its way out by §7.1g)
+      if (!scattered) {
+        const f3 em = sf.mat.emission;
+        if (em.x > 0.0f || em.y > 0.0f || em.z > 0.0f) L = L + T * em;
+      }
       const f3 wo = -d;
       if (nl > 0u) {  // NEE: one light
         const float rl = rng_next(rng), r1 = rng_next(rng), r2 = rng_next(rng);
         const uint32_t idx = min((uint32_t)(rl * (float)nl), nl - 1u);
-        const LightSample ls = sample_light(sv.lights[idx], sf.P, r1, r2);
+        const LightSample ls = sample_light(sv.lights[idx], pm, r1, r2);
         if (ls.valid) {
           f3 fb; float pdf_b;
-          bsdf_eval(sf.mat, wo, ls.wi, sf.ns, &fb, &pdf_b);
+          if (scattered) { pdf_b = hg_phase(hg_g, dot3(d, ls.wi)); fb = splat3(pdf_b); }
+          else bsdf_eval(sf.mat, wo, ls.wi, sf.ns, &fb, &pdf_b);
           if (pdf_b > 0.0f) {
             const float side = dot3(ls.wi, sf.ng) >= 0.0f ? sv.ray_eps : -sv.ray_eps;
-            const f3 so = madd3(sf.ng, side, sf.P);
+            const f3 so = scattered ? pm : madd3(sf.ng, side, sf.P);
             const float tmax = ls.dist >= kTMax ? kTMax : maxf(ls.dist - 2.0f * sv.ray_eps, 0.0f);
-            const float cosl = fabsf(dot3(sf.ns, ls.wi));  // |cos|: a connection may leave through the surface (§7.1c)
+            const float cosl = scattered ? 1.0f : fabsf(dot3(sf.ns, ls.wi));  // |cos|: a connection may leave through the surface (§7.1c)
             f3 contrib;
             if (ls.delta) contrib = fb * ls.le * (cosl * (float)nl);
             else {
@@ -584,11 +581,12 @@ __global__ void __launch_bounds__(kShadeThreads, SIMPLE ? RT_SHADE_WAVES_SIMPLE 
         f3 wi; float pdf_e;
         if (env_map_sample(fc, sv, r1, r2, &wi, &pdf_e)) {
           f3 fb; float pdf_b;
-          bsdf_eval(sf.mat, wo, wi, sf.ns, &fb, &pdf_b);
+          if (scattered) { pdf_b = hg_phase(hg_g, dot3(d, wi)); fb = splat3(pdf_b); }
+          else bsdf_eval(sf.mat, wo, wi, sf.ns, &fb, &pdf_b);
           if (pdf_b > 0.0f) {
             const float side = dot3(wi, sf.ng) >= 0.0f ? sv.ray_eps : -sv.ray_eps;
-            const f3 so = madd3(sf.ng, side, sf.P);
-            const float cosl = fabsf(dot3(sf.ns, wi));
+            const f3 so = scattered ? pm : madd3(sf.ng, side, sf.P);
+            const float cosl = scattered ? 1.0f : fabsf(dot3(sf.ns, wi));
             const float w = power_heuristic(pdf_e, pdf_b);
             const f3 col = env_map_eval(fc, sv, wi);
             const f3 tc = T * (fb * col * (cosl * w / pdf_e));
@@ -600,11 +598,19 @@ __global__ void __launch_bounds__(kShadeThreads, SIMPLE ? RT_SHADE_WAVES_SIMPLE 
         }
       }
       // continue the path
-      const float r1 = rng_next(rng), r2 = rng_next(rng), r3 = rng_next(rng);
-      f3 wi, fb; float pdf_b;
-      if (bsdf_sample(sf.mat, wo, sf.ns, r1, r2, r3, &wi, &fb, &pdf_b)) {
-        T = T * fb * (fabsf(dot3(sf.ns, wi)) / pdf_b);
-        prev_pdf = pdf_b;
+      f3 wi = d; bool sampled;
+      if (scattered) {
+        const float r1 = rng_next(rng), r2 = rng_next(rng);
+        wi = hg_sample(d, hg_g, r1, r2);
+        prev_pdf = hg_phase(hg_g, dot3(d, wi));  // the phase function is sampled exactly: throughput unchanged, the pdf goes to the next vertex's MIS weight
+        sampled = true;
+      } else {
+        const float r1 = rng_next(rng), r2 = rng_next(rng), r3 = rng_next(rng);
+        f3 fb; float pdf_b;
+        sampled = bsdf_sample(sf.mat, wo, sf.ns, r1, r2, r3, &wi, &fb, &pdf_b);
+        if (sampled) { T = T * fb * (fabsf(dot3(sf.ns, wi)) / pdf_b); prev_pdf = pdf_b; }
+      }
+      if (sampled) {
         bool alive = true;
         if (depth >= fc.u.rr_depth) {
           const float qq = minf(max3f(T), 0.95f);
@@ -615,7 +621,7 @@ __global__ void __launch_bounds__(kShadeThreads, SIMPLE ? RT_SHADE_WAVES_SIMPLE 
         keep[0] = alive;
         if (alive) {
           const float side = dot3(wi, sf.ng) >= 0.0f ? sv.ray_eps : -sv.ray_eps;
-          no = madd3(sf.ng, side, sf.P);
+          no = scattered ? pm : madd3(sf.ng, side, sf.P);
           nd = wi;
         }
       }
@@ -792,11 +798,14 @@ void launch_trace_primary(const LaunchCfg& lc, const SceneView& sv, const FrameC
 void launch_shade(const FrameConst& fc, const SceneView& sv, const Queues& q, const PathState& ps, Control* ctl, uint32_t depth, hipStream_t s) {
   const dim3 grid(blocks_for(fc.slot_count, kShadeThreads)), block(kShadeThreads);
   if (sv.simple_materials) {
-    if (depth == 0u) hipLaunchKernelGGL((k_shade<true, true>), grid, block, 0, s, fc, sv, q, ps, ctl, depth);
-    else hipLaunchKernelGGL((k_shade<false, true>), grid, block, 0, s, fc, sv, q, ps, ctl, depth);
+    if (depth == 0u) hipLaunchKernelGGL((k_shade<true, true, false>), grid, block, 0, s, fc, sv, q, ps, ctl, depth);
+    else hipLaunchKernelGGL((k_shade<false, true, false>), grid, block, 0, s, fc, sv, q, ps, ctl, depth);
+  } else if (sv.scatter_media) {
+    if (depth == 0u) hipLaunchKernelGGL((k_shade<true, false, true>), grid, block, 0, s, fc, sv, q, ps, ctl, depth);
+    else hipLaunchKernelGGL((k_shade<false, false, true>), grid, block, 0, s, fc, sv, q, ps, ctl, depth);
   } else {
-    if (depth == 0u) hipLaunchKernelGGL((k_shade<true, false>), grid, block, 0, s, fc, sv, q, ps, ctl, depth);
-    else hipLaunchKernelGGL((k_shade<false, false>), grid, block, 0, s, fc, sv, q, ps, ctl, depth);
+    if (depth == 0u) hipLaunchKernelGGL((k_shade<true, false, false>), grid, block, 0, s, fc, sv, q, ps, ctl, depth);
+    else hipLaunchKernelGGL((k_shade<false, false, false>), grid, block, 0, s, fc, sv, q, ps, ctl, depth);
   }
 }
 void launch_resolve(const FrameConst& fc, const PathState& ps, float4* accum, float4* albedo, float4* normal, float4* final_img, hipStream_t s) {

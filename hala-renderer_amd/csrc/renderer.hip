@@ -119,7 +119,7 @@ struct hala_rt_renderer {
   DeviceArray<hala_gpu_light> d_lights;
   DeviceArray<hala_gpu_material> d_materials;
   DeviceArray<uint8_t> d_material_kind;
-  bool shade_sort = false, simple_materials = false;
+  bool shade_sort = false, simple_materials = false, scatter_media = false;
   DeviceArray<hala_gpu_mesh_data> d_instances;
   DeviceArray<uint32_t> d_inst_first_tri;
   DeviceArray<float4> d_tex_arena;
@@ -220,7 +220,7 @@ struct hala_rt_renderer {
     sv.nodes = d_nodes.ptr; sv.tris = d_tris.ptr; sv.tris_any = any_invisible ? d_tris_any.ptr : d_tris.ptr; sv.tris_by_id = d_tris_by_id.ptr; sv.shade_tris = d_shade_tris.ptr; sv.tri_instance = d_tri_instance.ptr;
     sv.inst_first_tri = d_inst_first_tri.ptr; sv.primitives = d_instances.ptr; sv.materials = d_materials.ptr; sv.material_kind = d_material_kind.ptr;
     sv.lights = d_lights.ptr; sv.cameras = d_cameras.ptr;
-    sv.textures = d_textures.ptr; sv.tex_arena = d_tex_arena.ptr; sv.texture_count = (uint32_t)host_textures.size(); sv.shade_sort = shade_sort ? 1u : 0u; sv.simple_materials = simple_materials ? 1u : 0u; sv.any_translucent = any_translucent ? 1u : 0u;
+    sv.textures = d_textures.ptr; sv.tex_arena = d_tex_arena.ptr; sv.texture_count = (uint32_t)host_textures.size(); sv.shade_sort = shade_sort ? 1u : 0u; sv.simple_materials = simple_materials ? 1u : 0u; sv.scatter_media = scatter_media ? 1u : 0u; sv.any_translucent = any_translucent ? 1u : 0u;
     sv.env_pixels = reinterpret_cast<const float*>(d_env.ptr); sv.env_marginal = d_marginal.ptr; sv.env_conditional = d_conditional.ptr;
     sv.node_count = bvh.node_count; sv.tri_count = bvh.tri_count; sv.lds_nodes = lds_nodes; sv.lds_tris = lds_tris;
     sv.ray_eps = ray_eps;
@@ -401,6 +401,8 @@ int upload_packed(hala_rt_renderer* r, bool geometry = true) {
     uint32_t seen = 0;
     for (uint8_t k : kind) seen |= 1u << k;
     r->shade_sort = (seen & (seen - 1u)) != 0u;  // two kinds or more (a one-kind scene like the Cornell box only pays for the sort)
+    r->scatter_media = false;
+    for (const auto& m : hs.gpu_materials) r->scatter_media = r->scatter_media || m.medium_type == 2u;
     r->simple_materials = seen == (1u << kShadeKindFirst);  // nothing but untextured opaque DIFFUSE: the SIMPLE shade kernels (configs[1])
     if (getenv("HALART_NO_SIMPLE_SHADE")) r->simple_materials = false;  // A/B knob
   }

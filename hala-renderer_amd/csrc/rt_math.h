@@ -204,6 +204,15 @@ RT_DI f3 hg_sample(f3 d, float g, float u1, float u2) {
   onb(d, &t, &b);
   return to_world(f3{st * c, st * s, ct}, t, b, d);
 }
+// Henyey-Greenstein phase function (= the pdf of hg_sample) for the cosine c between the propagation direction and the new one
+RT_DI float hg_phase(float g, float c) {
+  g = minf(maxf(g, -0.99f), 0.99f);
+  if (fabsf(g) < 1e-3f) return 0.07957747154594767f;  // 1 / (4 pi)
+  c = minf(maxf(c, -1.0f), 1.0f);
+  const float g2 = g * g;
+  const float x = (1.0f + g2) - (2.0f * g) * c;
+  return (1.0f - g2) / (12.566370614359172f * (x * sqrtf(x)));
+}
 RT_DI float luminance(f3 c) { return 0.212671f * c.x + 0.715160f * c.y + 0.072169f * c.z; }
 RT_DI float power_heuristic(float a, float b) {
   float a2 = a * a;

@@ -615,7 +615,7 @@ static PixelOut trace_path(const Frame& f, uint32_t px, uint32_t py, uint32_t fr
   V3 o, d;
   camera_ray(f, px, py, &rng, &o, &d);
   V3 L = v3s(0.0f), T = v3s(1.0f);
-  float prev_pdf = 0.0f;
+  float prev_pdf = kNoNeePdf;  // no vertex has sampled a direction yet: an emitter reached through skipped (7.1d) surfaces counts in full
   PixelOut out; out.albedo = v3s(0.0f); out.normal = v3s(0.0f);
   const uint32_t nl = (uint32_t)s->light_count;
   for (uint32_t depth = 0; depth < f.p.max_depth; ++depth) {
@@ -651,49 +651,48 @@ static PixelOut trace_path(const Frame& f, uint32_t px, uint32_t py, uint32_t fr
     if (depth == 0) { out.albedo = sf.base; out.normal = sf.ns; }
     if (sf.glow.x > 0.0f || sf.glow.y > 0.0f || sf.glow.z > 0.0f) L = L + T * sf.glow;  // §7.1e, before the absorption of the same segment... (only one of the two is ever set)
     T = T * sf.absorb;
+    bool scattered = false;
+    V3 pm = sf.P;       // the vertex the path is at: the surface point, or the scattering point inside the medium
+    float hg_g = 0.0f;
     if (sf.sigma > 0.0f) {  // §7.1f: free flight through a scattering medium; the surface is only reached if the flight outlasts the segment
       float rs = rng_next(&rng);
       float dist = -log_poly(1.0f - rs) / sf.sigma;
       if (dist < h.t) {
-        float r1 = rng_next(&rng), r2 = rng_next(&rng);
-        V3 wi = hg_sample(d, sf.hg, r1, r2);
         T = T * sf.scol;
-        prev_pdf = kNoNeePdf;  // no next-event estimation at a scattering vertex: an emitter reached next counts in full
-        if (depth >= f.p.rr_depth) {
-          float q = minf(max3f(T), 0.95f);
-          float rr = rng_next(&rng);
-          if (!(rr < q)) break;
-          T = T * (1.0f / q);
-        }
-        o = madd3(d, dist, o);
-        d = wi;
-        continue;
+        pm = madd3(d, dist, o);  // no offset: the point is inside the object
+        hg_g = sf.hg;
+        scattered = true;
       }
     }
-    if (sf.opacity < 1.0f) {  // §7.1d: the surface is skipped with probability 1 - opacity (one extra random number, drawn only here)
+    if (!scattered && sf.opacity < 1.0f) {  // §7.1d: the surface is skipped with probability 1 - opacity (one extra random number, drawn only here)
       float ro = rng_next(&rng);
       if (!(ro < sf.opacity)) { o = madd3(sf.ng, -s->ray_eps, sf.P); continue; }
     }
-    V3 em = ld3(sf.m.emission);
-    if (em.x > 0.0f || em.y > 0.0f || em.z > 0.0f) L = L + T * em;
+    // a vertex with next-event estimation: a surface (BSDF, cosine, offset origin) or — §7.1f — a scattering point (Henyey-Greenstein
+    // phase function: value = pdf, no cosine, the connection starts at the point itself and is attenuated on its way out by §7.1g)
+    if (!scattered) {
+      V3 em = ld3(sf.m.emission);
+      if (em.x > 0.0f || em.y > 0.0f || em.z > 0.0f) L = L + T * em;
+    }
     V3 wo = -d;
     // next-event estimation: one light
     if (nl > 0) {
       float rl = rng_next(&rng), r1 = rng_next(&rng), r2 = rng_next(&rng);
       uint32_t idx = std::min((uint32_t)(rl * (float)nl), nl - 1);
-      LightSample ls = sample_light(s->lights[idx], sf.P, r1, r2);
+      LightSample ls = sample_light(s->lights[idx], pm, r1, r2);
       if (ls.valid) {
         V3 fb; float pdf_b;
-        bsdf_eval(sf.m, sf.base, sf.tr, wo, ls.wi, sf.ns, &fb, &pdf_b);
+        if (scattered) { pdf_b = hg_phase(hg_g, dot3(d, ls.wi)); fb = v3s(pdf_b); }
+        else bsdf_eval(sf.m, sf.base, sf.tr, wo, ls.wi, sf.ns, &fb, &pdf_b);
         if (pdf_b > 0.0f) {
           float side = dot3(ls.wi, sf.ng) >= 0.0f ? s->ray_eps : -s->ray_eps;
-          V3 so = madd3(sf.ng, side, sf.P);
+          V3 so = scattered ? pm : madd3(sf.ng, side, sf.P);
           float tmax = ls.dist >= kTMax ? kTMax : maxf(ls.dist - 2.0f * s->ray_eps, 0.0f);
           st->rays_shadow++;
           V3 trans;
           bool occ = scene_trace_any(s, so, ls.wi, 0.0f, tmax, pcg_hash(rng ^ kAnyKeyLight), ctr, &trans);  // §7.1d: the connection's key
           if (!occ) {
-            float cosl = fabsf(dot3(sf.ns, ls.wi));
+            float cosl = scattered ? 1.0f : fabsf(dot3(sf.ns, ls.wi));
             V3 contrib;
             if (ls.delta) contrib = fb * ls.le * (cosl * (float)nl);
             else {
@@ -714,15 +713,16 @@ static PixelOut trace_path(const Frame& f, uint32_t px, uint32_t py, uint32_t fr
       V3 wi; float pdf_e;
       if (env_map_sample(f, r1, r2, &wi, &pdf_e)) {
         V3 fb; float pdf_b;
-        bsdf_eval(sf.m, sf.base, sf.tr, wo, wi, sf.ns, &fb, &pdf_b);
+        if (scattered) { pdf_b = hg_phase(hg_g, dot3(d, wi)); fb = v3s(pdf_b); }
+        else bsdf_eval(sf.m, sf.base, sf.tr, wo, wi, sf.ns, &fb, &pdf_b);
         if (pdf_b > 0.0f) {
           float side = dot3(wi, sf.ng) >= 0.0f ? s->ray_eps : -s->ray_eps;
-          V3 so = madd3(sf.ng, side, sf.P);
+          V3 so = scattered ? pm : madd3(sf.ng, side, sf.P);
           st->rays_shadow++;
           V3 trans;
           bool occ = scene_trace_any(s, so, wi, 0.0f, kTMax, pcg_hash(rng ^ kAnyKeyEnv), ctr, &trans);
           if (!occ) {
-            float cosl = fabsf(dot3(sf.ns, wi));
+            float cosl = scattered ? 1.0f : fabsf(dot3(sf.ns, wi));
             float w = power_heuristic(pdf_e, pdf_b);
             V3 col = env_map_eval(f, wi);
             V3 tc = T * (fb * col * (cosl * w / pdf_e));
@@ -733,11 +733,18 @@ static PixelOut trace_path(const Frame& f, uint32_t px, uint32_t py, uint32_t fr
       }
     }
     // continue the path
-    float r1 = rng_next(&rng), r2 = rng_next(&rng), r3 = rng_next(&rng);
-    V3 wi, fb; float pdf_b;
-    if (!bsdf_sample(sf.m, sf.base, sf.tr, wo, sf.ns, r1, r2, r3, &wi, &fb, &pdf_b)) break;
-    T = T * fb * (fabsf(dot3(sf.ns, wi)) / pdf_b);
-    prev_pdf = pdf_b;
+    V3 wi;
+    if (scattered) {
+      float r1 = rng_next(&rng), r2 = rng_next(&rng);
+      wi = hg_sample(d, hg_g, r1, r2);
+      prev_pdf = hg_phase(hg_g, dot3(d, wi));  // the phase function is sampled exactly: throughput unchanged, the pdf goes to the next vertex's MIS weight
+    } else {
+      float r1 = rng_next(&rng), r2 = rng_next(&rng), r3 = rng_next(&rng);
+      V3 fb; float pdf_b;
+      if (!bsdf_sample(sf.m, sf.base, sf.tr, wo, sf.ns, r1, r2, r3, &wi, &fb, &pdf_b)) break;
+      T = T * fb * (fabsf(dot3(sf.ns, wi)) / pdf_b);
+      prev_pdf = pdf_b;
+    }
     if (depth >= f.p.rr_depth) {
       float q = minf(max3f(T), 0.95f);
       float rr = rng_next(&rng);
@@ -745,7 +752,7 @@ static PixelOut trace_path(const Frame& f, uint32_t px, uint32_t py, uint32_t fr
       T = T * (1.0f / q);
     }
     float side = dot3(wi, sf.ng) >= 0.0f ? s->ray_eps : -s->ray_eps;
-    o = madd3(sf.ng, side, sf.P);
+    o = scattered ? pm : madd3(sf.ng, side, sf.P);
     d = wi;
   }
   if (!(std::isfinite(L.x) && std::isfinite(L.y) && std::isfinite(L.z))) L = v3s(0.0f);

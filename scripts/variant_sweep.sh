@@ -25,4 +25,4 @@ for v in "$@"; do
     *) build "$v"; rebuilt=1; echo "$v"; run "";;
   esac
 done
-[ $rebuilt = 1 ] && build ""
+if [ $rebuilt = 1 ]; then build ""; fi
