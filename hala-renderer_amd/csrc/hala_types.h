@@ -75,10 +75,21 @@ static_assert(sizeof(ShadeTri) == 128, "shading record is 128 B");
 // texture arena (8-bit sources are decoded once at upload; gen_mipmaps of gpu_uploader.rs:366-400 is a 2x2 box filter
 // kernel).  mip_offset[l] = first texel of level l, in float4 units from the arena base.
 constexpr uint32_t kMaxMips = 16;
+// Texel storage (RENDER_SPEC 7.4).  Float images: linear RGBA32F, row-major, in the float arena.  8-bit images stay 8-bit — 4 B per
+// texel in the byte arena, tiled 4x4 (a 64-B line holds a 4x4 block: a bilinear footprint touches 1.6 lines on average instead of 2.5,
+// and the whole set of textures is a quarter of the RGBA32F size: the bounce shade is bound by random 64-B requests) — and the sampler
+// decodes them: sRGB bytes through a 256-entry table (what the *_SRGB sampler of the reference does), UNORM bytes / 255.
+constexpr uint32_t kTexFloat = 0, kTexSrgb8 = 1, kTexUnorm8 = 2;
 struct TexDesc {
-  uint32_t width, height, mips, pad;
-  uint32_t mip_offset[kMaxMips];
+  uint32_t width, height, mips, format;
+  uint32_t mip_offset[kMaxMips];  // first texel of level l in its arena (float4 units / tiled 4-B texels: level l holds ceil(w/4) x ceil(h/4) tiles of 16)
 };
+// index of texel (x, y) inside a tiled level of width w (x < w, y < h)
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline uint32_t tex_tiled_index(uint32_t x, uint32_t y, uint32_t w) { return (((y >> 2) * ((w + 3u) >> 2) + (x >> 2)) << 4) + ((y & 3u) << 2) + (x & 3u); }
+inline uint32_t tex_tiled_size(uint32_t w, uint32_t h) { return ((w + 3u) >> 2) * ((h + 3u) >> 2) * 16u; }
 static_assert(sizeof(TexDesc) == 80, "texture descriptor is 80 B");
 
 // What every kernel of one update() sees (the "descriptor sets" of src/rt_renderer.rs:141-209, :671-745 as
@@ -86,6 +97,8 @@ static_assert(sizeof(TexDesc) == 80, "texture descriptor is 80 B");
 struct SceneView {
   const TexDesc* textures;   // set 2 binding 0, indexed by the material's *_map_index
   const float4* tex_arena;
+  const uint32_t* tex_arena8;  // 8-bit images (RGBA bytes, tiled 4x4)
+  const float* tex_lut;        // 512 floats: the sRGB EOTF, then b / 255 (shading.h::tex8_fetch)
   uint32_t texture_count;
   uint32_t shade_sort;  // 1: the scene's materials span several shading kinds — the bounce shade kernel regroups its paths by kind
   const BvhNode4* nodes;

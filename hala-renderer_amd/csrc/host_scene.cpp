@@ -10,6 +10,19 @@
 
 namespace rt {
 
+const float* srgb_decode_lut() {  // sRGB EOTF (the *_SRGB formats of gltf_loader.rs:395-396 are decoded by the sampler in the reference)
+  static float lut[256];
+  static bool ready = false;
+  if (!ready) {
+    for (int i = 0; i < 256; ++i) {
+      const double c = i / 255.0;
+      lut[i] = (float)(c <= 0.04045 ? c / 12.92 : std::pow((c + 0.055) / 1.055, 2.4));
+    }
+    ready = true;
+  }
+  return lut;
+}
+
 // glam::Mat4 * Mat4 (column-major): column c of the product = ((A.x*b.x + A.y*b.y) + A.z*b.z) + A.w*b.w
 static Mat4 mul(const Mat4& a, const Mat4& b) {
   Mat4 r;
@@ -75,38 +88,26 @@ std::string HostScene::assign(const hala_scene_desc* d) {
   // becomes one linear RGBA32F level-0 image (8-bit data decoded here once; the mip chain is built on the GPU).
   images.clear(); texture_image.clear();
   {
-    static float srgb_lut[256];
-    static bool lut_ready = false;
-    if (!lut_ready) {  // sRGB EOTF (the *_SRGB formats of gltf_loader.rs:395-396 are decoded by the sampler in the reference)
-      for (int i = 0; i < 256; ++i) {
-        const double c = i / 255.0;
-        srgb_lut[i] = (float)(c <= 0.04045 ? c / 12.92 : std::pow((c + 0.055) / 1.055, 2.4));
-      }
-      lut_ready = true;
-    }
     for (uint32_t k = 0; k < d->image_data_count; ++k) {
       const hala_image_desc& im = d->image_data[k];
       if (!im.data || !im.width || !im.height) return "The image data is empty.";
       HostImage32F out;
       out.width = im.width; out.height = im.height;
       const size_t n = (size_t)im.width * im.height;
-      out.rgba.resize(n * 4);
       if (im.format == HALA_FORMAT_R32G32B32A32_SFLOAT) {
         if (im.num_of_bytes < n * 16) return "The image data is too small.";
+        out.format = kTexFloat;
+        out.rgba.resize(n * 4);
         memcpy(out.rgba.data(), im.data, n * 16);
+        for (size_t i = 0; i < n && !out.has_alpha; ++i) out.has_alpha = out.rgba[4 * i + 3] < 1.0f;
       } else if (im.format == HALA_FORMAT_R8G8B8A8_UNORM || im.format == HALA_FORMAT_R8G8B8A8_SRGB || im.format == HALA_FORMAT_B8G8R8A8_UNORM) {
         if (im.num_of_bytes < n * 4) return "The image data is too small.";
-        const uint8_t* p = static_cast<const uint8_t*>(im.data);
-        for (size_t i = 0; i < n; ++i) {
-          const uint8_t b0 = p[4 * i], b1 = p[4 * i + 1], b2 = p[4 * i + 2], b3 = p[4 * i + 3];
-          float* o = &out.rgba[4 * i];
-          if (im.format == HALA_FORMAT_R8G8B8A8_SRGB) { o[0] = srgb_lut[b0]; o[1] = srgb_lut[b1]; o[2] = srgb_lut[b2]; }
-          else if (im.format == HALA_FORMAT_B8G8R8A8_UNORM) { o[0] = (float)b2 / 255.0f; o[1] = (float)b1 / 255.0f; o[2] = (float)b0 / 255.0f; }  // cpu/image_data.rs:39-43
-          else { o[0] = (float)b0 / 255.0f; o[1] = (float)b1 / 255.0f; o[2] = (float)b2 / 255.0f; }
-          o[3] = (float)b3 / 255.0f;
-        }
+        out.format = im.format == HALA_FORMAT_R8G8B8A8_SRGB ? kTexSrgb8 : kTexUnorm8;
+        out.rgba8.assign(static_cast<const uint8_t*>(im.data), static_cast<const uint8_t*>(im.data) + n * 4);
+        if (im.format == HALA_FORMAT_B8G8R8A8_UNORM)  // RGBA bytes tagged BGRA without a swizzle: red and blue swap (cpu/image_data.rs:39-43)
+          for (size_t i = 0; i < n; ++i) std::swap(out.rgba8[4 * i], out.rgba8[4 * i + 2]);
+        for (size_t i = 0; i < n && !out.has_alpha; ++i) out.has_alpha = out.rgba8[4 * i + 3] < 255u;
       } else return "Unsupported image format.";
-      for (size_t i = 0; i < n && !out.has_alpha; ++i) out.has_alpha = out.rgba[4 * i + 3] < 1.0f;
       images.push_back(std::move(out));
     }
     uint32_t prev_key = 0;

@@ -30,11 +30,16 @@ struct HostPrimitive {
   uint32_t material_index = HALA_INVALID_INDEX;
 };
 
-struct HostImage32F {  // one cpu::HalaImageData decoded to linear RGBA32F (level 0 of its mip chain)
+// one cpu::HalaImageData as it is kept on the device (level 0 of its mip chain, RENDER_SPEC 7.4): float images as linear RGBA32F texels;
+// 8-bit images stay 8-bit (RGBA byte order; B8G8R8A8-tagged data is swizzled here) and are decoded by the sampler
+struct HostImage32F {
   uint32_t width = 0, height = 0;
-  std::vector<float> rgba;
+  uint32_t format = 0;         // kTexFloat | kTexSrgb8 | kTexUnorm8 (hala_types.h)
+  std::vector<float> rgba;     // format 0
+  std::vector<uint8_t> rgba8;  // formats 1, 2
   bool has_alpha = false;  // some texel has alpha < 1: a base-colour map that cuts its surface out (RENDER_SPEC 7.1d)
 };
+const float* srgb_decode_lut();  // 256 entries: the sRGB EOTF in float (what the *_SRGB sampler of the reference computes)
 
 struct HostScene {
   // cpu::HalaScene

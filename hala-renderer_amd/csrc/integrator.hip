@@ -402,6 +402,13 @@ __global__ void __launch_bounds__(kShadeThreads, SIMPLE ? RT_SHADE_WAVES_SIMPLE 
   }
   if (blockIdx.x * blockDim.x >= n) return;  // whole workgroup beyond the queue (uniform exit: barriers below)
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  // the texel decode table in LDS (shading.h::tex8_fetch); the barriers of the block compaction come long after every read of it
+  __shared__ float s_tex_lut[SIMPLE ? 1 : kTexLutEntries];
+  const RT_LDS float* lut = (const RT_LDS float*)s_tex_lut;
+  if (!SIMPLE && sv.texture_count) {
+    for (uint32_t k = threadIdx.x; k < kTexLutEntries; k += kShadeThreads) s_tex_lut[k] = sv.tex_lut[k];
+    __syncthreads();
+  }
 #ifndef RT_SHADE_NOSORT
   if (!PRIMARY && sv.shade_sort) {
     // Bounce paths arrive in no particular order and the BSDF code is a forest of branches (miss / diffuse / Disney / glass /
@@ -501,7 +508,7 @@ __global__ void __launch_bounds__(kShadeThreads, SIMPLE ? RT_SHADE_WAVES_SIMPLE 
         ps.normal[slot] = P3{0.0f, 0.0f, 0.0f};
       }
     } else {
-      const Surface sf = make_surface<SIMPLE>(sv, fc.pixel_spread, o, d, hv.x, hv.y, hv.z, hit_prim);
+      const Surface sf = make_surface<SIMPLE>(sv, lut, fc.pixel_spread, o, d, hv.x, hv.y, hv.z, hit_prim);
       if (PRIMARY) {
         ps.albedo[slot] = P3{sf.mat.base.x, sf.mat.base.y, sf.mat.base.z};
         ps.normal[slot] = P3{sf.ns.x, sf.ns.y, sf.ns.z};
@@ -684,7 +691,7 @@ __global__ void __launch_bounds__(256) k_resolve(FrameConst fc, PathState ps, fl
 __global__ void __launch_bounds__(256) k_sample_texture(SceneView sv, uint32_t tex, const float* __restrict__ uvl, uint32_t n, float4* __restrict__ out) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  out[i] = tex_sample(sv, tex, uvl[3 * i], uvl[3 * i + 1], uvl[3 * i + 2]);
+  out[i] = tex_sample(sv, sv.tex_lut, tex, uvl[3 * i], uvl[3 * i + 1], uvl[3 * i + 2]);
 }
 
 // tile-major gathered buffer [world][tiles_per_rank][ts][ts] -> row-major full image (RENDER_SPEC §9)

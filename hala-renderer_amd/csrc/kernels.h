@@ -36,6 +36,10 @@ void launch_sample_texture(const SceneView& sv, uint32_t tex, const float* uvl, 
 
 // texture.hip — K8: one level of the mip chain (2x2 box filter over linear RGBA32F texels)
 void launch_mip_downsample(const float4* src, uint32_t sw, uint32_t sh, float4* dst, uint32_t dw, uint32_t dh, hipStream_t s);
+// 8-bit images: row-major bytes -> 4x4-tiled level 0; tiled level l - 1 -> tiled level l (decode, box filter, encode)
+void launch_tile8(const uint32_t* src, uint32_t w, uint32_t h, uint32_t* dst, hipStream_t s);
+void launch_mip_downsample8(const uint32_t* src, uint32_t sw, uint32_t sh, uint32_t* dst, uint32_t dw, uint32_t dh, uint32_t format, const float* lut,
+                            const float* thr, hipStream_t s);
 
 // bvh_build.hip — K1/K3/K4: flatten instances to world space, LBVH build, refit
 struct BvhBuffers {

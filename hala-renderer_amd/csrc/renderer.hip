@@ -123,6 +123,8 @@ struct hala_rt_renderer {
   DeviceArray<hala_gpu_mesh_data> d_instances;
   DeviceArray<uint32_t> d_inst_first_tri;
   DeviceArray<float4> d_tex_arena;
+  DeviceArray<uint32_t> d_tex_arena8;  // 8-bit images: RGBA bytes, tiled 4x4 (RENDER_SPEC 7.4)
+  DeviceArray<float> d_srgb_lut, d_srgb_thr;
   DeviceArray<TexDesc> d_textures;
   std::vector<TexDesc> host_textures;
 
@@ -220,7 +222,7 @@ struct hala_rt_renderer {
     sv.nodes = d_nodes.ptr; sv.tris = d_tris.ptr; sv.tris_any = any_invisible ? d_tris_any.ptr : d_tris.ptr; sv.tris_by_id = d_tris_by_id.ptr; sv.shade_tris = d_shade_tris.ptr; sv.tri_instance = d_tri_instance.ptr;
     sv.inst_first_tri = d_inst_first_tri.ptr; sv.primitives = d_instances.ptr; sv.materials = d_materials.ptr; sv.material_kind = d_material_kind.ptr;
     sv.lights = d_lights.ptr; sv.cameras = d_cameras.ptr;
-    sv.textures = d_textures.ptr; sv.tex_arena = d_tex_arena.ptr; sv.texture_count = (uint32_t)host_textures.size(); sv.shade_sort = shade_sort ? 1u : 0u; sv.simple_materials = simple_materials ? 1u : 0u; sv.scatter_media = scatter_media ? 1u : 0u; sv.any_translucent = any_translucent ? 1u : 0u;
+    sv.textures = d_textures.ptr; sv.tex_arena = d_tex_arena.ptr; sv.tex_arena8 = d_tex_arena8.ptr; sv.tex_lut = d_srgb_lut.ptr; sv.texture_count = (uint32_t)host_textures.size(); sv.shade_sort = shade_sort ? 1u : 0u; sv.simple_materials = simple_materials ? 1u : 0u; sv.scatter_media = scatter_media ? 1u : 0u; sv.any_translucent = any_translucent ? 1u : 0u;
     sv.env_pixels = reinterpret_cast<const float*>(d_env.ptr); sv.env_marginal = d_marginal.ptr; sv.env_conditional = d_conditional.ptr;
     sv.node_count = bvh.node_count; sv.tri_count = bvh.tri_count; sv.lds_nodes = lds_nodes; sv.lds_tris = lds_tris;
     sv.ray_eps = ray_eps;
@@ -417,32 +419,57 @@ int upload_packed(hala_rt_renderer* r, bool geometry = true) {
 int upload_textures(hala_rt_renderer* r) {
   const HostScene& hs = r->hs;
   std::vector<TexDesc> img_desc(hs.images.size());
-  size_t total = 0;
+  size_t total_f = 0, total_8 = 0, largest_8 = 0;  // float4 texels / tiled 4-B texels / largest level 0 among the 8-bit images
   for (size_t k = 0; k < hs.images.size(); ++k) {
     TexDesc& td = img_desc[k];
     memset(&td, 0, sizeof(td));
-    td.width = hs.images[k].width; td.height = hs.images[k].height;
+    td.width = hs.images[k].width; td.height = hs.images[k].height; td.format = hs.images[k].format;
     uint32_t m = std::max(td.width, td.height), p2 = 1, lg = 0;
     while (p2 < m) { p2 <<= 1; ++lg; }
     td.mips = std::min<uint32_t>(lg + 1, kMaxMips);
+    size_t& total = td.format == kTexFloat ? total_f : total_8;
     for (uint32_t l = 0; l < td.mips; ++l) {
       if (total > 0xffffffffull) RT_FAIL("The texture arena exceeds 2^32 texels.");
       td.mip_offset[l] = (uint32_t)total;
-      total += (size_t)std::max(1u, td.width >> l) * std::max(1u, td.height >> l);
+      const uint32_t lw = std::max(1u, td.width >> l), lh = std::max(1u, td.height >> l);
+      total += td.format == kTexFloat ? (size_t)lw * lh : (size_t)tex_tiled_size(lw, lh);
     }
+    if (td.format != kTexFloat) largest_8 = std::max(largest_8, (size_t)td.width * td.height);
   }
-  RT_HIP(r->d_tex_arena.resize(total));
+  RT_HIP(r->d_tex_arena.resize(total_f));
+  RT_HIP(r->d_tex_arena8.resize(total_8));
+  if (total_8) RT_HIP(hipMemsetAsync(r->d_tex_arena8.ptr, 0, total_8 * 4, r->stream));  // the padding texels of partial tiles
+  // the sRGB decode table and the midpoints between its entries (the encoder of the 8-bit mip chain bisects them)
+  const float* lut = srgb_decode_lut();
+  float thr[256];
+  for (int k = 0; k < 255; ++k) thr[k] = (lut[k] + lut[k + 1]) * 0.5f;
+  thr[255] = 3.402823466e+38f;
+  float lut512[512];  // shading.h::tex8_fetch: the sRGB EOTF, then b / 255
+  for (int k = 0; k < 256; ++k) { lut512[k] = lut[k]; lut512[256 + k] = (float)k / 255.0f; }
+  RT_HIP(r->d_srgb_lut.upload(lut512, 512, r->stream));
+  RT_HIP(r->d_srgb_thr.upload(thr, 256, r->stream));
+  DeviceArray<uint32_t> staging;  // row-major level 0 of one 8-bit image at a time
+  RT_HIP(staging.resize(largest_8));
   for (size_t k = 0; k < hs.images.size(); ++k) {
     const TexDesc& td = img_desc[k];
-    RT_HIP(hipMemcpyAsync(r->d_tex_arena.ptr + td.mip_offset[0], hs.images[k].rgba.data(), (size_t)td.width * td.height * 16, hipMemcpyHostToDevice, r->stream));
-    for (uint32_t l = 1; l < td.mips; ++l)
-      launch_mip_downsample(r->d_tex_arena.ptr + td.mip_offset[l - 1], std::max(1u, td.width >> (l - 1)), std::max(1u, td.height >> (l - 1)),
-                            r->d_tex_arena.ptr + td.mip_offset[l], std::max(1u, td.width >> l), std::max(1u, td.height >> l), r->stream);
+    if (td.format == kTexFloat) {
+      RT_HIP(hipMemcpyAsync(r->d_tex_arena.ptr + td.mip_offset[0], hs.images[k].rgba.data(), (size_t)td.width * td.height * 16, hipMemcpyHostToDevice, r->stream));
+      for (uint32_t l = 1; l < td.mips; ++l)
+        launch_mip_downsample(r->d_tex_arena.ptr + td.mip_offset[l - 1], std::max(1u, td.width >> (l - 1)), std::max(1u, td.height >> (l - 1)),
+                              r->d_tex_arena.ptr + td.mip_offset[l], std::max(1u, td.width >> l), std::max(1u, td.height >> l), r->stream);
+    } else {
+      RT_HIP(hipMemcpyAsync(staging.ptr, hs.images[k].rgba8.data(), (size_t)td.width * td.height * 4, hipMemcpyHostToDevice, r->stream));
+      launch_tile8(staging.ptr, td.width, td.height, r->d_tex_arena8.ptr + td.mip_offset[0], r->stream);
+      for (uint32_t l = 1; l < td.mips; ++l)
+        launch_mip_downsample8(r->d_tex_arena8.ptr + td.mip_offset[l - 1], std::max(1u, td.width >> (l - 1)), std::max(1u, td.height >> (l - 1)),
+                               r->d_tex_arena8.ptr + td.mip_offset[l], std::max(1u, td.width >> l), std::max(1u, td.height >> l), td.format,
+                               r->d_srgb_lut.ptr, r->d_srgb_thr.ptr, r->stream);
+    }
   }
   std::vector<TexDesc> tex(hs.texture_image.size());
   for (size_t i = 0; i < tex.size(); ++i) tex[i] = img_desc[hs.texture_image[i]];
   RT_HIP(r->d_textures.upload(tex.data(), tex.size(), r->stream));
-  RT_HIP(hipStreamSynchronize(r->stream));
+  RT_HIP(hipStreamSynchronize(r->stream));  // (also: `staging` and the host images may go)
   RT_HIP(hipGetLastError());
   r->host_textures = tex;
   return HALA_OK;
@@ -976,8 +1003,23 @@ int hala_rt_read_texture_level(hala_rt_renderer* r, uint32_t texture, uint32_t l
   if (!r->has_scene || texture >= r->host_textures.size() || !dst_rgba32f) RT_FAIL("The texture does not exist.");
   const TexDesc& td = r->host_textures[texture];
   if (level >= td.mips) RT_FAIL("The mip level does not exist.");
-  const size_t n = (size_t)std::max(1u, td.width >> level) * std::max(1u, td.height >> level);
-  RT_HIP(hipMemcpy(dst_rgba32f, r->d_tex_arena.ptr + td.mip_offset[level], n * 16, hipMemcpyDeviceToHost));
+  const uint32_t lw = std::max(1u, td.width >> level), lh = std::max(1u, td.height >> level);
+  const size_t n = (size_t)lw * lh;
+  if (td.format == kTexFloat) {
+    RT_HIP(hipMemcpy(dst_rgba32f, r->d_tex_arena.ptr + td.mip_offset[level], n * 16, hipMemcpyDeviceToHost));
+    return HALA_OK;
+  }
+  // 8-bit texels: de-tile and decode on the host exactly like the sampler does on the device
+  std::vector<uint32_t> tiled(tex_tiled_size(lw, lh));
+  RT_HIP(hipMemcpy(tiled.data(), r->d_tex_arena8.ptr + td.mip_offset[level], tiled.size() * 4, hipMemcpyDeviceToHost));
+  const float* lut = srgb_decode_lut();
+  for (uint32_t y = 0; y < lh; ++y)
+    for (uint32_t x = 0; x < lw; ++x) {
+      const uint32_t t = tiled[tex_tiled_index(x, y, lw)];
+      float* o = dst_rgba32f + ((size_t)y * lw + x) * 4;
+      for (int c = 0; c < 3; ++c) { const uint32_t b = (t >> (8 * c)) & 0xffu; o[c] = td.format == kTexSrgb8 ? lut[b] : (float)b / 255.0f; }
+      o[3] = (float)(t >> 24) / 255.0f;
+    }
   return HALA_OK;
 }
 int hala_rt_sample_texture_host(hala_rt_renderer* r, uint32_t texture, const float* uv_lod, uint32_t count, float* dst_rgba32f) {

@@ -446,16 +446,34 @@ RT_DI float log2_approx(float x) {
   const float m = __uint_as_float((b & 0x007fffffu) | 0x3f800000u);
   return e + (m - 1.0f);
 }
-RT_DI float4 tex_bilinear(const SceneView& sv, const TexDesc& td, uint32_t level, float u, float v) {
+// Texel decode table (512 floats): [0, 256) the sRGB EOTF, [256, 512) b / 255.  The shade kernel keeps a copy in LDS (a table read is
+// then a ds_read instead of one more request to the texture-address unit, which is what that kernel is short of); LUT is `const
+// float*` (global) or `const RT_LDS float*`.
+constexpr uint32_t kTexLutEntries = 512;
+template <typename LUT>
+RT_DI float4 tex8_fetch(LUT lut, const uint32_t* base, uint32_t format, int x, int y, int w) {
+  const uint32_t t = base[tex_tiled_index((uint32_t)x, (uint32_t)y, (uint32_t)w)];
+  const uint32_t o = format == kTexSrgb8 ? 0u : 256u;
+  return make_float4(lut[o + (t & 0xffu)], lut[o + ((t >> 8) & 0xffu)], lut[o + ((t >> 16) & 0xffu)], lut[256u + (t >> 24)]);
+}
+template <typename LUT>
+RT_DI float4 tex_bilinear(const SceneView& sv, LUT lut, const TexDesc& td, uint32_t level, float u, float v) {
   const int w = max((int)(td.width >> level), 1), h = max((int)(td.height >> level), 1);
-  const float4* base = sv.tex_arena + td.mip_offset[level];
   const float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
   const float x0 = floorf(x), y0 = floorf(y);
   const float fx = x - x0, fy = y - y0;
   const int ix0 = wrapi((int)x0, w), iy0 = wrapi((int)y0, h);  // REPEAT (gpu_uploader.rs:346)
   const int ix1 = wrapi(ix0 + 1, w), iy1 = wrapi(iy0 + 1, h);
-  const float4 c00 = base[(size_t)iy0 * w + ix0], c10 = base[(size_t)iy0 * w + ix1];
-  const float4 c01 = base[(size_t)iy1 * w + ix0], c11 = base[(size_t)iy1 * w + ix1];
+  float4 c00, c10, c01, c11;
+  if (td.format == kTexFloat) {
+    const float4* base = sv.tex_arena + td.mip_offset[level];
+    c00 = base[(size_t)iy0 * w + ix0]; c10 = base[(size_t)iy0 * w + ix1];
+    c01 = base[(size_t)iy1 * w + ix0]; c11 = base[(size_t)iy1 * w + ix1];
+  } else {  // 8-bit texels, tiled 4x4, decoded here (RENDER_SPEC 7.4)
+    const uint32_t* base = sv.tex_arena8 + td.mip_offset[level];
+    c00 = tex8_fetch(lut, base, td.format, ix0, iy0, w); c10 = tex8_fetch(lut, base, td.format, ix1, iy0, w);
+    c01 = tex8_fetch(lut, base, td.format, ix0, iy1, w); c11 = tex8_fetch(lut, base, td.format, ix1, iy1, w);
+  }
   const float gx = 1.0f - fx, gy = 1.0f - fy;
   float4 r;
   r.x = (c00.x * gx + c10.x * fx) * gy + (c01.x * gx + c11.x * fx) * fy;
@@ -465,16 +483,17 @@ RT_DI float4 tex_bilinear(const SceneView& sv, const TexDesc& td, uint32_t level
   return r;
 }
 // linear / linear-mip / repeat sampler of gpu_uploader.rs:341-353; lod is clamped to the chain
-RT_DI float4 tex_sample(const SceneView& sv, uint32_t tex, float u, float v, float lod) {
+template <typename LUT>
+RT_DI float4 tex_sample(const SceneView& sv, LUT lut, uint32_t tex, float u, float v, float lod) {
   const TexDesc& td = sv.textures[tex];
   const float top = (float)(td.mips - 1u);
   lod = lod < 0.0f ? 0.0f : (lod > top ? top : lod);
   const float l0 = floorf(lod);
   const float fl = lod - l0;
   const uint32_t level = (uint32_t)l0;
-  float4 a = tex_bilinear(sv, td, level, u, v);
+  float4 a = tex_bilinear(sv, lut, td, level, u, v);
   if (fl > 0.0f && level + 1u < td.mips) {
-    const float4 b = tex_bilinear(sv, td, level + 1u, u, v);
+    const float4 b = tex_bilinear(sv, lut, td, level + 1u, u, v);
     const float g = 1.0f - fl;
     a.x = a.x * g + b.x * fl; a.y = a.y * g + b.y * fl; a.z = a.z * g + b.z * fl; a.w = a.w * g + b.w * fl;
   }
@@ -499,7 +518,7 @@ RT_DI float hit_alpha(const SceneView& sv, uint32_t prim, float u, float v) {
     const float w0 = 1.0f - u - v;
     const float tu = __fmaf_rn(s5.x, v, __fmaf_rn(s4.z, u, s4.x * w0));
     const float tv = __fmaf_rn(s5.y, v, __fmaf_rn(s4.w, u, s4.y * w0));
-    alpha = alpha * tex_bilinear(sv, sv.textures[tex], 0u, tu, tv).w;
+    alpha = alpha * tex_bilinear(sv, sv.tex_lut, sv.textures[tex], 0u, tu, tv).w;
   }
   return alpha;
 }
@@ -550,8 +569,8 @@ RT_DI f3 transform_vector(const float* m, f3 p) {
 }
 // SIMPLE: the scene's materials are all untextured, opaque DIFFUSE ones without a medium (the host checks: SceneView::simple_materials);
 // the compiler then drops the texture, Disney and medium code from the kernel variant — half the registers, twice the waves.
-template <bool SIMPLE>
-RT_DI Surface make_surface(const SceneView& sv, float pixel_spread, f3 o, f3 d, float t, float u, float v, uint32_t prim) {
+template <bool SIMPLE, typename LUT>
+RT_DI Surface make_surface(const SceneView& sv, LUT lut, float pixel_spread, f3 o, f3 d, float t, float u, float v, uint32_t prim) {
   Surface sf;
   // line 1 of the 128-B shading record: geometric normal, vertex normals, instance, material
   const float4* sp = reinterpret_cast<const float4*>(sv.shade_tris + prim);
@@ -593,16 +612,16 @@ RT_DI Surface make_surface(const SceneView& sv, float pixel_spread, f3 o, f3 d, 
     const float ratio = foot * foot * uv_area / world_area;
     const float lod_base = (ratio > 0.0f && ratio < 3.0e38f) ? 0.5f * log2_approx(ratio) : 0.0f;
     if (has_base) {
-      const float4 s = tex_sample(sv, m.base_color_map_index, tu, tv, tex_lod(sv, m.base_color_map_index, lod_base));
+      const float4 s = tex_sample(sv, lut, m.base_color_map_index, tu, tv, tex_lod(sv, m.base_color_map_index, lod_base));
       sf.mat.base = sf.mat.base * mk3(s.x, s.y, s.z);
       sf.mat.opacity = sf.mat.opacity * s.w;
     }
     if (has_em) {
-      const float4 s = tex_sample(sv, m.emission_map_index, tu, tv, tex_lod(sv, m.emission_map_index, lod_base));
+      const float4 s = tex_sample(sv, lut, m.emission_map_index, tu, tv, tex_lod(sv, m.emission_map_index, lod_base));
       sf.mat.emission = sf.mat.emission * mk3(s.x, s.y, s.z);
     }
     if (has_mr) {  // glTF: G = roughness, B = metallic
-      const float4 s = tex_sample(sv, m.metallic_roughness_map_index, tu, tv, tex_lod(sv, m.metallic_roughness_map_index, lod_base));
+      const float4 s = tex_sample(sv, lut, m.metallic_roughness_map_index, tu, tv, tex_lod(sv, m.metallic_roughness_map_index, lod_base));
       sf.mat.metallic = sf.mat.metallic * s.z;
       if (m.type == 1u) {  // re-derive the packed alphas exactly like src/scene/gpu/material.rs:61-69
         const float rl = sqrtf(m.roughness) * s.y;
@@ -614,7 +633,7 @@ RT_DI Surface make_surface(const SceneView& sv, float pixel_spread, f3 o, f3 d, 
       }
     }
     if (has_nrm) {
-      const float4 s = tex_sample(sv, m.normal_map_index, tu, tv, tex_lod(sv, m.normal_map_index, lod_base));
+      const float4 s = tex_sample(sv, lut, m.normal_map_index, tu, tv, tex_lod(sv, m.normal_map_index, lod_base));
       // tangents: s5.z s5.w s6.x | s6.y s6.z s6.w | s7.x s7.y s7.z
       const f3 tl = madd3(mk3(s7.x, s7.y, s7.z), v, madd3(mk3(s6.y, s6.z, s6.w), u, mk3(s5.z, s5.w, s6.x) * w0));
       f3 tw = transform_vector(md.transform, tl);

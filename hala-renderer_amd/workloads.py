@@ -22,7 +22,7 @@ def atrium(target_triangles=1_000_000, aspect=16.0 / 9.0, textures=True, texture
     """configs[3]/[4]'s scene + env map (the 18 textures: 6 sets of base colour + normal + metallic-roughness)"""
     s = scenes.sponza_class(target_triangles=target_triangles, aspect=aspect)
     if textures and not os.environ.get("HALART_NO_TEXTURES"):  # (experiment knob: what the texture fetches cost)
-        scenes.attach_textures(s, sets=6, size=texture_size)
+        scenes.attach_textures(s, sets=6, size=int(os.environ.get("HALART_TEXTURE_SIZE", texture_size)))  # (experiment knob)
     return s, scenes.sky_sun_envmap(1024, 512, sun_gain=50.0)
 
 

@@ -208,7 +208,14 @@ extern "C" orc_scene* orc_scene_create(const orc_scene_desc* desc) {
     img.width = im.width; img.height = im.height;
     const size_t n = (size_t)im.width * im.height;
     std::vector<float> l0(n * 4);
-    if (im.format == 2) memcpy(l0.data(), im.data, n * 16);
+    // RENDER_SPEC 7.4: float images are linear RGBA32F texels; 8-bit images STAY 8-bit at every mip level and are decoded by the sampler
+    // (sRGB bytes through the 256-entry table, UNORM bytes / 255; alpha always UNORM).  The oracle keeps the decoded values.
+    float lut[256], thr[256];
+    for (int i = 0; i < 256; ++i) { const double x = i / 255.0; lut[i] = (float)(x <= 0.04045 ? x / 12.92 : std::pow((x + 0.055) / 1.055, 2.4)); }
+    for (int k = 0; k < 255; ++k) thr[k] = (lut[k] + lut[k + 1]) * 0.5f;
+    thr[255] = 3.402823466e+38f;
+    const bool bytes = im.format != 2, srgb = im.format == 1;
+    if (!bytes) memcpy(l0.data(), im.data, n * 16);
     else {
       const uint8_t* p = static_cast<const uint8_t*>(im.data);
       for (size_t i = 0; i < n; ++i) {
@@ -216,17 +223,26 @@ extern "C" orc_scene* orc_scene_create(const orc_scene_desc* desc) {
           int src = c;
           if (im.format == 3 && c < 3) src = 2 - c;  // RGBA bytes tagged BGRA (cpu/image_data.rs:39-43)
           const uint8_t b = p[4 * i + src];
-          float v;
-          if (im.format == 1 && c < 3) { const double x = b / 255.0; v = (float)(x <= 0.04045 ? x / 12.92 : std::pow((x + 0.055) / 1.055, 2.4)); }
-          else v = (float)b / 255.0f;
-          l0[4 * i + c] = v;
+          l0[4 * i + c] = (srgb && c < 3) ? lut[b] : (float)b / 255.0f;
         }
       }
     }
+    // a mip texel of an 8-bit image goes back to a byte: UNORM floor(x * 255 + 0.5) clamped; sRGB the code whose decoded value is
+    // nearest = the number of midpoints thr[k] = (lut[k] + lut[k + 1]) / 2 below x (bisection) — and is stored as that byte decodes
+    auto requantise = [&](float x, int c) -> float {
+      if (srgb && c < 3) {
+        uint32_t lo = 0, hi = 255;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (thr[mid] < x) lo = mid + 1u; else hi = mid; }
+        return lut[lo];
+      }
+      float v = floorf(x * 255.0f + 0.5f);
+      v = v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v);
+      return (float)(uint32_t)v / 255.0f;
+    };
+    for (size_t i = 0; i < n; ++i) img.has_alpha = img.has_alpha || l0[4 * i + 3] < 1.0f;  // RENDER_SPEC 7.1d (NaN: not a cut-out)
     uint32_t m = std::max(im.width, im.height), p2 = 1, lg = 0;
     while (p2 < m) { p2 <<= 1; ++lg; }
     img.mips = std::min<uint32_t>(lg + 1, 16);  // gpu_uploader.rs:366
-    for (size_t i = 0; i < n; ++i) img.has_alpha = img.has_alpha || l0[4 * i + 3] < 1.0f;  // RENDER_SPEC 7.1d (NaN: not a cut-out)
     img.levels.push_back(std::move(l0));
     for (uint32_t l = 1; l < img.mips; ++l) {
       const uint32_t sw = std::max(1u, im.width >> (l - 1)), sh = std::max(1u, im.height >> (l - 1));
@@ -239,7 +255,8 @@ extern "C" orc_scene* orc_scene_create(const orc_scene_desc* desc) {
           for (int c = 0; c < 4; ++c) {
             const float a = src[((size_t)y0 * sw + x0) * 4 + c], b = src[((size_t)y0 * sw + x1) * 4 + c];
             const float cc = src[((size_t)y1 * sw + x0) * 4 + c], d = src[((size_t)y1 * sw + x1) * 4 + c];
-            dst[((size_t)y * dw + x) * 4 + c] = ((a + b) + (cc + d)) * 0.25f;
+            const float box = ((a + b) + (cc + d)) * 0.25f;
+            dst[((size_t)y * dw + x) * 4 + c] = bytes ? requantise(box, c) : box;
           }
         }
       img.levels.push_back(std::move(dst));

@@ -215,7 +215,15 @@ def textured_scene(size=64, disney=True, fmt_variant=False):
 
 def test_texture_mips_and_fetch_vs_independent_numpy(oracle):
     s = textured_scene(size=32)
+    # a 256 x 1 sRGB ramp holding every byte code: its level 0 IS the decode table (RENDER_SPEC 7.4), read here so that the 8-bit mip rule
+    # below can be emulated bit for bit whatever libm's pow() rounds to
+    ramp = np.zeros((1, 256, 4), np.uint8); ramp[0, :, :3] = np.arange(256)[:, None]; ramp[..., 3] = 255
+    k = len(s.image_data)
+    s.image_data.append(H.HalaImageData(scenes.A_FORMAT_SRGB, 256, 1, ramp)); s.image2data_mapping[k] = k; s.texture2image_mapping[k] = k
     osc = oracle.OracleScene(s)
+    lut = osc.texture_level(k, 0)[0, :, 0].copy()
+    assert lut[0] == 0.0 and lut[255] == 1.0 and np.all(np.diff(lut) > 0)
+    thr = ((lut[:-1] + lut[1:]) * f32(0.5)).astype(f32)  # midpoints between neighbouring codes
     for tex in (0, 1, 6, 7):
         w, h, mips = osc.texture_info(tex)
         img = s.image_data[tex]
@@ -246,7 +254,16 @@ def test_texture_mips_and_fetch_vs_independent_numpy(oracle):
             xs0 = np.minimum(2 * np.arange(dw), sw - 1); xs1 = np.minimum(2 * np.arange(dw) + 1, sw - 1)
             a, b = prev[ys0][:, xs0], prev[ys0][:, xs1]
             c, dd = prev[ys1][:, xs0], prev[ys1][:, xs1]
-            exp = ((a + b).astype(f32) + (c + dd).astype(f32)).astype(f32) * f32(0.25)
+            exp = (((a + b).astype(f32) + (c + dd).astype(f32)).astype(f32) * f32(0.25)).astype(f32)
+            if img.format != scenes.A_FORMAT_FLOAT:
+                # 8-bit images stay 8-bit at every level: UNORM floor(x * 255 + 0.5), sRGB the nearest code (the number of midpoints
+                # below x); the level holds what those bytes decode to
+                un = (np.clip(np.floor(exp * f32(255) + f32(0.5)), 0, 255).astype(np.uint32).astype(f32) / f32(255)).astype(f32)
+                if img.format == scenes.A_FORMAT_SRGB:
+                    code = np.searchsorted(thr, exp[..., :3], side="left")
+                    exp = np.concatenate([lut[code], un[..., 3:]], -1).astype(f32)
+                else:
+                    exp = un
             cur = osc.texture_level(tex, l)
             assert cur.tobytes() == exp.astype(f32).tobytes(), (tex, l)
             prev = cur
