@@ -4,9 +4,10 @@
 //   flatten   every instance (node x primitive, in the reference's instance order gpu_uploader.rs:843-875) is
 //             transformed to world space once -> one triangle soup, one BVH (288 GB of HBM make the copy free and
 //             single-level traversal needs no per-instance ray transform)
-//   build     60-bit Morton codes (+ 2-bit size class) -> rocPRIM radix sort -> binary hierarchy: PLOC (nearest-neighbour
-//             clustering along the Morton order) for >= 4096 triangles, Karras 2012 LBVH below ->
-//             bottom-up AABB fit with arrival counters -> subtrees of <= leaf_max triangles become leaves ->
+//   build     binary hierarchy: >= 4096 triangles: top-down full-sweep SAH, one tree level per round (three centroid orders kept through
+//             every partition, segmented box scans with rocPRIM; sah_hierarchy) | below: 60-bit Morton codes -> rocPRIM radix sort ->
+//             Karras 2012 LBVH | HALART_BUILDER=ploc: PLOC over the Morton order, the fast large-scene build ->
+//             fitted AABBs -> subtrees of <= leaf_max triangles become leaves ->
 //             top-down collapse into 4-wide nodes, breadth-first, by surface area -> 64-B compressed nodes
 //             (8-bit child boxes quantised conservatively against the node's own box, RENDER_SPEC §4.1b)
 //   refit     (north_star; the reference only rebuilds) re-flatten + bottom-up fit + re-pack on the frozen topology
@@ -707,6 +708,164 @@ __global__ void __launch_bounds__(256) k_ploc_renumber(uint32_t* __restrict__ le
   if (r & kLeafBit) right[i] = kLeafBit | new_pos[r & ~kLeafBit];
 }
 
+
+// ---- full-sweep SAH hierarchy (top-down, one tree level per round) --------------------------------------------------------------
+// The triangles are sorted ONCE along each axis by the centroid of their box; every open node owns the same range [first, last] of
+// positions in all three orders.  A round, for all open nodes at once: per axis a segmented prefix and suffix union of the boxes
+// (rocPRIM scan-by-key over the node ids; min / max are exactly associative, so the result does not depend on how the scan is cut up),
+// the surface-area cost area(L)*|L| + area(R)*|R| of every split position, the cheapest (cost, axis, position) per node through a
+// 64-bit atomic min, then a stable partition of the three orders by the side each triangle went to.  The contract is PLOC's:
+// left / right / first / last / parents / fitted node boxes / sorted_ids, node 0 = root, a full binary tree down to single triangles.
+struct BoxUnionOp {
+  __host__ __device__ Box6 operator()(const Box6& a, const Box6& b) const {
+    Box6 r;
+    for (int k = 0; k < 3; ++k) { r.mn[k] = fminf(a.mn[k], b.mn[k]); r.mx[k] = fmaxf(a.mx[k], b.mx[k]); }
+    return r;
+  }
+};
+struct Flag3 { uint32_t v[3]; };
+struct Flag3Plus {
+  __host__ __device__ Flag3 operator()(const Flag3& a, const Flag3& b) const { return Flag3{{a.v[0] + b.v[0], a.v[1] + b.v[1], a.v[2] + b.v[2]}}; }
+};
+constexpr unsigned long long kSahNoSplit = ~0ull;
+constexpr int kSahQuant = 4;
+constexpr uint32_t kSahPosMask = 0x0fffffffu;  // split position relative to the node's first position (n < 2^28); axis in bits 28-29
+
+__global__ void __launch_bounds__(256) k_sah_keys(const Box6* __restrict__ tri_box, uint32_t n, int axis, uint32_t* __restrict__ keys,
+                                                   uint32_t* __restrict__ ids) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  keys[i] = f2ord(tri_box[i].mn[axis] + tri_box[i].mx[axis]);  // twice the centroid; ties keep id order (stable sort)
+  ids[i] = i;
+}
+__global__ void __launch_bounds__(256) k_sah_init(uint32_t n, uint32_t* __restrict__ node_of, uint32_t* __restrict__ first, uint32_t* __restrict__ last,
+                                                   uint32_t* __restrict__ node_parent, uint32_t* __restrict__ act, unsigned long long* __restrict__ best) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) node_of[i] = 0u;
+  if (i == 0u) { first[0] = 0u; last[0] = n - 1u; node_parent[0] = kAbsent; act[0] = 0u; best[0] = kSahNoSplit; }
+}
+__global__ void __launch_bounds__(256) k_sah_gather(const uint32_t* __restrict__ ord, const Box6* __restrict__ tri_box, uint32_t n, Box6* __restrict__ out) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n) out[p] = tri_box[ord[p]];
+}
+// cost of splitting the node of position p between p - 1 and p along `axis`; axis 0 also leaves the node's fitted box
+__global__ void __launch_bounds__(256) k_sah_cost(uint32_t n, uint32_t axis, const uint32_t* __restrict__ node_of, const uint32_t* __restrict__ first,
+                                                   const uint32_t* __restrict__ last, const Box6* __restrict__ box_l, const Box6* __restrict__ box_r,
+                                                   unsigned long long* __restrict__ best, Box6* __restrict__ node_box, float pad, uint32_t quant) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t node = kAbsent;
+  unsigned long long key = kSahNoSplit;
+  if (p < n) {
+    node = node_of[p];
+    if (node != kAbsent) {
+      const uint32_t lo = first[node], hi = last[node] + 1u;
+      if (p > lo) {
+        // triangles are tested `quant` at a time (a leaf item of the cooperative pass occupies kLeafSlots lanes however full it is)
+        const float cost = half_area(box_l[p - 1u]) * (float)((p - lo + quant - 1u) / quant) + half_area(box_r[p]) * (float)((hi - p + quant - 1u) / quant);
+        // areas and counts are >= 0: the bits of the cost order like the cost (a NaN cannot arise from finite boxes; +inf sorts last)
+        key = ((unsigned long long)__float_as_uint(cost) << 32) | ((unsigned long long)axis << 28) | (unsigned long long)(p - lo);
+      }
+      if (axis == 0u && p + 1u == hi) {
+        const Box6 u = box_l[p];
+        Box6 w;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { w.mn[c] = u.mn[c] - pad; w.mx[c] = u.mx[c] + pad; }  // = the union of the widened leaf boxes (k_ploc_apply)
+        node_box[node] = w;
+      }
+    }
+  }
+  // the positions of a node are contiguous: fold the wave's keys per run of equal nodes first, one atomic per run
+  const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+  for (uint32_t off = 1; off < 64u; off <<= 1) {
+    const unsigned long long ok = __shfl_down(key, off);
+    const uint32_t on = __shfl_down(node, off);
+    if (lane + off < 64u && on == node && ok < key) key = ok;
+  }
+  const uint32_t prev = __shfl_up(node, 1u);
+  if (node != kAbsent && (lane == 0u || prev != node) && key != kSahNoSplit) atomicMin(&best[node], key);
+}
+// per open node: the split it takes, and how many of its two children are inner nodes (>= 2 triangles)
+__global__ void __launch_bounds__(256) k_sah_decide(const uint32_t* __restrict__ act, uint32_t count, const unsigned long long* __restrict__ best,
+                                                     const uint32_t* __restrict__ first, const uint32_t* __restrict__ last, uint32_t force_median,
+                                                     uint2* __restrict__ split, uint32_t* __restrict__ cnt) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= count) return;
+  const uint32_t node = act[j], lo = first[node], hi = last[node] + 1u;
+  const unsigned long long key = best[node];
+  uint32_t axis = (uint32_t)(key >> 28) & 3u, k = lo + ((uint32_t)key & kSahPosMask);
+  if (force_median || key == kSahNoSplit || axis > 2u || k <= lo || k >= hi) { axis = 0u; k = lo + (hi - lo) / 2u; }  // very deep trees: halve
+  split[node] = make_uint2(axis, k);
+  cnt[j] = (k - lo >= 2u ? 1u : 0u) + (hi - k >= 2u ? 1u : 0u);
+}
+__global__ void __launch_bounds__(256) k_sah_children(const uint32_t* __restrict__ act, uint32_t count, const uint32_t* __restrict__ cnt,
+                                                       const uint32_t* __restrict__ off, uint32_t next_id, const uint2* __restrict__ split,
+                                                       uint32_t* __restrict__ first, uint32_t* __restrict__ last, uint32_t* __restrict__ left,
+                                                       uint32_t* __restrict__ right, uint32_t* __restrict__ node_parent, uint32_t* __restrict__ leaf_parent,
+                                                       uint32_t* __restrict__ act_next, unsigned long long* __restrict__ best, uint32_t* __restrict__ made) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= count) return;
+  const uint32_t node = act[j], lo = first[node], hi = last[node] + 1u, k = split[node].y;
+  uint32_t slot = off[j];
+  if (k - lo >= 2u) {
+    const uint32_t id = next_id + slot;
+    left[node] = id; first[id] = lo; last[id] = k - 1u; node_parent[id] = node; best[id] = kSahNoSplit; act_next[slot] = id;
+    ++slot;
+  } else { left[node] = kLeafBit | lo; leaf_parent[lo] = node; }
+  if (hi - k >= 2u) {
+    const uint32_t id = next_id + slot;
+    right[node] = id; first[id] = k; last[id] = hi - 1u; node_parent[id] = node; best[id] = kSahNoSplit; act_next[slot] = id;
+  } else { right[node] = kLeafBit | k; leaf_parent[k] = node; }
+  if (j + 1u == count) made[0] = off[j] + cnt[j];
+}
+// side[triangle] = 1 when it goes to the left child of its node
+__global__ void __launch_bounds__(256) k_sah_side(uint32_t n, const uint32_t* __restrict__ node_of, const uint2* __restrict__ split,
+                                                   const uint32_t* __restrict__ ord0, const uint32_t* __restrict__ ord1, const uint32_t* __restrict__ ord2,
+                                                   uint8_t* __restrict__ side) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const uint32_t node = node_of[p];
+  if (node == kAbsent) return;
+  const uint2 sp = split[node];
+  const uint32_t id = sp.x == 0u ? ord0[p] : (sp.x == 1u ? ord1[p] : ord2[p]);
+  side[id] = p < sp.y ? 1u : 0u;
+}
+__global__ void __launch_bounds__(256) k_sah_flags(uint32_t n, const uint32_t* __restrict__ node_of, const uint32_t* __restrict__ ord0,
+                                                    const uint32_t* __restrict__ ord1, const uint32_t* __restrict__ ord2, const uint8_t* __restrict__ side,
+                                                    Flag3* __restrict__ flags) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  Flag3 f{{0u, 0u, 0u}};
+  if (node_of[p] != kAbsent) { f.v[0] = side[ord0[p]]; f.v[1] = side[ord1[p]]; f.v[2] = side[ord2[p]]; }
+  flags[p] = f;
+}
+// stable partition of every open node's range in the three orders, and the node every position belongs to in the next round
+__global__ void __launch_bounds__(256) k_sah_scatter(uint32_t n, uint32_t* __restrict__ node_of, const uint2* __restrict__ split,
+                                                      const uint32_t* __restrict__ first, const uint32_t* __restrict__ left, const uint32_t* __restrict__ right,
+                                                      const Flag3* __restrict__ flags, const Flag3* __restrict__ scan, const uint32_t* __restrict__ in0,
+                                                      const uint32_t* __restrict__ in1, const uint32_t* __restrict__ in2, uint32_t* __restrict__ out0,
+                                                      uint32_t* __restrict__ out1, uint32_t* __restrict__ out2) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const uint32_t node = node_of[p];
+  const uint32_t id[3] = {in0[p], in1[p], in2[p]};
+  uint32_t* const out[3] = {out0, out1, out2};
+  if (node == kAbsent) {
+#pragma unroll
+    for (int b = 0; b < 3; ++b) out[b][p] = id[b];
+    return;
+  }
+  const uint32_t lo = first[node], k = split[node].y;
+  const Flag3 f = flags[p], sp = scan[p], s0 = scan[lo];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    const uint32_t lefts = sp.v[b] - s0.v[b];  // left-going triangles before p in this node's range of order b
+    out[b][f.v[b] ? lo + lefts : k + ((p - lo) - lefts)] = id[b];
+  }
+  const uint32_t child = p < k ? left[node] : right[node];
+  node_of[p] = (child & kLeafBit) ? kAbsent : child;
+}
+
 // Device buffers of the builder.  A build makes ~60 of them; hipMalloc / hipFree cost 50-200 us each (the free also waits for the
 // device), which was a third of a 1 M-triangle commit.  While an Arena is active on this thread, alloc() carves from it instead
 // (256-B aligned bump allocation, released all at once with the arena); anything that does not fit falls back to hipMalloc.
@@ -948,6 +1107,100 @@ static std::string ploc_hierarchy(BvhBuffers& b, BvhTopology& t, hipStream_t s) 
   return "";
 }
 
+
+// Builds the same tables as ploc_hierarchy with the full-sweep SAH rounds above (t.sorted_ids is re-ordered; node boxes come out fitted).
+static std::string sah_hierarchy(BvhBuffers& b, BvhTopology& t, hipStream_t s) {
+  const uint32_t n = b.tri_count, ni = n - 1;
+  DevBuf keys_in, keys_out, ids_in, ord[3][2], node_of, box_in, box_l, box_r, best, side, flags, scan, act[2], cnt, off, split, made, tmp;
+  std::string e;
+  for (DevBuf* d : {&keys_in, &keys_out, &ids_in, &ord[0][0], &ord[0][1], &ord[1][0], &ord[1][1], &ord[2][0], &ord[2][1], &node_of, &act[0], &act[1], &cnt, &off})
+    if (!(e = d->alloc((size_t)n * 4)).empty()) return e;
+  for (DevBuf* d : {&box_in, &box_l, &box_r})
+    if (!(e = d->alloc((size_t)n * sizeof(Box6))).empty()) return e;
+  if (!(e = best.alloc((size_t)ni * 8)).empty()) return e;
+  if (!(e = split.alloc((size_t)ni * 8)).empty()) return e;
+  if (!(e = side.alloc(n)).empty()) return e;
+  if (!(e = flags.alloc((size_t)n * sizeof(Flag3))).empty()) return e;
+  if (!(e = scan.alloc((size_t)n * sizeof(Flag3))).empty()) return e;
+  if (!(e = made.alloc(16)).empty()) return e;
+  const uint32_t* nk = node_of.as<uint32_t>();
+  auto rk = rocprim::make_reverse_iterator(nk + n);
+  auto rin = rocprim::make_reverse_iterator(box_in.as<Box6>() + n);
+  auto rout = rocprim::make_reverse_iterator(box_r.as<Box6>() + n);
+  size_t need[5] = {0, 0, 0, 0, 0};
+  HIP_TRY(rocprim::radix_sort_pairs(nullptr, need[0], keys_in.as<uint32_t>(), keys_out.as<uint32_t>(), ids_in.as<uint32_t>(), ord[0][0].as<uint32_t>(), n, 0, 32, s));
+  HIP_TRY(rocprim::inclusive_scan_by_key(nullptr, need[1], nk, box_in.as<Box6>(), box_l.as<Box6>(), n, BoxUnionOp(), rocprim::equal_to<uint32_t>(), s));
+  HIP_TRY(rocprim::inclusive_scan_by_key(nullptr, need[2], rk, rin, rout, n, BoxUnionOp(), rocprim::equal_to<uint32_t>(), s));
+  HIP_TRY(rocprim::exclusive_scan(nullptr, need[3], cnt.as<uint32_t>(), off.as<uint32_t>(), 0u, n, rocprim::plus<uint32_t>(), s));
+  HIP_TRY(rocprim::exclusive_scan(nullptr, need[4], flags.as<Flag3>(), scan.as<Flag3>(), Flag3{{0u, 0u, 0u}}, n, Flag3Plus(), s));
+  size_t tmp_bytes = 0;
+  for (size_t v : need) tmp_bytes = std::max(tmp_bytes, v);
+  if (!(e = tmp.alloc(tmp_bytes)).empty()) return e;
+  for (int a = 0; a < 3; ++a) {
+    hipLaunchKernelGGL(k_sah_keys, dim3(nblk(n)), dim3(256), 0, s, t.tri_box.as<Box6>(), n, a, keys_in.as<uint32_t>(), ids_in.as<uint32_t>());
+    size_t tb = tmp_bytes;
+    HIP_TRY(rocprim::radix_sort_pairs(tmp.p, tb, keys_in.as<uint32_t>(), keys_out.as<uint32_t>(), ids_in.as<uint32_t>(), ord[a][0].as<uint32_t>(), n, 0, 32, s));
+  }
+  hipLaunchKernelGGL(k_sah_init, dim3(nblk(n)), dim3(256), 0, s, n, node_of.as<uint32_t>(), t.first.as<uint32_t>(), t.last.as<uint32_t>(),
+                     t.node_parent.as<uint32_t>(), act[0].as<uint32_t>(), best.as<unsigned long long>());
+  const float pad = box_pad(b);
+  uint32_t quant = (uint32_t)kSahQuant;  // = the leaf slots of the cooperative pass (traverse.h: RT_LEAF_SLOTS)
+  if (const char* ev = getenv("HALART_SAH_QUANT")) quant = (uint32_t)std::max(1, atoi(ev));  // tuning knob
+  uint32_t open = 1, next_id = 1, round = 0;
+  int cur = 0, ac = 0;
+  constexpr uint32_t kSweepRounds = 64;  // below that depth every node is halved instead: at most 28 more rounds
+  while (open > 0) {
+    if (round > kSweepRounds + 32u) return "bvh_build: the SAH rounds do not terminate";
+    const uint32_t* o[3] = {ord[0][cur].as<uint32_t>(), ord[1][cur].as<uint32_t>(), ord[2][cur].as<uint32_t>()};
+    if (round < kSweepRounds) {
+      for (uint32_t a = 0; a < 3; ++a) {
+        hipLaunchKernelGGL(k_sah_gather, dim3(nblk(n)), dim3(256), 0, s, o[a], t.tri_box.as<Box6>(), n, box_in.as<Box6>());
+        size_t tb = tmp_bytes;
+        HIP_TRY(rocprim::inclusive_scan_by_key(tmp.p, tb, nk, box_in.as<Box6>(), box_l.as<Box6>(), n, BoxUnionOp(), rocprim::equal_to<uint32_t>(), s));
+        tb = tmp_bytes;
+        HIP_TRY(rocprim::inclusive_scan_by_key(tmp.p, tb, rk, rin, rout, n, BoxUnionOp(), rocprim::equal_to<uint32_t>(), s));
+        hipLaunchKernelGGL(k_sah_cost, dim3(nblk(n)), dim3(256), 0, s, n, a, nk, t.first.as<uint32_t>(), t.last.as<uint32_t>(), box_l.as<Box6>(),
+                           box_r.as<Box6>(), best.as<unsigned long long>(), t.node_box.as<Box6>(), pad, quant);
+      }
+    } else {  // the boxes are still needed: axis 0 only
+      hipLaunchKernelGGL(k_sah_gather, dim3(nblk(n)), dim3(256), 0, s, o[0], t.tri_box.as<Box6>(), n, box_in.as<Box6>());
+      size_t tb = tmp_bytes;
+      HIP_TRY(rocprim::inclusive_scan_by_key(tmp.p, tb, nk, box_in.as<Box6>(), box_l.as<Box6>(), n, BoxUnionOp(), rocprim::equal_to<uint32_t>(), s));
+      tb = tmp_bytes;
+      HIP_TRY(rocprim::inclusive_scan_by_key(tmp.p, tb, rk, rin, rout, n, BoxUnionOp(), rocprim::equal_to<uint32_t>(), s));
+      hipLaunchKernelGGL(k_sah_cost, dim3(nblk(n)), dim3(256), 0, s, n, 0u, nk, t.first.as<uint32_t>(), t.last.as<uint32_t>(), box_l.as<Box6>(),
+                         box_r.as<Box6>(), best.as<unsigned long long>(), t.node_box.as<Box6>(), pad, quant);
+    }
+    hipLaunchKernelGGL(k_sah_decide, dim3(nblk(open)), dim3(256), 0, s, act[ac].as<uint32_t>(), open, best.as<unsigned long long>(), t.first.as<uint32_t>(),
+                       t.last.as<uint32_t>(), round >= kSweepRounds ? 1u : 0u, split.as<uint2>(), cnt.as<uint32_t>());
+    size_t tb = tmp_bytes;
+    HIP_TRY(rocprim::exclusive_scan(tmp.p, tb, cnt.as<uint32_t>(), off.as<uint32_t>(), 0u, open, rocprim::plus<uint32_t>(), s));
+    hipLaunchKernelGGL(k_sah_children, dim3(nblk(open)), dim3(256), 0, s, act[ac].as<uint32_t>(), open, cnt.as<uint32_t>(), off.as<uint32_t>(), next_id,
+                       split.as<uint2>(), t.first.as<uint32_t>(), t.last.as<uint32_t>(), t.left.as<uint32_t>(), t.right.as<uint32_t>(),
+                       t.node_parent.as<uint32_t>(), t.leaf_parent.as<uint32_t>(), act[ac ^ 1].as<uint32_t>(), best.as<unsigned long long>(),
+                       made.as<uint32_t>());
+    hipLaunchKernelGGL(k_sah_side, dim3(nblk(n)), dim3(256), 0, s, n, nk, split.as<uint2>(), o[0], o[1], o[2], side.as<uint8_t>());
+    hipLaunchKernelGGL(k_sah_flags, dim3(nblk(n)), dim3(256), 0, s, n, nk, o[0], o[1], o[2], side.as<uint8_t>(), flags.as<Flag3>());
+    tb = tmp_bytes;
+    HIP_TRY(rocprim::exclusive_scan(tmp.p, tb, flags.as<Flag3>(), scan.as<Flag3>(), Flag3{{0u, 0u, 0u}}, n, Flag3Plus(), s));
+    hipLaunchKernelGGL(k_sah_scatter, dim3(nblk(n)), dim3(256), 0, s, n, node_of.as<uint32_t>(), split.as<uint2>(), t.first.as<uint32_t>(),
+                       t.left.as<uint32_t>(), t.right.as<uint32_t>(), flags.as<Flag3>(), scan.as<Flag3>(), o[0], o[1], o[2], ord[0][cur ^ 1].as<uint32_t>(),
+                       ord[1][cur ^ 1].as<uint32_t>(), ord[2][cur ^ 1].as<uint32_t>());
+    uint32_t now = 0;
+    HIP_TRY(hipMemcpyAsync(&now, made.p, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    next_id += now;
+    if (next_id > ni) return "bvh_build: the SAH rounds made more nodes than a binary tree has";
+    open = now;
+    cur ^= 1; ac ^= 1; ++round;
+  }
+  if (next_id != ni) return "bvh_build: the SAH rounds made " + std::to_string(next_id) + " of " + std::to_string(ni) + " nodes";
+  HIP_TRY(hipMemcpyAsync(t.sorted_ids.p, ord[0][cur].p, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  HIP_TRY(hipGetLastError());
+  return "";
+}
+
 void bvh_free_topology(void* topo) { delete static_cast<BvhTopology*>(topo); }
 
 std::string bvh_build(BvhBuffers& b, uint32_t leaf_max, hipStream_t s) {
@@ -989,11 +1242,16 @@ std::string bvh_build(BvhBuffers& b, uint32_t leaf_max, hipStream_t s) {
     if (!(e = tmp.alloc(tmp_bytes)).empty()) return e;
     HIP_TRY(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, keys_in.as<unsigned long long>(), keys_out.as<unsigned long long>(),
                                       ids_in.as<uint32_t>(), t.sorted_ids.as<uint32_t>(), n, 0, 64, s));
-    // hierarchy over the sorted triangles: PLOC for scenes large enough to repay its ~40 rounds of launches (+4-5 % rays/s on
-    // the 82 k and 1 M triangle scenes for +6 ms of build, profiles/r01_h_experiments.txt), Karras' LBVH otherwise
-    const char* builder = getenv("HALART_BUILDER");  // "ploc" | "lbvh": A/B knob
-    const bool ploc = builder ? !strcmp(builder, "ploc") : n >= 4096u;
-    if (ploc) {
+    // hierarchy over the triangles: full-sweep SAH rounds for scenes large enough to repay them (1 M triangles: 34 ms of build instead
+    // of PLOC's 11 ms for 10-15 % fewer node visits per closest-hit ray, profiles/r02_experiments.txt), Karras' LBVH over the Morton
+    // order otherwise; PLOC (nearest-neighbour clustering along the Morton order) stays selectable as the fast large-scene build
+    const char* builder = getenv("HALART_BUILDER");  // "sah" | "ploc" | "lbvh": A/B knob
+    const bool sah = builder ? !strcmp(builder, "sah") : n >= 4096u;
+    const bool ploc = builder && !strcmp(builder, "ploc");
+    if (sah) {
+      if (!(e = sah_hierarchy(b, t, s)).empty()) return e;
+      t.fitted = true;
+    } else if (ploc) {
       if (!(e = ploc_hierarchy(b, t, s)).empty()) return e;
       t.fitted = true;
     } else

@@ -2,7 +2,8 @@
 # Compile-time / env knob sweep on the GPU box (the box has hipcc and rebuilds libhalart.so in ~20 s):
 #   gpurun -- 'bash scripts/variant_sweep.sh "-DRT_STACK_LDS=6" "ENV:HALART_LEAF_MAX=4" ...'
 # prints Mrays/s, ms/frame and the per-kernel split of bench.py (configs[3]) for the default build and for each variant
-# (a compile flag rebuilds the library; "ENV:NAME=VALUE" runs the current build with that environment variable); the default is rebuilt at the end.
+# (a compile flag rebuilds the library; "ENV:NAME=VALUE" runs the current build with that environment variable; "BOTH:<flags>|<NAME=VALUE ...>"
+# does both); the default is rebuilt at the end.
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd $ROOT
 STEPS=${SWEEP_STEPS:-20}
@@ -22,6 +23,7 @@ rebuilt=0
 for v in "$@"; do
   case "$v" in
     ENV:*) echo "$v"; run "${v#ENV:}";;
+    BOTH:*) w="${v#BOTH:}"; build "${w%%|*}"; rebuilt=1; echo "$v"; run "${w#*|}";;
     *) build "$v"; rebuilt=1; echo "$v"; run "";;
   esac
 done
