@@ -205,6 +205,8 @@ struct P3 { float x, y, z; };  // 12-B per-path record: one dwordx3 load / store
 struct PathState {
   P3* radiance;            // L of the path: set by the depth-0 shade, added to by later shades (rarely: light hit,
                            // environment, emission) and by the shadow passes
+  P3* radiance_env;        // Le of the path: the unoccluded environment connections (their own sum, RENDER_SPEC 6: the two shadow
+                           // passes of a bounce then never touch the same word and may share a launch)
   P3* albedo;              // first-hit AOVs of this sample
   P3* normal;
 };

@@ -344,31 +344,35 @@ k_trace_shadow(SceneView sv, Queues q, PathState ps, Control* __restrict__ ctl, 
   const uint32_t n = ctl->n_shadow[kind][depth];
   uint2* spill = spill_base ? spill_base + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * kStackSpill : nullptr;
   StepCounters sc;
-  ShadowSource<STAGED, ALPHA> src{q.shadow[kind], ps.radiance};
+  ShadowSource<STAGED, ALPHA> src{q.shadow[kind], kind ? ps.radiance_env : ps.radiance};
   persistent_trace<true, COUNT, STAGED, ALPHA>(sv, lds, spill, &ctl->work_shadow[kind], n, refill, src, sc);
   if (COUNT) flush_counters(ctl, 1, sc);
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// K5c + K5a in one launch: the last shadow pass of bounce d and the closest-hit traversal of bounce d + 1.  They are independent (the
-// shadow pass only adds to radiance, the closest-hit pass only reads the ray queue shade(d) wrote) and every persistent launch ends in
-// a tail of a few long rays during which most of the chip idles — a fixed cost that weighs more the smaller the launch (late bounces,
-// a rank's share of a strong-scaled frame).  Here a wave that finds the shadow queue dry moves straight on to the bounce rays: one tail
-// instead of two.  (Two launches side by side on two streams do not achieve this: each takes the chip from the other all the time,
-// profiles/r02_experiments.txt.)  Not used by updates that carry per-launch timing events or counting kernels.
+// K5c + K5a in one launch: the shadow passes of bounce d and the closest-hit traversal of bounce d + 1.  They are independent (a light
+// connection only adds to its path's L, an environment connection to its Le, the closest-hit pass only reads the ray queue shade(d)
+// wrote) and every persistent launch ends in a tail of a few long rays during which most of the chip idles — a fixed cost that weighs
+// more the smaller the launch (late bounces, a rank's share of a strong-scaled frame; 10-20 % of the wave slots of a configs[3] launch).
+// Here a wave that finds one queue dry moves straight on to the next: one tail instead of three.  (Launches side by side on two streams
+// do not achieve this: each takes the chip from the other all the time, profiles/r02_experiments.txt.)  Not used by updates that carry
+// per-launch timing events or counting kernels.
 // ---------------------------------------------------------------------------------------------------------
 template <bool STAGED, bool ALPHA>
 __global__ void __launch_bounds__(kTraverseThreads, STAGED ? kTraverseWavesPerSimdStaged : kTraverseWavesPerSimd)
 k_trace_shadow_then_batch(SceneView sv, const Tri* __restrict__ tris_any, Queues q, PathState ps, Control* __restrict__ ctl, uint32_t depth,
-                          uint32_t kind, const hala_ray* __restrict__ rays, hala_hit* __restrict__ hits, uint2* __restrict__ spill_base, uint32_t refill) {
+                          uint32_t kinds, const hala_ray* __restrict__ rays, hala_hit* __restrict__ hits, uint2* __restrict__ spill_base, uint32_t refill) {
   const TraverseLds lds = stage_bvh<STAGED>(sv, g_smem);
   uint2* spill = spill_base ? spill_base + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * kStackSpill : nullptr;
   StepCounters sc;
   {
     SceneView sva = sv;
     sva.tris = tris_any;  // RENDER_SPEC 7.1d (STAGED: the launcher only fuses when both passes traverse the same triangles)
-    ShadowSource<STAGED, ALPHA> src{q.shadow[kind], ps.radiance};
-    persistent_trace<true, false, STAGED, ALPHA>(sva, lds, spill, &ctl->work_shadow[kind], ctl->n_shadow[kind][depth], refill, src, sc);
+    for (uint32_t kind = 0; kind < 2u; ++kind) {  // bit 0: light connections, bit 1: environment connections
+      if (!((kinds >> kind) & 1u)) continue;
+      ShadowSource<STAGED, ALPHA> src{q.shadow[kind], kind ? ps.radiance_env : ps.radiance};
+      persistent_trace<true, false, STAGED, ALPHA>(sva, lds, spill, &ctl->work_shadow[kind], ctl->n_shadow[kind][depth], refill, src, sc);
+    }
   }
   const uint32_t n = ctl->n_active[depth + 1u];
   if (blockIdx.x == 0 && threadIdx.x == 0) ctl->rays_closest += n;
@@ -457,6 +461,7 @@ __global__ void __launch_bounds__(kShadeThreads, SIMPLE ? RT_SHADE_WAVES_SIMPLE 
   if (PRIMARY && active) {
     slot = i;
     real = primary_ray(fc, sv, slot, &o, &d, &rng);
+    if (fc.u.env_type == 1u) ps.radiance_env[slot] = P3{0.0f, 0.0f, 0.0f};
     if (!real) {  // resolve reads every slot of the rank's tile buffer
       ps.radiance[slot] = P3{0.0f, 0.0f, 0.0f};
       ps.albedo[slot] = P3{0.0f, 0.0f, 0.0f};
@@ -675,6 +680,7 @@ __global__ void __launch_bounds__(256) k_resolve(FrameConst fc, PathState ps, fl
     const uint32_t slot = k * fc.pixel_slots + pslot;
     const P3 lr = ps.radiance[slot];
     f3 L = mk3(lr.x, lr.y, lr.z);
+    if (fc.u.env_type == 1u) { const P3 le = ps.radiance_env[slot]; L = L + mk3(le.x, le.y, le.z); }  // RENDER_SPEC §6: L + Le
     if (!(isfinite(L.x) && isfinite(L.y) && isfinite(L.z))) L = splat3(0.0f);
     const uint32_t fi = fc.u.frame_index + k;
     const P3 sa = ps.albedo[slot], sn = ps.normal[slot];
@@ -775,17 +781,17 @@ void launch_trace_shadow(const LaunchCfg& lc, const SceneView& sv0, const Queues
 // the fused launch; false: the caller must issue the two launches separately (an LDS-staged scene whose any-hit rays traverse a
 // different triangle copy than its closest-hit rays: only one of them is staged)
 bool launch_trace_shadow_then_batch(const LaunchCfg& lc, const SceneView& sv, const Queues& q, const PathState& ps, Control* ctl, uint32_t depth,
-                                    uint32_t kind, hipStream_t s) {
+                                    uint32_t kinds, hipStream_t s) {
   if (sv.staged && sv.tris_any != sv.tris) return false;
   const size_t smem = traverse_smem(sv);
   const dim3 grid(lc.persistent_blocks), block(kTraverseThreads);
   const hala_ray* rays = q.rays[(depth + 1u) & 1u];
   if (sv.staged) {
-    if (sv.any_translucent) hipLaunchKernelGGL((k_trace_shadow_then_batch<true, true>), grid, block, smem, s, sv, sv.tris_any, q, ps, ctl, depth, kind, rays, q.hits, lc.spill, lc.refill);
-    else hipLaunchKernelGGL((k_trace_shadow_then_batch<true, false>), grid, block, smem, s, sv, sv.tris_any, q, ps, ctl, depth, kind, rays, q.hits, lc.spill, lc.refill);
+    if (sv.any_translucent) hipLaunchKernelGGL((k_trace_shadow_then_batch<true, true>), grid, block, smem, s, sv, sv.tris_any, q, ps, ctl, depth, kinds, rays, q.hits, lc.spill, lc.refill);
+    else hipLaunchKernelGGL((k_trace_shadow_then_batch<true, false>), grid, block, smem, s, sv, sv.tris_any, q, ps, ctl, depth, kinds, rays, q.hits, lc.spill, lc.refill);
   } else {
-    if (sv.any_translucent) hipLaunchKernelGGL((k_trace_shadow_then_batch<false, true>), grid, block, smem, s, sv, sv.tris_any, q, ps, ctl, depth, kind, rays, q.hits, lc.spill, lc.refill);
-    else hipLaunchKernelGGL((k_trace_shadow_then_batch<false, false>), grid, block, smem, s, sv, sv.tris_any, q, ps, ctl, depth, kind, rays, q.hits, lc.spill, lc.refill);
+    if (sv.any_translucent) hipLaunchKernelGGL((k_trace_shadow_then_batch<false, true>), grid, block, smem, s, sv, sv.tris_any, q, ps, ctl, depth, kinds, rays, q.hits, lc.spill, lc.refill);
+    else hipLaunchKernelGGL((k_trace_shadow_then_batch<false, false>), grid, block, smem, s, sv, sv.tris_any, q, ps, ctl, depth, kinds, rays, q.hits, lc.spill, lc.refill);
   }
   return true;
 }

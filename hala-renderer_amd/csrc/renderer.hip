@@ -157,7 +157,7 @@ struct hala_rt_renderer {
   DeviceArray<float4> img_local[4];  // accum, albedo, normal, final (slot order)
   DeviceArray<float4> img_full[4];   // row-major, only after scatter_gathered_tiles (world > 1)
   bool full_valid[4] = {false, false, false, false};
-  DeviceArray<P3> ps_lr, ps_alb, ps_nrm;
+  DeviceArray<P3> ps_lr, ps_le, ps_alb, ps_nrm;
   DeviceArray<hala_ray> q_rays[2];
   DeviceArray<float4> q_state[2];
   DeviceArray<hala_hit> q_hits;
@@ -235,7 +235,7 @@ struct hala_rt_renderer {
     q.hits = q_hits.ptr; q.shadow[0] = q_shadow[0].ptr; q.shadow[1] = q_shadow[1].ptr;
     return q;
   }
-  PathState path_state() const { return PathState{ps_lr.ptr, ps_alb.ptr, ps_nrm.ptr}; }
+  PathState path_state() const { return PathState{ps_lr.ptr, ps_le.ptr, ps_alb.ptr, ps_nrm.ptr}; }
 
   FrameConst frame_const(const hala_global_uniform& u, uint32_t samples = 1) const {
     FrameConst fc{};
@@ -350,7 +350,7 @@ void compute_tiling(hala_rt_renderer* r) {
 int alloc_wavefront(hala_rt_renderer* r, uint32_t samples) {
   const size_t n = (size_t)r->slot_count * samples;
   if (n > 0xfffffff0ull) RT_FAIL("The sample batch is too large for 32-bit path slots.");
-  RT_HIP(r->ps_lr.resize(n)); RT_HIP(r->ps_alb.resize(n)); RT_HIP(r->ps_nrm.resize(n));
+  RT_HIP(r->ps_lr.resize(n)); RT_HIP(r->ps_le.resize(n)); RT_HIP(r->ps_alb.resize(n)); RT_HIP(r->ps_nrm.resize(n));
   RT_HIP(r->q_rays[0].resize(n)); RT_HIP(r->q_rays[1].resize(n)); RT_HIP(r->q_state[0].resize(n)); RT_HIP(r->q_state[1].resize(n));
   RT_HIP(r->q_hits.resize(n)); RT_HIP(r->q_shadow[0].resize(n)); RT_HIP(r->q_shadow[1].resize(n));
   r->batch_capacity = samples;
@@ -809,8 +809,8 @@ static int update_impl(hala_rt_renderer* r, uint32_t frames) {
   // packet on the stream, i.e. a few microseconds between two launches
   const bool timed = r->launch_event_period == 1u || (r->launch_event_period > 1u && (r->update_counter % r->launch_event_period) == 0u);
   r->update_counter++;
-  // The last shadow pass of bounce d and the closest-hit traversal of bounce d + 1 are independent: untimed updates issue them as ONE
-  // persistent launch (k_trace_shadow_then_batch: one tail of long rays instead of two).  Updates that carry per-launch timing events or
+  // The shadow passes of bounce d and the closest-hit traversal of bounce d + 1 are independent: untimed updates issue them as ONE
+  // persistent launch (k_trace_shadow_then_batch: one tail of long rays instead of three).  Updates that carry per-launch timing events or
   // counting kernels keep one launch per pass, so that every measured launch is one kernel symbol with the chip to itself.
   const bool fuse = r->fuse_passes && !timed && !r->counting && (u.num_of_lights > 0 || u.env_type == 1u);
   bool traced = false;  // the closest-hit pass of this depth already ran inside the previous depth's fused launch
@@ -826,19 +826,16 @@ static int update_impl(hala_rt_renderer* r, uint32_t frames) {
     if (timed) { hipEvent_t b = r->next_event(te); RT_HIP(hipEventRecord(b, s)); }
     launch_shade(fc, sv, q, ps, ctl, depth, s);
     if (timed) { hipEvent_t c = r->next_event(te); RT_HIP(hipEventRecord(c, s)); }
-    // light connections first, environment connections second: contributions land in spec order (RENDER_SPEC §6)
-    const uint32_t last_kind = u.env_type == 1u ? 1u : 0u;
-    const bool fuse_here = fuse && depth + 1u < r->max_depth;
-    if (u.num_of_lights > 0) {
-      if (fuse_here && last_kind == 0u && launch_trace_shadow_then_batch(r->lcfg, sv, q, ps, ctl, depth, 0, s)) traced = true;
-      else launch_trace_shadow(r->lcfg, sv, q, ps, ctl, depth, 0, r->counting, s);
-      te.shadow_launches += timed ? 1u : 0u;
-    }
-    if (u.env_type == 1u) {
-      if (fuse_here && launch_trace_shadow_then_batch(r->lcfg, sv, q, ps, ctl, depth, 1, s)) traced = true;
-      else launch_trace_shadow(r->lcfg, sv, q, ps, ctl, depth, 1, r->counting, s);
-      te.shadow_launches += timed ? 1u : 0u;
-    }
+    // light connections add to the path's L, environment connections to its Le (RENDER_SPEC §6): the two passes are independent of each
+    // other and of the next bounce's closest-hit pass
+    const uint32_t kinds = (u.num_of_lights > 0 ? 1u : 0u) | (u.env_type == 1u ? 2u : 0u);
+    if (fuse && kinds && depth + 1u < r->max_depth && launch_trace_shadow_then_batch(r->lcfg, sv, q, ps, ctl, depth, kinds, s)) traced = true;
+    else
+      for (uint32_t kind = 0; kind < 2u; ++kind) {
+        if (!((kinds >> kind) & 1u)) continue;
+        launch_trace_shadow(r->lcfg, sv, q, ps, ctl, depth, kind, r->counting, s);
+        te.shadow_launches += timed ? 1u : 0u;
+      }
     if (timed) { hipEvent_t d = r->next_event(te); RT_HIP(hipEventRecord(d, s)); }
   }
   launch_resolve(fc, ps, r->img_local[0].ptr, r->img_local[1].ptr, r->img_local[2].ptr, r->img_local[3].ptr, s);

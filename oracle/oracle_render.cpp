@@ -614,7 +614,7 @@ static PixelOut trace_path(const Frame& f, uint32_t px, uint32_t py, uint32_t fr
   uint32_t rng = rng_init(py * f.p.width + px, frame_index);
   V3 o, d;
   camera_ray(f, px, py, &rng, &o, &d);
-  V3 L = v3s(0.0f), T = v3s(1.0f);
+  V3 L = v3s(0.0f), Le = v3s(0.0f), T = v3s(1.0f);
   float prev_pdf = kNoNeePdf;  // no vertex has sampled a direction yet: an emitter reached through skipped (7.1d) surfaces counts in full
   PixelOut out; out.albedo = v3s(0.0f); out.normal = v3s(0.0f);
   const uint32_t nl = (uint32_t)s->light_count;
@@ -727,7 +727,7 @@ static PixelOut trace_path(const Frame& f, uint32_t px, uint32_t py, uint32_t fr
             V3 col = env_map_eval(f, wi);
             V3 tc = T * (fb * col * (cosl * w / pdf_e));
             if (trans.x != 1.0f || trans.y != 1.0f || trans.z != 1.0f) tc = tc * trans;
-            L = L + tc;
+            Le = Le + tc;  // RENDER_SPEC 6: the environment connections have their own running sum
           }
         }
       }
@@ -755,6 +755,7 @@ static PixelOut trace_path(const Frame& f, uint32_t px, uint32_t py, uint32_t fr
     o = scattered ? pm : madd3(sf.ng, side, sf.P);
     d = wi;
   }
+  if (f.env_type == 1u) L = L + Le;
   if (!(std::isfinite(L.x) && std::isfinite(L.y) && std::isfinite(L.z))) L = v3s(0.0f);
   out.L = L;
   return out;
