@@ -436,6 +436,7 @@ def test_ploc_drivers_build_the_same_tree(halart, oracle, monkeypatch):
     (k_ploc_tail) or not (HALART_PLOC_TAIL=0): all of them must emit byte-identical nodes and triangle orders"""
     s = scenes.sponza_class(target_triangles=60_000)
     trees = []
+    monkeypatch.setenv("HALART_BUILDER", "ploc")  # the fast large-scene build (the default at this size is the SAH one)
     for tail, look, collapse_look in (("1", "6", "4"), ("0", "1", "1"), ("1", "1", "3"), ("0", "7", "9")):
         monkeypatch.setenv("HALART_PLOC_TAIL", tail)
         monkeypatch.setenv("HALART_PLOC_LOOK_EVERY", look)
@@ -444,12 +445,75 @@ def test_ploc_drivers_build_the_same_tree(halart, oracle, monkeypatch):
         trees.append(r.download_bvh())
         info = r.bvh_info()
         r.close()
-    assert info.triangle_count >= 4096  # PLOC is the builder at this size
+    assert info.triangle_count >= 4096
     for nodes, tris in trees[1:]:
         assert nodes.tobytes() == trees[0][0].tobytes() and tris.tobytes() == trees[0][1].tobytes()
     osc = oracle.OracleScene(s)
     rc, _ = oracle.validate_bvh(trees[0][0], trees[0][1], osc.triangles())
     assert rc == 0
+
+
+def test_builders_differ_in_trees_not_in_results(halart, oracle, monkeypatch):
+    """the three hierarchy builders (full-sweep SAH: the default from 4096 triangles; PLOC; LBVH) over one scene: every tree passes the
+    structural check, is rebuilt byte for byte, gives the oracle's hits (the oracle traverses its OWN tree) and the oracle's step counts
+    on that very tree; the SAH tree is the one with the fewest node visits per ray"""
+    s = scenes.sponza_class(target_triangles=60_000, disney=False)
+    osc = oracle.OracleScene(s)
+    mn, mx = osc.bounds()
+    rays = np.concatenate([random_rays(30000, mn, mx, 23), osc.camera_rays(160, 90, 0)])
+    want = osc.trace(rays, 0)
+    want_any = osc.trace(rays, 1)
+    visits = {}
+    for builder in ("sah", "ploc", "lbvh", None):
+        if builder is None: monkeypatch.delenv("HALART_BUILDER")
+        else: monkeypatch.setenv("HALART_BUILDER", builder)
+        r = make_renderer(halart, s, 16, 16)
+        nodes, tris = r.download_bvh()
+        rc, depth = oracle.validate_bvh(nodes, tris, osc.triangles())
+        assert rc == 0 and depth == r.bvh_info().max_depth, builder
+        got, cnt = r.trace_rays_host(rays, 0, count_steps=True)
+        assert got.tobytes() == want.tobytes(), builder
+        ohits, ocnt = oracle.trace_on_bvh(nodes, tris, rays, 0)
+        assert cnt == ocnt, builder
+        got_any, cnt_any = r.trace_rays_host(rays, 1, count_steps=True)
+        assert np.array_equal(got_any["t"], want_any["t"]), builder
+        assert cnt_any == oracle.trace_on_bvh(nodes, tris, rays, 1)[1], builder
+        r.close()
+        r2 = make_renderer(halart, s, 16, 16)  # deterministic: atomics only carry min / max / integer sums
+        n2, t2 = r2.download_bvh()
+        r2.close()
+        assert n2.tobytes() == nodes.tobytes() and t2.tobytes() == tris.tobytes(), builder
+        visits[builder] = (cnt[0], nodes.tobytes())
+    assert visits[None][1] == visits["sah"][1]  # the default at this size
+    assert visits["sah"][0] < min(visits["ploc"][0], visits["lbvh"][0]), {k: v[0] for k, v in visits.items()}
+
+
+def test_sah_build_of_coincident_triangles(halart, oracle):
+    """6000 copies of ONE triangle pair among ordinary geometry: every split of the pile costs the same, the sweep peels it a few
+    triangles at a time until the round limit, then halves (bvh_build.hip: kSweepRounds) — the build must end, the tree must be valid
+    and a ray into the pile must report the copy with the lowest id (RENDER_SPEC 4.2 tie rule), as brute force does"""
+    s = scenes.cornell_box()
+    quad = ((200.0, 100.0, 300.0), (350.0, 100.0, 300.0), (350.0, 250.0, 300.0), (200.0, 250.0, 300.0))  # inside the box, facing the camera
+    pile = scenes._merge_quads([quad] * 3000); pile.material_index = 0
+    s.meshes.append(H.HalaMesh([pile]))
+    s.nodes.append(H.HalaNode(name="pile", mesh_index=len(s.meshes) - 1))
+    osc = oracle.OracleScene(s)
+    r = make_renderer(halart, s, 16, 16)
+    info = r.bvh_info()
+    assert info.triangle_count == osc.triangle_count >= 6000
+    nodes, tris = r.download_bvh()
+    rc, depth = oracle.validate_bvh(nodes, tris, osc.triangles())
+    assert rc == 0 and depth == info.max_depth
+    rays = osc.camera_rays(96, 96, 0)
+    got = r.trace_rays_host(rays, 0)
+    assert got.tobytes() == osc.trace(rays, 0, brute=True).tobytes()
+    hits, cnt = r.trace_rays_host(rays, 0, count_steps=True)
+    assert cnt == oracle.trace_on_bvh(nodes, tris, rays, 0)[1]
+    imgs, _ = osc.render(48, 48, frames=1)
+    r2 = make_renderer(halart, s, 48, 48)
+    r2.update()
+    assert_images_equal(r2, imgs)
+    r.close(); r2.close()
 
 
 def test_refit_without_change_reproduces_the_build(halart, oracle):
