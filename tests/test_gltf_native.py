@@ -167,6 +167,55 @@ def test_jpeg_textures_decode_like_pil(tmp_path, variant):
     nat.close()
 
 
+def _native_decode_jpeg(tmp_path, data, name):
+    """the C++ loader's RGBA8 decode of a JPEG, through a glTF file that embeds it"""
+    import base64
+    s = scenes.cornell_box()
+    scenes.attach_textures(s, sets=1, size=16)
+    p = tmp_path / f"{name}.gltf"
+    write_gltf(s, str(p))
+    doc = json.load(open(p))
+    doc["images"][0] = {"uri": "data:image/jpeg;base64," + base64.b64encode(data).decode()}
+    json.dump(doc, open(p, "w"))
+    nat = NativeScene(str(p))
+    im = nat.desc.image_data[0]
+    got = np.frombuffer(C.string_at(im.data, im.num_of_bytes), dtype=np.uint8).reshape(im.height, im.width, 4).copy()
+    nat.close()
+    return got
+
+
+@pytest.mark.parametrize("variant", ["444", "420", "grey", "ragged", "tiny", "noise", "low_quality", "restart"])
+def test_progressive_jpeg_decodes_like_the_sequential_encoding(tmp_path, variant):
+    """progressive JPEG (SOF2: spectral selection + successive approximation, T.81 annex G) in the C++ loader.  libjpeg writes the SAME
+    quantised coefficients whether it entropy-codes them sequentially or progressively, so the two files must decode to the same bytes
+    here (the sequential decode is the one held against PIL above); PIL's own decode of the progressive file is the second check"""
+    import io
+    from PIL import Image
+    w, h = {"ragged": (61, 37), "tiny": (3, 5)}.get(variant, (64, 48))
+    yy, xx = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+    img = np.stack([128 + 100 * np.sin(xx / 17.0), 128 + 100 * np.cos(yy / 13.0), 60 + 1.5 * xx + 1.2 * yy], -1).clip(0, 255).astype(np.uint8)
+    if variant == "noise":  # every band and every refinement pass carries data
+        img = np.random.RandomState(5).randint(0, 256, img.shape).astype(np.uint8)
+    pil = Image.fromarray(img, "RGB").convert("L") if variant == "grey" else Image.fromarray(img, "RGB")
+    kw = dict(quality=35 if variant == "low_quality" else 92, subsampling=2 if variant in ("420", "ragged", "tiny") else 0)
+    if variant == "restart":
+        kw["restart_marker_blocks"] = 2
+    seq, pro = io.BytesIO(), io.BytesIO()
+    pil.save(seq, format="JPEG", **kw)
+    pil.save(pro, format="JPEG", progressive=True, **kw)
+    assert b"\xff\xc2" in pro.getvalue() and b"\xff\xc2" not in seq.getvalue()
+    a = _native_decode_jpeg(tmp_path, seq.getvalue(), "seq")
+    b = _native_decode_jpeg(tmp_path, pro.getvalue(), "pro")
+    assert a.shape == (h, w, 4) and a.tobytes() == b.tobytes()
+    want = np.array(Image.open(io.BytesIO(pro.getvalue())).convert("RGBA"), dtype=np.int32)
+    diff = np.abs(b.astype(np.int32) - want)
+    if variant not in ("noise", "tiny"):  # (replicated vs interpolated chroma only stays close on smooth images)
+        sub = kw["subsampling"] == 2
+        assert diff[..., :3].mean() < (3.0 if sub else 1.5) and np.percentile(diff[..., :3], 99) <= (12 if sub else 6), (diff[..., :3].mean(), diff.max())
+    elif variant == "noise":
+        assert diff[..., :3].mean() < 1.5
+
+
 def test_malformed_inputs_are_refused_not_read_out_of_bounds(tmp_path):
     """untrusted-input robustness of the C++ loader (round-1 advisor findings): every case must come back as an error through the
     C ABI — no out-of-bounds table index, no endless node walk, no undefined cast"""
