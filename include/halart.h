@@ -508,8 +508,7 @@ int hala_rt_trace_rays_host(hala_rt_renderer* r, const hala_ray* rays, hala_hit*
                             int mode, uint64_t counters[2]);
 
 /* BVH introspection for the oracle cross-check: 64-B nodes + 48-B triangles as laid out in HBM.
- * node_width 4: compressed 4-wide nodes (docs/RENDER_SPEC.md §4.1b, the default); 2: BVH2 nodes (§4.1,
- * HALART_BVH_WIDTH=2). */
+ * node_width is 4: compressed 4-wide nodes (docs/RENDER_SPEC.md §4.1b). */
 typedef struct hala_bvh_info {
   uint32_t node_count;
   uint32_t triangle_count;
