@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Mutation corpus for scripts/fuzz/run.sh: sequential + progressive JPEGs, glTF documents (byte-level and structural mutations),
+PNGs of every colour type embedded in a glTF.  usage: make_corpus.py <outdir>"""
+import base64, copy, io, json, os, sys
+import numpy as np
+from PIL import Image
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from hala_renderer_amd import scenes  # noqa: E402
+from gltf_writer import write_gltf  # noqa: E402
+
+out = sys.argv[1]
+for d in ("jpeg", "gltf", "png"):
+    os.makedirs(os.path.join(out, d), exist_ok=True)
+rs = np.random.RandomState(1)
+
+
+def mutate(base, lo):
+    b = bytearray(base)
+    for _ in range(rs.randint(1, 4)):
+        pos = rs.randint(lo, len(b)); mode = rs.randint(3)
+        if mode == 0: b[pos] = rs.randint(256)
+        elif mode == 1: b = b[:pos]
+        else: b[pos:pos] = bytes(rs.randint(0, 256, rs.randint(1, 5)).tolist())
+        if len(b) < lo + 2: break
+    return bytes(b)
+
+
+n = 0
+for variant, (w, h) in enumerate([(64, 48), (61, 37), (3, 5), (40, 40), (17, 9), (128, 16)]):
+    img = rs.randint(0, 256, (h, w, 3)).astype(np.uint8) if variant % 2 else (np.indices((h, w)).sum(0)[..., None] * np.array([1, 2, 3]) % 256).astype(np.uint8)
+    for prog in (False, True):
+        for sub in (0, 2):
+            for grey in (False, True):
+                bio = io.BytesIO(); pil = Image.fromarray(img, "RGB"); pil = pil.convert("L") if grey else pil
+                pil.save(bio, format="JPEG", quality=80, subsampling=sub, progressive=prog, **({"restart_marker_blocks": 2} if variant == 3 else {}))
+                for k in range(41):
+                    open(os.path.join(out, "jpeg", f"{n:05d}.jpg"), "wb").write(bio.getvalue() if k == 0 else mutate(bio.getvalue(), 2)); n += 1
+s = scenes.cornell_box(); scenes.attach_textures(s, sets=1, size=16)
+base = os.path.join(out, "gltf", "base.gltf")
+write_gltf(s, base)
+doc = json.load(open(base)); raw = open(base, "rb").read()
+for k in range(400):
+    b = bytearray(raw)
+    for _ in range(rs.randint(1, 4)):
+        pos = rs.randint(0, len(b)); mode = rs.randint(3)
+        if mode == 0: b[pos] = rs.randint(32, 127)
+        elif mode == 1: del b[pos:pos + rs.randint(1, 20)]
+        else: b[pos:pos] = bytes(rs.randint(32, 127, rs.randint(1, 6)).tolist())
+    open(os.path.join(out, "gltf", f"m{k:04d}.gltf"), "wb").write(b)
+
+
+def leaves(o, path=()):
+    if isinstance(o, dict):
+        for k, v in o.items(): yield from leaves(v, path + (k,))
+    elif isinstance(o, list):
+        for i, v in enumerate(o): yield from leaves(v, path + (i,))
+    else: yield path, o
+
+
+numeric = [p for p, v in leaves(doc) if isinstance(v, (int, float)) and not isinstance(v, bool)]
+hostile = [-1, 0, 1, 2**31 - 1, 2**31, 2**32 - 1, 2**32, 2**53, -2**31, 1e30, -1e30, 0.5, 1e-30, 3.5]
+for k in range(600):
+    d = copy.deepcopy(doc)
+    for _ in range(rs.randint(1, 3)):
+        p = numeric[rs.randint(len(numeric))]; o = d
+        for key in p[:-1]: o = o[key]
+        o[p[-1]] = hostile[rs.randint(len(hostile))]
+    json.dump(d, open(os.path.join(out, "gltf", f"s{k:04d}.gltf"), "w"))
+n = 0
+for mode, size, ch in (("RGB", (17, 9), 3), ("RGBA", (16, 16), 4), ("L", (5, 7), 1), ("LA", (8, 3), 2), ("P", (12, 12), 1), ("I;16", (6, 6), 1)):
+    arr = rs.randint(0, 256, (size[1], size[0], ch)).astype(np.uint8)
+    if mode == "P": im = Image.fromarray(arr[..., 0], "L").convert("P")
+    elif mode == "I;16": im = Image.fromarray(arr[..., 0].astype(np.uint16) * 257)
+    elif mode == "L": im = Image.fromarray(arr[..., 0], "L")
+    else: im = Image.fromarray(arr, mode)
+    bio = io.BytesIO(); im.save(bio, format="PNG")
+    for k in range(120):
+        b = bio.getvalue() if k == 0 else mutate(bio.getvalue(), 8)
+        d = json.loads(json.dumps(doc)); d["images"][0] = {"uri": "data:image/png;base64," + base64.b64encode(b).decode()}
+        json.dump(d, open(os.path.join(out, "png", f"p{n:04d}.gltf"), "w")); n += 1
