@@ -1137,3 +1137,42 @@ def test_large_configs_full_resolution_bit_exact(halart, oracle, config):
     assert (stg.rays_closest_total, stg.rays_shadow_total) == (st.rays_closest, st.rays_shadow)
     assert float(imgs[0][..., :3].mean()) > 0.01
     r.close()
+
+
+def render_random_scene_both(halart, oracle, seed, big=False):
+    """one random scene (tests/random_scenes.py) on the GPU and in the oracle -> number of differing pixels per image"""
+    from random_scenes import random_scene
+    s, env, kw = random_scene(seed, big)
+    r = halart.HalaRenderer("random", kw["width"], kw["height"], kw["max_depth"], kw["rr_depth"], *kw["tonemap"], 0)
+    if env is not None:
+        r.set_envmap(env, kw["env_rotation"])
+        r.set_env_intensity(kw["env_intensity"])
+    r.set_exposure_value(kw["exposure"])
+    r.set_scene(s)
+    r.commit()
+    # the frames in two uneven batches (update_batch and update are held to the same images)
+    first = kw["frames"] // 2
+    if first:
+        r.update_batch(first)
+    for _ in range(kw["frames"] - first):
+        r.update()
+    r.render()
+    osc = oracle.OracleScene(s, envmap=env)
+    imgs, st = osc.render(kw["width"], kw["height"], frames=kw["frames"], max_depth=kw["max_depth"], rr_depth=kw["rr_depth"], tonemap=kw["tonemap"],
+                          env_rotation=kw["env_rotation"] if env is not None else 0.0, env_intensity=kw["env_intensity"] if env is not None else 1.0,
+                          exposure=kw["exposure"])
+    bad = [int(np.any(r.read_image(k) != imgs[k], axis=-1).sum()) for k in range(4)]
+    stg = r.statistics()
+    rays_ok = (stg.rays_closest_total, stg.rays_shadow_total) == (st.rays_closest, st.rays_shadow)
+    lit = float(imgs[0][..., :3].mean())
+    r.close()
+    return bad, rays_ok, lit
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_random_scenes_bit_exact(halart, oracle, seed):
+    """every feature of the rendering spec drawn at random and combined (tests/random_scenes.py): all four images and the ray counts of
+    the GPU render equal the oracle's; scripts/soak_random_scenes.py runs the same comparison over hundreds of seeds"""
+    bad, rays_ok, lit = render_random_scene_both(halart, oracle, seed, big=seed % 6 == 5)
+    assert bad == [0, 0, 0, 0] and rays_ok, (seed, bad, rays_ok)
+    assert lit >= 0.0
