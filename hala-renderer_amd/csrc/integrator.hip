@@ -374,6 +374,7 @@ k_trace_shadow_then_batch(SceneView sv, const Tri* __restrict__ tris_any, Queues
       persistent_trace<true, false, STAGED, ALPHA>(sva, lds, spill, &ctl->work_shadow[kind], ctl->n_shadow[kind][depth], refill, src, sc);
     }
   }
+  if (rays == nullptr) return;  // the last bounce: its two shadow passes share the launch, no closest-hit pass follows
   const uint32_t n = ctl->n_active[depth + 1u];
   if (blockIdx.x == 0 && threadIdx.x == 0) ctl->rays_closest += n;
   BatchSource src{rays, hits, false, true, STAGED && refill == 64u};
@@ -781,11 +782,11 @@ void launch_trace_shadow(const LaunchCfg& lc, const SceneView& sv0, const Queues
 // the fused launch; false: the caller must issue the two launches separately (an LDS-staged scene whose any-hit rays traverse a
 // different triangle copy than its closest-hit rays: only one of them is staged)
 bool launch_trace_shadow_then_batch(const LaunchCfg& lc, const SceneView& sv, const Queues& q, const PathState& ps, Control* ctl, uint32_t depth,
-                                    uint32_t kinds, hipStream_t s) {
+                                    uint32_t kinds, bool with_closest, hipStream_t s) {
   if (sv.staged && sv.tris_any != sv.tris) return false;
   const size_t smem = traverse_smem(sv);
   const dim3 grid(lc.persistent_blocks), block(kTraverseThreads);
-  const hala_ray* rays = q.rays[(depth + 1u) & 1u];
+  const hala_ray* rays = with_closest ? q.rays[(depth + 1u) & 1u] : nullptr;
   if (sv.staged) {
     if (sv.any_translucent) hipLaunchKernelGGL((k_trace_shadow_then_batch<true, true>), grid, block, smem, s, sv, sv.tris_any, q, ps, ctl, depth, kinds, rays, q.hits, lc.spill, lc.refill);
     else hipLaunchKernelGGL((k_trace_shadow_then_batch<true, false>), grid, block, smem, s, sv, sv.tris_any, q, ps, ctl, depth, kinds, rays, q.hits, lc.spill, lc.refill);

@@ -26,7 +26,7 @@ void launch_trace_shadow(const LaunchCfg& lc, const SceneView& sv, const Queues&
                          uint32_t kind /* 0 light, 1 environment */, bool count, hipStream_t s);
 // the last shadow pass of bounce `depth` and the closest-hit traversal of bounce depth + 1 as ONE persistent launch (false: not fusable)
 bool launch_trace_shadow_then_batch(const LaunchCfg& lc, const SceneView& sv, const Queues& q, const PathState& ps, Control* ctl, uint32_t depth,
-                                    uint32_t kinds /* bit 0 light, bit 1 environment connections */, hipStream_t s);
+                                    uint32_t kinds /* bit 0 light, bit 1 environment connections */, bool with_closest, hipStream_t s);
 void launch_trace_primary(const LaunchCfg& lc, const SceneView& sv, const FrameConst& fc, hala_hit* hits, WorkCounters* work, Control* ctl,
                           uint32_t n_account /* real paths among fc.slot_count */, bool count, hipStream_t s);
 void launch_shade(const FrameConst& fc, const SceneView& sv, const Queues& q, const PathState& ps, Control* ctl, uint32_t depth, hipStream_t s);

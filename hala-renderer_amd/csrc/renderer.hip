@@ -829,7 +829,8 @@ static int update_impl(hala_rt_renderer* r, uint32_t frames) {
     // light connections add to the path's L, environment connections to its Le (RENDER_SPEC §6): the two passes are independent of each
     // other and of the next bounce's closest-hit pass
     const uint32_t kinds = (u.num_of_lights > 0 ? 1u : 0u) | (u.env_type == 1u ? 2u : 0u);
-    if (fuse && kinds && depth + 1u < r->max_depth && launch_trace_shadow_then_batch(r->lcfg, sv, q, ps, ctl, depth, kinds, s)) traced = true;
+    const bool last = depth + 1u >= r->max_depth;  // no closest-hit pass follows: only worth one launch when there are two shadow passes
+    if (fuse && kinds && (!last || kinds == 3u) && launch_trace_shadow_then_batch(r->lcfg, sv, q, ps, ctl, depth, kinds, !last, s)) traced = !last;
     else
       for (uint32_t kind = 0; kind < 2u; ++kind) {
         if (!((kinds >> kind) & 1u)) continue;
