@@ -285,7 +285,7 @@ def main():
                         "come from one extra frame with the counting kernels in this run; avg_launch_ms from HIP events on the renderer's stream around "
                         "every launch of every `timing_period`-th frame of the timed region (`launches` = the launches so measured; "
                         "profiles/r02_*_kernel_stats_bench.csv holds the rocprofv3 average of the same command). The tree "
-                        "(16 MB of nodes + 48 MB of triangles) sits in L2 / Infinity Cache, so `traffic` (fabric bytes by PMC) is far below the algorithmic bytes: "
+                        f"({info.node_count * 64 / 1e6:.0f} MB of nodes + {info.triangle_count * 48 / 1e6:.0f} MB of triangles) sits in L2 / Infinity Cache, so `traffic` (fabric bytes by PMC) is far below the algorithmic bytes: "
                         "frac prices useful work against the HBM peak, traffic_frac_of_peak is what the memory side really carries; the kernels are "
                         "VALU-issue bound (`simt`: active lanes per wave on the two code paths).",
                 "bytes_per_ray": b["bytes_per_ray"], "nodes_per_ray": b["nodes_per_ray"], "tris_per_ray": b["tris_per_ray"],
