@@ -71,6 +71,10 @@ std::string HostScene::assign(const hala_scene_desc* d) {
       hp.vertices.assign(pd.vertices, pd.vertices + pd.vertex_count);
       hp.indices.assign(pd.indices, pd.indices + pd.index_count);
       for (uint32_t idx : hp.indices) if (idx >= pd.vertex_count) return "Primitive index out of range.";
+      // Vulkan makes a triangle with a non-finite position inactive; here it would poison the scene bounds every box is quantised
+      // against (and the SAH costs of the build): refused, like the other inputs the reference would pass to the driver unchecked
+      for (const hala_vertex& v : hp.vertices)
+        if (!std::isfinite(v.position[0]) || !std::isfinite(v.position[1]) || !std::isfinite(v.position[2])) return "Vertex position is not finite.";
       hp.material_index = pd.material_index;
       // primitives without a material carry u32::MAX and the reference passes it through unchecked
       // (gltf_loader.rs:298, gpu_uploader.rs:868); a device-side out-of-bounds read is not acceptable here.

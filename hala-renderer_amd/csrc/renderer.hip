@@ -1273,6 +1273,8 @@ int hala_rt_update_vertices(hala_rt_renderer* r, uint32_t mesh_index, uint32_t p
   if (primitive_index >= end - first) RT_FAIL("The primitive does not exist.");
   HostPrimitive& p = r->hs.prims[first + primitive_index];
   if (vertex_count != p.vertices.size()) RT_FAIL("The vertex count differs from the primitive's (" + std::to_string(p.vertices.size()) + "): refit keeps the topology, use set_scene + commit.");
+  for (uint32_t k = 0; k < vertex_count; ++k)
+    if (!std::isfinite(vertices[k].position[0]) || !std::isfinite(vertices[k].position[1]) || !std::isfinite(vertices[k].position[2])) RT_FAIL("Vertex position is not finite.");
   memcpy(p.vertices.data(), vertices, (size_t)vertex_count * sizeof(hala_vertex));
   // the copy below reads the renderer's own host copy, which outlives it; earlier frames still read the arena: wait for them
   RT_HIP(hipStreamSynchronize(r->stream));

@@ -120,6 +120,10 @@ def test_error_behaviour(halart):
         r.set_scene(s)
     with pytest.raises(halart.HalaRendererError):
         halart.HalaRenderer("zero", 0, 16, 2, 1, False, False, False, 0)
+    bad = scenes.cornell_box()
+    bad.meshes[0].primitives[0].vertices["position"][1, 2] = np.nan  # would poison the scene bounds of the BVH build
+    with pytest.raises(halart.HalaRendererError, match="not finite"):
+        r.set_scene(bad)
     r.close()
 
 
