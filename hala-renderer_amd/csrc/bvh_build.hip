@@ -1228,36 +1228,38 @@ std::string bvh_build(BvhBuffers& b, uint32_t leaf_max, hipStream_t s) {
   if (leaf_max > 8u || n >= (1u << 28)) return "bvh_build: the 4-wide node format holds leaves of <= 8 triangles and < 2^28 triangles";
   if (!(e = flatten_and_bounds(b, t, s)).empty()) return e;
   if (n >= 2) {
-    DevBuf keys_in, keys_out, ids_in, tmp;
-    if (!(e = keys_in.alloc((size_t)n * 8)).empty()) return e;
-    if (!(e = keys_out.alloc((size_t)n * 8)).empty()) return e;
-    if (!(e = ids_in.alloc((size_t)n * 4)).empty()) return e;
-    uint32_t size_classes = 1;
-    if (const char* ev = getenv("HALART_SIZE_CLASSES")) size_classes = (uint32_t)atoi(ev);  // tuning knob
-    hipLaunchKernelGGL(k_morton, dim3(nblk(n)), dim3(256), 0, s, t.tri_box.as<Box6>(), n, t.scene_ord.as<uint32_t>(),
-                       keys_in.as<unsigned long long>(), ids_in.as<uint32_t>(), size_classes);
-    size_t tmp_bytes = 0;
-    HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in.as<unsigned long long>(), keys_out.as<unsigned long long>(),
-                                      ids_in.as<uint32_t>(), t.sorted_ids.as<uint32_t>(), n, 0, 64, s));
-    if (!(e = tmp.alloc(tmp_bytes)).empty()) return e;
-    HIP_TRY(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, keys_in.as<unsigned long long>(), keys_out.as<unsigned long long>(),
-                                      ids_in.as<uint32_t>(), t.sorted_ids.as<uint32_t>(), n, 0, 64, s));
     // hierarchy over the triangles: full-sweep SAH rounds for scenes large enough to repay them (1 M triangles: 34 ms of build instead
     // of PLOC's 11 ms for 10-15 % fewer node visits per closest-hit ray, profiles/r02_experiments.txt), Karras' LBVH over the Morton
     // order otherwise; PLOC (nearest-neighbour clustering along the Morton order) stays selectable as the fast large-scene build
     const char* builder = getenv("HALART_BUILDER");  // "sah" | "ploc" | "lbvh": A/B knob
     const bool sah = builder ? !strcmp(builder, "sah") : n >= 4096u;
     const bool ploc = builder && !strcmp(builder, "ploc");
-    if (sah) {
+    if (sah) {  // (needs no Morton order)
       if (!(e = sah_hierarchy(b, t, s)).empty()) return e;
       t.fitted = true;
-    } else if (ploc) {
-      if (!(e = ploc_hierarchy(b, t, s)).empty()) return e;
-      t.fitted = true;
-    } else
-      hipLaunchKernelGGL(k_hierarchy, dim3(nblk(n - 1)), dim3(256), 0, s, keys_out.as<unsigned long long>(), (int)n, t.left.as<uint32_t>(),
-                         t.right.as<uint32_t>(), t.first.as<uint32_t>(), t.last.as<uint32_t>(), t.node_parent.as<uint32_t>(),
-                         t.leaf_parent.as<uint32_t>());
+    } else {
+      DevBuf keys_in, keys_out, ids_in, tmp;
+      if (!(e = keys_in.alloc((size_t)n * 8)).empty()) return e;
+      if (!(e = keys_out.alloc((size_t)n * 8)).empty()) return e;
+      if (!(e = ids_in.alloc((size_t)n * 4)).empty()) return e;
+      uint32_t size_classes = 1;
+      if (const char* ev = getenv("HALART_SIZE_CLASSES")) size_classes = (uint32_t)atoi(ev);  // tuning knob
+      hipLaunchKernelGGL(k_morton, dim3(nblk(n)), dim3(256), 0, s, t.tri_box.as<Box6>(), n, t.scene_ord.as<uint32_t>(),
+                         keys_in.as<unsigned long long>(), ids_in.as<uint32_t>(), size_classes);
+      size_t tmp_bytes = 0;
+      HIP_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_in.as<unsigned long long>(), keys_out.as<unsigned long long>(),
+                                        ids_in.as<uint32_t>(), t.sorted_ids.as<uint32_t>(), n, 0, 64, s));
+      if (!(e = tmp.alloc(tmp_bytes)).empty()) return e;
+      HIP_TRY(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, keys_in.as<unsigned long long>(), keys_out.as<unsigned long long>(),
+                                        ids_in.as<uint32_t>(), t.sorted_ids.as<uint32_t>(), n, 0, 64, s));
+      if (ploc) {
+        if (!(e = ploc_hierarchy(b, t, s)).empty()) return e;
+        t.fitted = true;
+      } else
+        hipLaunchKernelGGL(k_hierarchy, dim3(nblk(n - 1)), dim3(256), 0, s, keys_out.as<unsigned long long>(), (int)n, t.left.as<uint32_t>(),
+                           t.right.as<uint32_t>(), t.first.as<uint32_t>(), t.last.as<uint32_t>(), t.node_parent.as<uint32_t>(),
+                           t.leaf_parent.as<uint32_t>());
+    }
     hipLaunchKernelGGL(k_keep_flags, dim3(nblk(n - 1)), dim3(256), 0, s, t.first.as<uint32_t>(), t.last.as<uint32_t>(), n - 1, leaf_max,
                        t.keep.as<uint32_t>());
   } else if (n == 1) {
