@@ -489,6 +489,7 @@ int configure_traversal(hala_rt_renderer* r) {
   uint32_t per_cu = traverse_blocks_per_cu(smem, r->staged);
   if (per_cu == 0) RT_FAIL("The traversal kernel does not fit on a compute unit with the requested LDS staging.");
   per_cu = std::min(per_cu, 8u);
+  if (const char* e = getenv("HALART_BLOCKS_PER_CU")) per_cu = std::min(per_cu, std::max(1u, (uint32_t)atoi(e)));  // tuning knob
   r->lcfg.persistent_blocks = r->cu_count * per_cu;
   r->lcfg.spill = nullptr;
   // measured (profiles/r01_c_refill_sweep.txt): whole-wave refills are best when the BVH lives in LDS (uniform, cheap rays);
