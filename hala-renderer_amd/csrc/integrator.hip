@@ -34,10 +34,17 @@ RT_DI uint32_t wave_sum(uint32_t v) {
 // Block-level compaction of up to two predicates at once: one atomic per workgroup and counter instead of one per
 // wave (a single counter word takes ~88 atomics/us; a 2 M-path launch of 64-lane waves would need 32 K of them).
 // All threads of the block must call it.  Returns this lane's output index for each predicate.
+// Workgroup size of k_shade: 512 for the SIMPLE variant, 256 for the generic one (configs[3]: 512 / 256 threads = 3.33 / 3.21 ms of shade
+// per frame — fewer waves behind every barrier of the kind sort and of the compaction — while the Cornell box loses 25 % at 256:
+// profiles/r02_experiments.txt).  kShadeThreads sizes the shared arrays.
 #ifndef RT_SHADE_THREADS
 #define RT_SHADE_THREADS 512
 #endif
+#ifndef RT_SHADE_THREADS_GENERIC
+#define RT_SHADE_THREADS_GENERIC 256
+#endif
 constexpr int kShadeThreads = RT_SHADE_THREADS;
+constexpr int kShadeThreadsGeneric = RT_SHADE_THREADS_GENERIC < RT_SHADE_THREADS ? RT_SHADE_THREADS_GENERIC : RT_SHADE_THREADS;
 struct BlockCompact {
   uint32_t cnt[3][kShadeThreads / 64];
   uint32_t base[3];
@@ -394,7 +401,7 @@ k_trace_shadow_then_batch(SceneView sv, const Tri* __restrict__ tris_any, Queues
 #endif
 // SCATTER: some material holds a scattering medium (§7.1f): only then does the kernel carry the free-flight / phase-function code
 template <bool PRIMARY, bool SIMPLE, bool SCATTER>
-__global__ void __launch_bounds__(kShadeThreads, SIMPLE ? RT_SHADE_WAVES_SIMPLE : RT_SHADE_WAVES) k_shade(FrameConst fc, SceneView sv, Queues q, PathState ps, Control* __restrict__ ctl, uint32_t depth) {
+__global__ void __launch_bounds__(SIMPLE ? kShadeThreads : kShadeThreadsGeneric, SIMPLE ? RT_SHADE_WAVES_SIMPLE : RT_SHADE_WAVES) k_shade(FrameConst fc, SceneView sv, Queues q, PathState ps, Control* __restrict__ ctl, uint32_t depth) {
   __shared__ BlockCompact s_compact;
   const uint32_t n = PRIMARY ? fc.slot_count : ctl->n_active[depth];
   // the traversal of this bounce is over and the next users (shadow pass of this bounce, closest-hit pass of the next)
@@ -411,14 +418,14 @@ __global__ void __launch_bounds__(kShadeThreads, SIMPLE ? RT_SHADE_WAVES_SIMPLE 
   __shared__ float s_tex_lut[SIMPLE ? 1 : kTexLutEntries];
   const RT_LDS float* lut = (const RT_LDS float*)s_tex_lut;
   if (!SIMPLE && sv.texture_count) {
-    for (uint32_t k = threadIdx.x; k < kTexLutEntries; k += kShadeThreads) s_tex_lut[k] = sv.tex_lut[k];
+    for (uint32_t k = threadIdx.x; k < kTexLutEntries; k += blockDim.x) s_tex_lut[k] = sv.tex_lut[k];
     __syncthreads();
   }
 #ifndef RT_SHADE_NOSORT
   if (!PRIMARY && sv.shade_sort) {
     // Bounce paths arrive in no particular order and the BSDF code is a forest of branches (miss / diffuse / Disney / glass /
     // textured ...): a wave ran its VALU instructions at 21 of 64 lanes on the 1 M-triangle scene (profiles/r02_a_pmc_config4.txt).
-    // Regroup the workgroup's 512 paths by shading kind first (counting sort through LDS: 9 ballots, one pass): a wave then
+    // Regroup the workgroup's paths by shading kind first (counting sort through LDS: 9 ballots, one pass): a wave then
     // shades (mostly) one kind.  Which lane shades which path is not observable: every output is indexed by path slot or comes
     // out of the block compaction below.
     __shared__ uint16_t s_perm[kShadeThreads];
@@ -441,7 +448,7 @@ __global__ void __launch_bounds__(kShadeThreads, SIMPLE ? RT_SHADE_WAVES_SIMPLE 
     if (threadIdx.x == 0u) {  // exclusive prefix in (kind, wave) order: 72 serial adds
       uint32_t run = 0;
       for (uint32_t b = 0; b < kShadeKinds; ++b)
-        for (uint32_t j = 0; j < kShadeThreads / 64; ++j) { const uint32_t c = s_bin[b][j]; s_bin[b][j] = run; run += c; }
+        for (uint32_t j = 0; j < (blockDim.x >> 6); ++j) { const uint32_t c = s_bin[b][j]; s_bin[b][j] = run; run += c; }
     }
     __syncthreads();
     s_perm[s_bin[kind][w] + rank] = (uint16_t)threadIdx.x;
@@ -810,7 +817,8 @@ void launch_trace_primary(const LaunchCfg& lc, const SceneView& sv, const FrameC
   }
 }
 void launch_shade(const FrameConst& fc, const SceneView& sv, const Queues& q, const PathState& ps, Control* ctl, uint32_t depth, hipStream_t s) {
-  const dim3 grid(blocks_for(fc.slot_count, kShadeThreads)), block(kShadeThreads);
+  const uint32_t threads = sv.simple_materials ? (uint32_t)kShadeThreads : (uint32_t)kShadeThreadsGeneric;
+  const dim3 grid(blocks_for(fc.slot_count, threads)), block(threads);
   if (sv.simple_materials) {
     if (depth == 0u) hipLaunchKernelGGL((k_shade<true, true, false>), grid, block, 0, s, fc, sv, q, ps, ctl, depth);
     else hipLaunchKernelGGL((k_shade<false, true, false>), grid, block, 0, s, fc, sv, q, ps, ctl, depth);
