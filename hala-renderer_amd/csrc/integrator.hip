@@ -256,18 +256,22 @@ struct CameraSource {
     else reinterpret_cast<float4*>(hits)[i] = out;
   }
 };
+#ifndef RT_SHADOW_PREFETCH
+#define RT_SHADOW_PREFETCH 1  // large scenes too: 84 of the 102 VGPRs of 5 waves per SIMD are in use, the three words fit (shadow 4.06 -> 3.99 ms, configs[3])
+#endif
 template <bool PREFETCH, bool ALPHA>
 struct ShadowSource {
   // contribution.xyz | pixel slot, fetched with the ray (one coalesced 48-B record), and the path's radiance as it stands
   struct Payload { float4 cs; float lx, ly, lz; };
   const ShadowEntry* entries;
   P3* radiance;
-  // A path owns at most one connection per queue and the two queues are traced by separate launches, so nothing else touches this
+  // A path owns at most one connection per queue and the two queues add to different arrays, so nothing else touches this word of the
   // path's radiance during the launch: it is fetched here, behind the entry (the load is in flight while the ray is traced), and
   // an unoccluded ray stores radiance + contribution — one IEEE add per component, no ordering freedom.  (Three memory-side float
   // atomics per unoccluded ray did the same and cost 57 of the launch's 160 us on the headline config: profiles/r01_h_experiments.txt.)
-  // PREFETCH = false (the 6-waves-per-SIMD kernels of large scenes, where three more live registers spill): the add is done by
-  // fire-and-forget float atomics instead — at most one per radiance word per launch, so exactly the same single IEEE add.
+  // PREFETCH = false (kept for register-starved variants): the add is done by fire-and-forget float atomics instead — at most one per
+  // radiance word per launch, so exactly the same single IEEE add.  (The two connection kinds of a bounce share a launch but not an
+  // array: light connections add to L, environment connections to Le.)
   RT_DI bool load(uint32_t i, f3* o, f3* d, float* tmin, float* tmax, uint32_t* key, Payload* p) const {
     const float4* e = reinterpret_cast<const float4*>(entries + i);
     const float4 ro = e[0], rd = e[1];
@@ -351,7 +355,7 @@ k_trace_shadow(SceneView sv, Queues q, PathState ps, Control* __restrict__ ctl, 
   const uint32_t n = ctl->n_shadow[kind][depth];
   uint2* spill = spill_base ? spill_base + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * kStackSpill : nullptr;
   StepCounters sc;
-  ShadowSource<STAGED, ALPHA> src{q.shadow[kind], kind ? ps.radiance_env : ps.radiance};
+  ShadowSource<(STAGED || RT_SHADOW_PREFETCH), ALPHA> src{q.shadow[kind], kind ? ps.radiance_env : ps.radiance};
   persistent_trace<true, COUNT, STAGED, ALPHA>(sv, lds, spill, &ctl->work_shadow[kind], n, refill, src, sc);
   if (COUNT) flush_counters(ctl, 1, sc);
 }
@@ -377,7 +381,7 @@ k_trace_shadow_then_batch(SceneView sv, const Tri* __restrict__ tris_any, Queues
     sva.tris = tris_any;  // RENDER_SPEC 7.1d (STAGED: the launcher only fuses when both passes traverse the same triangles)
     for (uint32_t kind = 0; kind < 2u; ++kind) {  // bit 0: light connections, bit 1: environment connections
       if (!((kinds >> kind) & 1u)) continue;
-      ShadowSource<STAGED, ALPHA> src{q.shadow[kind], kind ? ps.radiance_env : ps.radiance};
+      ShadowSource<(STAGED || RT_SHADOW_PREFETCH), ALPHA> src{q.shadow[kind], kind ? ps.radiance_env : ps.radiance};
       persistent_trace<true, false, STAGED, ALPHA>(sva, lds, spill, &ctl->work_shadow[kind], ctl->n_shadow[kind][depth], refill, src, sc);
     }
   }
