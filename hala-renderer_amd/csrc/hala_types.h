@@ -151,6 +151,13 @@ inline uint8_t any_class_of(const hala_gpu_material& m, bool base_map_has_alpha)
 }
 constexpr uint32_t kAnyKeyLight = 0xA511E9B3u, kAnyKeyEnv = 0x63D83595u, kAnyKeyBatch = 0x5BD1E995u;
 
+// Unsharded frames deal the pixels to path slots in 8 x 8 blocks (one block = the 64 lanes of a wave): camera rays of a square patch
+// share far more of the tree (and of the textures at their hits) than those of a 64 x 1 strip.  Which slot renders which pixel is not
+// observable (the RNG is keyed by the pixel id, images are written by pixel).
+#ifndef RT_PIXEL_BLOCK
+#define RT_PIXEL_BLOCK 8
+#endif
+constexpr uint32_t kPixelBlock = RT_PIXEL_BLOCK;  // 8: 64 pixels per block; 0: row-major slots (A/B)
 // per-update constants derived on the host from HalaGlobalUniform + camera 0 (RENDER_SPEC §5)
 struct FrameConst {
   hala_global_uniform u;  // the 112-B record itself (src/rt_renderer.rs:408-427)
@@ -159,6 +166,7 @@ struct FrameConst {
   uint32_t width, height;
   // pixel-tile sharding (RENDER_SPEC §9)
   uint32_t tile_size, tiles_x, tiles_y, world, rank, tiles_per_rank, perm_a, perm_b;
+  uint32_t blocks_x;     // world == 1: pixel blocks (kPixelBlock x kPixelBlock, one per wave) per row of blocks
   uint32_t pixel_slots;  // number of pixel slots this rank renders
   // sample batching: `samples` consecutive frames (frame_index .. frame_index+samples-1) travel through the wavefront
   // together; path slot = sample * pixel_slots + pixel slot.  The resolve kernel folds them in frame order, so the

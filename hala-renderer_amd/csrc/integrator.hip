@@ -685,9 +685,17 @@ __global__ void __launch_bounds__(256) k_resolve(FrameConst fc, PathState ps, fl
                                                   float4* __restrict__ normal, float4* __restrict__ final_img) {
   const uint32_t pslot = blockIdx.x * blockDim.x + threadIdx.x;
   if (pslot >= fc.pixel_slots) return;
+  // where the pixel of this slot lives in the images: sharded ranks keep their tile buffers in slot order (RENDER_SPEC §9), an unsharded
+  // frame is row-major whatever the slot order
+  uint32_t at = pslot;
+  if (fc.world <= 1u) {
+    uint32_t px, py;
+    if (!slot_to_pixel(fc, pslot, &px, &py)) return;  // padding slot of a border block
+    at = py * fc.width + px;
+  }
   // the running means; a batch that starts an accumulation (frame_index 0) never looks at them (fold_mean)
   float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f), b = a, n = a;
-  if (fc.u.frame_index != 0u) { a = accum[pslot]; b = albedo[pslot]; n = normal[pslot]; }
+  if (fc.u.frame_index != 0u) { a = accum[at]; b = albedo[at]; n = normal[at]; }
   for (uint32_t k = 0; k < fc.samples; ++k) {  // the batch's samples, folded in frame order
     const uint32_t slot = k * fc.pixel_slots + pslot;
     const P3 lr = ps.radiance[slot];
@@ -700,9 +708,9 @@ __global__ void __launch_bounds__(256) k_resolve(FrameConst fc, PathState ps, fl
     b = make_float4(fold_mean(b.x, sa.x, fi), fold_mean(b.y, sa.y, fi), fold_mean(b.z, sa.z, fi), 1.0f);
     n = make_float4(fold_mean(n.x, sn.x, fi), fold_mean(n.y, sn.y, fi), fold_mean(n.z, sn.z, fi), 1.0f);
   }
-  accum[pslot] = a; albedo[pslot] = b; normal[pslot] = n;
+  accum[at] = a; albedo[at] = b; normal[at] = n;
   const f3 c = tonemap_select(mk3(a.x, a.y, a.z) * fc.u.exposure_value, fc.u.enable_tonemap, fc.u.enable_aces, fc.u.use_simple_aces);
-  final_img[pslot] = make_float4(c.x, c.y, c.z, 1.0f);
+  final_img[at] = make_float4(c.x, c.y, c.z, 1.0f);
 }
 
 // stand-alone texture fetch (tests): uvl = (u, v, lod) per sample

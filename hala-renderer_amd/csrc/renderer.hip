@@ -152,6 +152,9 @@ struct hala_rt_renderer {
   uint32_t real_pixels = 0;  // pixels among the rank's slot_count slots that exist in the frame
   uint32_t rank = 0, world = 1, tile_size = 32, tiles_x = 0, tiles_y = 0, tiles_per_rank = 0, perm_a_inv = 0, perm_b = 7;
   uint32_t slot_count = 0;      // pixel slots of this rank
+  uint32_t blocks_x = 0;        // world == 1: 8 x 8 pixel blocks per row of blocks (hala_types.h: kPixelBlock)
+  // pixels of this rank's image buffers: its tile slots when sharded, the row-major frame otherwise (whose path slots may hold padding)
+  size_t image_pixels() const { return world <= 1 ? (size_t)width * height : (size_t)slot_count; }
   uint32_t batch_capacity = 1;  // samples the wavefront buffers can hold in flight (hala_rt_update_batch)
 
   DeviceArray<float4> img_local[4];  // accum, albedo, normal, final (slot order)
@@ -246,7 +249,7 @@ struct hala_rt_renderer {
     fc.tan_half = sn / cs;
     fc.pixel_spread = 2.0f * fc.tan_half / u.resolution[1];
     fc.width = width; fc.height = height;
-    fc.tile_size = tile_size; fc.tiles_x = tiles_x; fc.tiles_y = tiles_y; fc.world = world; fc.rank = rank;
+    fc.tile_size = tile_size; fc.tiles_x = tiles_x; fc.tiles_y = tiles_y; fc.world = world; fc.rank = rank; fc.blocks_x = blocks_x;
     fc.tiles_per_rank = tiles_per_rank; fc.perm_a = perm_a_inv; fc.perm_b = perm_b;
     fc.pixel_slots = slot_count; fc.samples = samples; fc.slot_count = slot_count * samples;
     return fc;
@@ -319,8 +322,13 @@ int ensure_device(hala_rt_renderer* r) {
 
 void compute_tiling(hala_rt_renderer* r) {
   if (r->world <= 1) {
-    r->slot_count = r->width * r->height;
-    r->real_pixels = r->slot_count;
+    r->real_pixels = r->width * r->height;
+    r->slot_count = r->real_pixels;
+    r->blocks_x = 0;
+    if (kPixelBlock) {  // whole blocks: the border blocks of a frame that is not a multiple of the block size hold padding slots
+      r->blocks_x = (r->width + kPixelBlock - 1) / kPixelBlock;
+      r->slot_count = r->blocks_x * ((r->height + kPixelBlock - 1) / kPixelBlock) * kPixelBlock * kPixelBlock;
+    }
     r->tiles_x = r->tiles_y = r->tiles_per_rank = 0;
     return;
   }
@@ -1053,7 +1061,7 @@ int hala_rt_set_tile_shard(hala_rt_renderer* r, uint32_t rank, uint32_t world, u
 int hala_rt_tile_buffer(hala_rt_renderer* r, int which, void** d_ptr, size_t* bytes) {
   if (!r || which < 0 || which > 3 || !d_ptr || !bytes) RT_FAIL("Invalid argument.");
   *d_ptr = r->img_local[which].ptr;
-  *bytes = (size_t)r->slot_count * sizeof(float4);
+  *bytes = r->image_pixels() * sizeof(float4);
   return HALA_OK;
 }
 int hala_rt_get_stream(hala_rt_renderer* r, void** hip_stream) {
@@ -1066,7 +1074,7 @@ int hala_rt_scatter_gathered_tiles_on_stream(hala_rt_renderer* r, int which, con
   if (ensure_device(r) != HALA_OK) return HALA_ERR;
   if (which < 0 || which > 3 || !d_gathered) RT_FAIL("Invalid argument.");
   if (r->world <= 1) RT_FAIL("The renderer is not sharded.");
-  if (bytes != (size_t)r->slot_count * r->world * sizeof(float4)) RT_FAIL("The gathered buffer has the wrong size.");
+  if (bytes != r->image_pixels() * r->world * sizeof(float4)) RT_FAIL("The gathered buffer has the wrong size.");
   RT_HIP(r->img_full[which].resize((size_t)r->width * r->height));
   hala_global_uniform u = r->last_uniform;
   const FrameConst fc = r->frame_const(u);
@@ -1143,7 +1151,7 @@ int hala_rt_tile_allgather_begin(hala_rt_renderer* r, uint32_t aov_mask) {
   if (!r->comm) RT_FAIL("The renderer has no communicator: call hala_rt_comm_init_rank or hala_rt_comm_attach first.");
   if (aov_mask == 0u || aov_mask > 15u) RT_FAIL("Invalid AOV mask.");
   if (hala_rt_tile_allgather_finish(r) != HALA_OK) return HALA_ERR;
-  const size_t n = r->slot_count;
+  const size_t n = r->image_pixels();
   hipStream_t g = r->gather_stream;
   RT_HIP(hipEventRecord(r->ev_rendered, r->stream));
   RT_HIP(hipStreamWaitEvent(g, r->ev_rendered, 0));

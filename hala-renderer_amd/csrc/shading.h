@@ -12,12 +12,21 @@
 namespace rt {
 
 // ---- §9 pixel slots -------------------------------------------------------------------------------------
-// world == 1: slot == pixel id (row-major).  world > 1: tile-major slots of this rank's tiles.
+// world == 1: slots in 8 x 8 pixel blocks, row-major over the blocks (hala_types.h: kPixelBlock).  world > 1: tile-major slots of this rank's tiles.
 RT_DI bool slot_to_pixel(const FrameConst& fc, uint32_t slot, uint32_t* px, uint32_t* py) {
   if (fc.world <= 1u) {
-    *py = slot / fc.width;
-    *px = slot - *py * fc.width;
-    return true;
+    if (kPixelBlock == 0u) {
+      *py = slot / fc.width;
+      *px = slot - *py * fc.width;
+      return true;
+    }
+    constexpr uint32_t kB = kPixelBlock ? kPixelBlock : 1u, kB2 = kB * kB;
+    const uint32_t blk = slot / kB2, within = slot - blk * kB2;
+    const uint32_t ly = within / kB, lx = within - ly * kB;
+    const uint32_t by = blk / fc.blocks_x, bx = blk - by * fc.blocks_x;
+    *px = bx * kB + lx;
+    *py = by * kB + ly;
+    return *px < fc.width && *py < fc.height;  // false: padding slot of a border block
   }
   const uint32_t ts2 = fc.tile_size * fc.tile_size;
   const uint32_t lt = slot / ts2, within = slot - lt * ts2;
