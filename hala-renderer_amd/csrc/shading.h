@@ -30,7 +30,14 @@ RT_DI bool slot_to_pixel(const FrameConst& fc, uint32_t slot, uint32_t* px, uint
   }
   const uint32_t ts2 = fc.tile_size * fc.tile_size;
   const uint32_t lt = slot / ts2, within = slot - lt * ts2;
-  const uint32_t ly = within / fc.tile_size, lx = within - ly * fc.tile_size;
+  uint32_t ly, lx;
+  if (kPixelBlock && fc.tile_size % kPixelBlock == 0u) {  // RENDER_SPEC §9: 8 x 8 pixel blocks inside the tile, row-major over the blocks
+    constexpr uint32_t kB = kPixelBlock ? kPixelBlock : 1u, kB2 = kB * kB;
+    const uint32_t per_row = fc.tile_size / kB;
+    const uint32_t blk = within / kB2, j = within - blk * kB2;
+    const uint32_t by = blk / per_row, bx = blk - by * per_row;
+    ly = by * kB + j / kB; lx = bx * kB + (j - (j / kB) * kB);
+  } else { ly = within / fc.tile_size; lx = within - ly * fc.tile_size; }
   const uint32_t n = fc.tiles_x * fc.tiles_y;
   const uint32_t k = lt * fc.world + fc.rank;  // position in the dealing order
   if (k >= n) return false;                    // padding tile

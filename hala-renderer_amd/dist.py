@@ -12,7 +12,8 @@ import numpy as np
 
 class TileLayout:
     """tile t (row-major over the tile grid) sits at position k = (t*A + B) mod n of the dealing order; rank k % world
-    owns it and stores it as its (k // world)-th tile; A = first integer >= 0x9E3779B1 % n coprime to n, B = 7."""
+    owns it and stores it as its (k // world)-th tile; A = first integer >= 0x9E3779B1 % n coprime to n, B = 7.  Inside a tile whose
+    size is a multiple of 8 the pixels are stored in 8 x 8 blocks (row-major over the blocks, row-major inside), else row-major."""
 
     def __init__(self, width, height, world, tile_size=32):
         self.width, self.height, self.world, self.tile_size = width, height, world, tile_size
@@ -37,7 +38,12 @@ class TileLayout:
         """for every local pixel slot of `rank`: (py, px) or (-1, -1) for padding / out-of-frame slots"""
         ts = self.tile_size
         out = np.full((self.pixels_per_rank, 2), -1, dtype=np.int64)
-        ly, lx = np.meshgrid(np.arange(ts), np.arange(ts), indexing="ij")
+        if ts % 8 == 0:  # RENDER_SPEC §9: inside a tile the pixels come in 8 x 8 blocks (one block = one wave), row-major over the blocks
+            w = np.arange(ts * ts)
+            blk, j = w // 64, w % 64
+            ly, lx = (blk // (ts // 8)) * 8 + j // 8, (blk % (ts // 8)) * 8 + j % 8
+        else:
+            ly, lx = np.meshgrid(np.arange(ts), np.arange(ts), indexing="ij")
         for t in np.nonzero(self.owner == rank)[0]:
             ty, tx = divmod(int(t), self.tiles_x)
             py = ty * ts + ly.reshape(-1)
