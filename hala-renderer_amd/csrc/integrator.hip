@@ -819,13 +819,16 @@ bool launch_trace_shadow_then_batch(const LaunchCfg& lc, const SceneView& sv, co
 void launch_trace_primary(const LaunchCfg& lc, const SceneView& sv, const FrameConst& fc, hala_hit* hits, WorkCounters* work, Control* ctl,
                           uint32_t n_account, bool count, hipStream_t s) {
   const size_t smem = traverse_smem(sv);
+  static const uint32_t refill_env = getenv("HALART_REFILL_PRIMARY") ? (uint32_t)atoi(getenv("HALART_REFILL_PRIMARY")) : 0u;  // A/B knob
+  // camera rays of neighbouring pixels are about equally long: larger refills (40 idle lanes instead of 24) keep the 8 x 8 pixel blocks together
+  const uint32_t refill = refill_env ? refill_env : (sv.staged ? lc.refill : std::max(lc.refill, 40u));
   dim3 grid(lc.persistent_blocks), block(kTraverseThreads);
   if (sv.staged) {
-    if (count) hipLaunchKernelGGL((k_trace_primary<true, true>), grid, block, smem, s, sv, fc, hits, work, lc.spill, ctl, n_account, lc.refill);
-    else hipLaunchKernelGGL((k_trace_primary<false, true>), grid, block, smem, s, sv, fc, hits, work, lc.spill, ctl, n_account, lc.refill);
+    if (count) hipLaunchKernelGGL((k_trace_primary<true, true>), grid, block, smem, s, sv, fc, hits, work, lc.spill, ctl, n_account, refill);
+    else hipLaunchKernelGGL((k_trace_primary<false, true>), grid, block, smem, s, sv, fc, hits, work, lc.spill, ctl, n_account, refill);
   } else {
-    if (count) hipLaunchKernelGGL((k_trace_primary<true, false>), grid, block, smem, s, sv, fc, hits, work, lc.spill, ctl, n_account, lc.refill);
-    else hipLaunchKernelGGL((k_trace_primary<false, false>), grid, block, smem, s, sv, fc, hits, work, lc.spill, ctl, n_account, lc.refill);
+    if (count) hipLaunchKernelGGL((k_trace_primary<true, false>), grid, block, smem, s, sv, fc, hits, work, lc.spill, ctl, n_account, refill);
+    else hipLaunchKernelGGL((k_trace_primary<false, false>), grid, block, smem, s, sv, fc, hits, work, lc.spill, ctl, n_account, refill);
   }
 }
 void launch_shade(const FrameConst& fc, const SceneView& sv, const Queues& q, const PathState& ps, Control* ctl, uint32_t depth, hipStream_t s) {
