@@ -235,10 +235,10 @@ def main():
     index = 4 if (world > 1 or os.environ.get("BENCH_WORKLOAD") == "configs4") else 3
     cfg = workloads.baseline_config(index)
     run = Run(H, cfg, local_rank, rank, world, dist, torch)
-    # per-launch HIP events (the roofline's avg_launch_ms) on every 4th frame of the timed region (still live, still inside it): a timed frame
-    # issues one launch per pass, the others fuse the last shadow pass of a bounce with the next bounce's closest-hit pass (renderer.hip)
-    # (fewer than 8 steps: exactly one timed frame — any `steps` consecutive updates hold one multiple of `steps`)
-    period = int(os.environ.get("BENCH_TIMING_PERIOD", "4" if args.steps >= 8 else str(max(1, args.steps))))
+    # per-launch HIP events (the roofline's avg_launch_ms) on two frames of the timed region (still live, still inside it): a timed frame
+    # issues one launch per pass, the others fuse the shadow passes of a bounce with the next bounce's closest-hit pass (renderer.hip)
+    # (two timed frames from 8 steps on, else exactly one: any `p` consecutive updates hold one multiple of `p`)
+    period = int(os.environ.get("BENCH_TIMING_PERIOD", str(args.steps // 2 if args.steps >= 8 else max(1, args.steps))))
     dt, s0, s1 = run.measure(args.steps, args.warmup, timing_period=period)
     rays_local = s1.rays_total - s0.rays_total
     t_local = torch.tensor([dt, float(rays_local)], dtype=torch.float64, device=f"cuda:{local_rank}")
