@@ -300,12 +300,13 @@ int hala_rt_push_hit_shaders_with_file(hala_rt_renderer* r, const char* closest_
  * reference, :319).  The image is decoded, validated and uploaded like the reference does, and then IGNORED:
  * the built-in integrator draws every sample from a counter-based hash RNG keyed by (pixel id, frame index)
  * (docs/RENDER_SPEC.md 2.3), which is what makes a pixel's value independent of tiling, batching and ranks. */
-int hala_rt_load_blue_noise_texture(hala_rt_renderer* r, const char* path); /* PNG / baseline JPEG, like HalaImageData::new_with_file */
+int hala_rt_load_blue_noise_texture(hala_rt_renderer* r, const char* path); /* PNG / JPEG, like HalaImageData::new_with_file */
 int hala_rt_load_blue_noise_pixels(hala_rt_renderer* r, const uint8_t* rgba8, uint32_t width,
                                    uint32_t height);
 
 /* set_scene (src/rt_renderer.rs:1161-1178) -> HalaSceneGPUUploader::upload(.., false, false, true)
- * (src/scene/loader/gpu_uploader.rs:63-545, :774-967). */
+ * (src/scene/loader/gpu_uploader.rs:63-545, :774-967).  Refused (the reference would hand them to the driver unchecked): primitives
+ * without a material, indices out of range, vertex positions that are not finite. */
 int hala_rt_set_scene(hala_rt_renderer* r, const hala_scene_desc* scene);
 
 /* set_envmap (src/rt_renderer.rs:1184-1195) -> EnvMap::new_with_file (src/envmap.rs:38-232).
@@ -424,8 +425,10 @@ int hala_rt_get_packed_primitives(hala_rt_renderer* r, hala_gpu_mesh_data* dst, 
 int hala_rt_get_env_distribution(hala_rt_renderer* r, float* total_sum, float* marginal, float* conditional);
 
 /* Textures of set 2 binding 0 (src/rt_renderer.rs:197-226) as uploaded by gpu_uploader.rs:334-403: every texture is a
- * full mip chain (gen_mipmaps, :400) of linear RGBA32F texels; the sampler is linear / linear-mip / REPEAT (:341-353).
- * Introspection + a stand-alone fetch for parity tests: uv_lod holds (u, v, lod) triples. */
+ * full mip chain (gen_mipmaps, :400); the sampler is linear / linear-mip / REPEAT (:341-353).  8-bit images stay 8-bit at
+ * every level (RGBA8 in HBM, decoded at fetch: docs/RENDER_SPEC.md 7.4), float images are RGBA32F.  Introspection + a stand-alone
+ * fetch for parity tests: read_texture_level returns the level's texel VALUES (decoded to linear RGBA32F), uv_lod holds (u, v, lod)
+ * triples. */
 int hala_rt_get_texture_info(hala_rt_renderer* r, uint32_t texture, uint32_t* width, uint32_t* height, uint32_t* mips);
 int hala_rt_read_texture_level(hala_rt_renderer* r, uint32_t texture, uint32_t level, float* dst_rgba32f);
 int hala_rt_sample_texture_host(hala_rt_renderer* r, uint32_t texture, const float* uv_lod, uint32_t count, float* dst_rgba32f);
@@ -434,8 +437,8 @@ int hala_rt_sample_texture_host(hala_rt_renderer* r, uint32_t texture, const flo
  * into tile_size x tile_size tiles; tile t belongs to rank perm(t) % world (perm = fixed bijective
  * scramble).  After this call update() renders only this rank's tiles into a tile-major buffer;
  * hala_rt_tile_buffer gives its device address + byte size (per AOV) for the RCCL all-gather, and
- * hala_rt_scatter_gathered_tiles de-interleaves the gathered [world][tiles_per_rank][ts][ts][4] buffer
- * into the row-major images of this renderer.  The renderer works on its own HIP stream: wait (hala_rt_wait_idle, or a stream
+ * hala_rt_scatter_gathered_tiles de-interleaves the gathered [world][tiles_per_rank][ts*ts][4] buffer (inside a tile the pixels
+ * come in 8 x 8 blocks when ts is a multiple of 8: docs/RENDER_SPEC.md 9) into the row-major images of this renderer.  The renderer works on its own HIP stream: wait (hala_rt_wait_idle, or a stream
  * dependency on hala_rt_get_stream) before another stream reads the tile buffer — hala_rt_render does not flush. */
 int hala_rt_set_tile_shard(hala_rt_renderer* r, uint32_t rank, uint32_t world, uint32_t tile_size);
 int hala_rt_tile_buffer(hala_rt_renderer* r, int which, void** d_ptr, size_t* bytes);
