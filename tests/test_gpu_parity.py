@@ -1169,6 +1169,31 @@ def render_random_scene_both(halart, oracle, seed, big=False):
     stg = r.statistics()
     rays_ok = (stg.rays_closest_total, stg.rays_shadow_total) == (st.rays_closest, st.rays_shadow)
     lit = float(imgs[0][..., :3].mean())
+    if seed % 3 == 0:  # random edits without a rebuild: a node moved, a material replaced, a mesh deformed -> refit -> the same comparison
+        from random_scenes import random_material, _xform
+        rs = np.random.RandomState(seed + 77)
+        node = 1 + int(rs.randint(len(s.meshes) - 1))  # an object node (0 is the root, objects follow)
+        s.nodes[node].local_transform = _xform(rs, rs.uniform(-1.2, 1.2, 3))
+        r.update_node_transform(node, s.nodes[node].local_transform)
+        mi = int(rs.randint(len(s.materials)))
+        keep_maps = s.materials[mi]
+        m = random_material(rs)
+        m.base_color_map_index, m.normal_map_index = keep_maps.base_color_map_index, keep_maps.normal_map_index
+        m.metallic_roughness_map_index, m.emission_map_index = keep_maps.metallic_roughness_map_index, keep_maps.emission_map_index
+        s.materials[mi] = m
+        r.update_material(mi, m)
+        v = s.meshes[0].primitives[0].vertices.copy()
+        v["position"] += (0.05 * np.sin(5.0 * v["position"][:, ::-1])).astype(np.float32)
+        s.meshes[0].primitives[0].vertices = v
+        r.update_vertices(0, 0, v)
+        r.refit()
+        r.update_batch(2)
+        r.render()
+        osc2 = oracle.OracleScene(s, envmap=env)
+        imgs2, st2 = osc2.render(kw["width"], kw["height"], frames=2, max_depth=kw["max_depth"], rr_depth=kw["rr_depth"], tonemap=kw["tonemap"],
+                                 env_rotation=kw["env_rotation"] if env is not None else 0.0, env_intensity=kw["env_intensity"] if env is not None else 1.0,
+                                 exposure=kw["exposure"])
+        bad = [b + int(np.any(r.read_image(k) != imgs2[k], axis=-1).sum()) for k, b in enumerate(bad)]
     r.close()
     return bad, rays_ok, lit
 
