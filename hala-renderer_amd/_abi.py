@@ -158,6 +158,11 @@ class RtStatistics(C.Structure):
                 ("shade_ms_total", C.c_double), ("shade_launches", C.c_uint64)]
 
 
+class BuildOptions(C.Structure):  # hala_rt_build_options
+    _fields_ = [("builder", C.c_uint32), ("ploc_tail", C.c_uint32), ("ploc_look_every", C.c_uint32),
+                ("collapse_look_every", C.c_uint32), ("reserved", C.c_uint32 * 4)]
+
+
 class BvhInfo(C.Structure):
     _fields_ = [("node_count", C.c_uint32), ("triangle_count", C.c_uint32), ("max_depth", C.c_uint32),
                 ("lds_node_count", C.c_uint32), ("scene_min", C.c_float * 3), ("scene_max", C.c_float * 3),
@@ -184,7 +189,7 @@ EXPORTS = [
     "hala_rt_push_hit_shaders", "hala_rt_push_hit_shaders_with_file",
     "hala_rt_load_blue_noise_texture", "hala_rt_load_blue_noise_pixels", "hala_rt_set_scene", "hala_rt_set_envmap_pixels",
     "hala_rt_set_envmap_file", "hala_rt_set_ground_color", "hala_rt_set_sky_color",
-    "hala_rt_set_env_intensity", "hala_rt_set_exposure_value", "hala_rt_commit", "hala_rt_update", "hala_rt_update_batch",
+    "hala_rt_set_env_intensity", "hala_rt_set_exposure_value", "hala_rt_commit", "hala_rt_set_build_options", "hala_rt_update", "hala_rt_update_batch",
     "hala_rt_render", "hala_rt_wait_idle", "hala_rt_save_images", "hala_rt_read_image",
     "hala_rt_get_info", "hala_rt_get_statistics", "hala_rt_set_counting", "hala_rt_set_launch_timing_period", "hala_rt_reset_accumulation", "hala_rt_get_global_uniform",
     "hala_rt_get_packed_cameras", "hala_rt_get_packed_lights", "hala_rt_get_packed_materials",

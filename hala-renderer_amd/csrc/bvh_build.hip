@@ -989,7 +989,7 @@ static std::string fit_and_emit(BvhBuffers& b, BvhTopology& t, hipStream_t s) {
     // looks the grid covers the largest size the level can have reached (a level is at most 4 times the one above, and < n)
     constexpr uint32_t kMaxLevels = 96;
     uint32_t look_every = 8;
-    if (const char* ev = getenv("HALART_COLLAPSE_LOOK_EVERY")) look_every = (uint32_t)std::max(1, atoi(ev));  // A/B knob
+    if (b.opt.collapse_look_every) look_every = b.opt.collapse_look_every;
     DevBuf level, bases;
     if (!(e = level.alloc(16)).empty()) return e;
     if (!(e = bases.alloc(kMaxLevels * 4)).empty()) return e;
@@ -1051,13 +1051,13 @@ static std::string ploc_hierarchy(BvhBuffers& b, BvhTopology& t, hipStream_t s) 
   uint32_t m = n, created = 0;
   int cur = 0;
   uint32_t radius = kPlocRadius;
-  if (const char* ev = getenv("HALART_PLOC_RADIUS")) radius = (uint32_t)std::max(1, atoi(ev));  // tuning knob
+  if (const char* ev = tune_env("HALART_PLOC_RADIUS")) radius = (uint32_t)std::max(1, atoi(ev));
   bool tail = true;
-  if (const char* ev = getenv("HALART_PLOC_TAIL")) tail = atoi(ev) != 0;  // A/B knob: 0 = every round as separate launches
+  if (b.opt.ploc_tail == 2u) tail = false;  // every round as separate launches
   // rounds between two looks at the device's counters: a look is a host round trip (~50 us, as long as a late round itself); the
   // grid of the rounds in between is sized for the count of the last look (clusters only get fewer).  Same tree for any value.
   uint32_t look_every = 6;
-  if (const char* ev = getenv("HALART_PLOC_LOOK_EVERY")) look_every = (uint32_t)std::max(1, atoi(ev));  // A/B knob
+  if (b.opt.ploc_look_every) look_every = b.opt.ploc_look_every;
   DevBuf state;
   if (!(e = state.alloc(8)).empty()) return e;
   const uint32_t init_state[2] = {n, 0u};
@@ -1145,7 +1145,7 @@ static std::string sah_hierarchy(BvhBuffers& b, BvhTopology& t, hipStream_t s) {
                      t.node_parent.as<uint32_t>(), act[0].as<uint32_t>(), best.as<unsigned long long>());
   const float pad = box_pad(b);
   uint32_t quant = (uint32_t)kSahQuant;  // = the leaf slots of the cooperative pass (traverse.h: RT_LEAF_SLOTS)
-  if (const char* ev = getenv("HALART_SAH_QUANT")) quant = (uint32_t)std::max(1, atoi(ev));  // tuning knob
+  if (const char* ev = tune_env("HALART_SAH_QUANT")) quant = (uint32_t)std::max(1, atoi(ev));
   uint32_t open = 1, next_id = 1, round = 0;
   int cur = 0, ac = 0;
   constexpr uint32_t kSweepRounds = 64;  // below that depth every node is halved instead: at most 28 more rounds
@@ -1231,9 +1231,8 @@ std::string bvh_build(BvhBuffers& b, uint32_t leaf_max, hipStream_t s) {
     // hierarchy over the triangles: full-sweep SAH rounds for scenes large enough to repay them (1 M triangles: 34 ms of build instead
     // of PLOC's 11 ms for 10-15 % fewer node visits per closest-hit ray, profiles/r02_experiments.txt), Karras' LBVH over the Morton
     // order otherwise; PLOC (nearest-neighbour clustering along the Morton order) stays selectable as the fast large-scene build
-    const char* builder = getenv("HALART_BUILDER");  // "sah" | "ploc" | "lbvh": A/B knob
-    const bool sah = builder ? !strcmp(builder, "sah") : n >= 4096u;
-    const bool ploc = builder && !strcmp(builder, "ploc");
+    const bool sah = b.opt.builder ? b.opt.builder == 1u : n >= 4096u;
+    const bool ploc = b.opt.builder == 2u;
     if (sah) {  // (needs no Morton order)
       if (!(e = sah_hierarchy(b, t, s)).empty()) return e;
       t.fitted = true;
@@ -1243,7 +1242,7 @@ std::string bvh_build(BvhBuffers& b, uint32_t leaf_max, hipStream_t s) {
       if (!(e = keys_out.alloc((size_t)n * 8)).empty()) return e;
       if (!(e = ids_in.alloc((size_t)n * 4)).empty()) return e;
       uint32_t size_classes = 1;
-      if (const char* ev = getenv("HALART_SIZE_CLASSES")) size_classes = (uint32_t)atoi(ev);  // tuning knob
+      if (const char* ev = tune_env("HALART_SIZE_CLASSES")) size_classes = (uint32_t)atoi(ev);
       hipLaunchKernelGGL(k_morton, dim3(nblk(n)), dim3(256), 0, s, t.tri_box.as<Box6>(), n, t.scene_ord.as<uint32_t>(),
                          keys_in.as<unsigned long long>(), ids_in.as<uint32_t>(), size_classes);
       size_t tmp_bytes = 0;

@@ -819,7 +819,7 @@ bool launch_trace_shadow_then_batch(const LaunchCfg& lc, const SceneView& sv, co
 void launch_trace_primary(const LaunchCfg& lc, const SceneView& sv, const FrameConst& fc, hala_hit* hits, WorkCounters* work, Control* ctl,
                           uint32_t n_account, bool count, hipStream_t s) {
   const size_t smem = traverse_smem(sv);
-  static const uint32_t refill_env = getenv("HALART_REFILL_PRIMARY") ? (uint32_t)atoi(getenv("HALART_REFILL_PRIMARY")) : 0u;  // A/B knob
+  static const uint32_t refill_env = tune_env("HALART_REFILL_PRIMARY") ? (uint32_t)atoi(tune_env("HALART_REFILL_PRIMARY")) : 0u;
   // camera rays of neighbouring pixels are about equally long: larger refills (40 idle lanes instead of 24) keep the 8 x 8 pixel blocks together
   const uint32_t refill = refill_env ? refill_env : (sv.staged ? lc.refill : std::max(lc.refill, 40u));
   dim3 grid(lc.persistent_blocks), block(kTraverseThreads);

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <string>
 
 #include "hala_types.h"
@@ -41,7 +42,23 @@ void launch_tile8(const uint32_t* src, uint32_t w, uint32_t h, uint32_t* dst, hi
 void launch_mip_downsample8(const uint32_t* src, uint32_t sw, uint32_t sh, uint32_t* dst, uint32_t dw, uint32_t dh, uint32_t format, const float* lut,
                             const float* thr, hipStream_t s);
 
+// Tuning knobs read from the environment exist only in builds made with -DHALART_TUNING (scripts/variant_sweep.sh): the results and
+// the speed of the release library do not depend on the caller's environment.
+#ifdef HALART_TUNING
+inline const char* tune_env(const char* name) { return getenv(name); }
+#else
+inline const char* tune_env(const char*) { return nullptr; }
+#endif
+
 // bvh_build.hip — K1/K3/K4: flatten instances to world space, LBVH build, refit
+// How commit() builds the hierarchy (hala_rt_set_build_options; 0 = the default everywhere).  The driver fields only change HOW the
+// host walks the rounds of a build, never the tree (tests/test_gpu_parity.py::test_ploc_drivers_build_the_same_tree).
+struct BuildOptions {
+  uint32_t builder = 0;              // 0 auto (full-sweep SAH from 4096 triangles, LBVH below) | 1 SAH | 2 PLOC | 3 LBVH
+  uint32_t ploc_tail = 0;            // 0 / 1: the last PLOC rounds (<= 512 clusters) inside one workgroup | 2: every round its own launch
+  uint32_t ploc_look_every = 0;      // PLOC rounds between two looks of the host at the device's counters (default 6)
+  uint32_t collapse_look_every = 0;  // levels of the 4-wide collapse between two looks (default 8)
+};
 struct BvhBuffers {
   // inputs (device)
   const hala_gpu_mesh_data* primitives;  // per instance
@@ -59,6 +76,7 @@ struct BvhBuffers {
   uint32_t* tri_instance;  // [tri_count]
   BvhNode4* nodes;         // capacity >= max(tri_count - 1, 1)
   void* topology = nullptr;  // builder state kept for refit (freed with bvh_free_topology)
+  BuildOptions opt;
   // results
   uint32_t node_count;
   uint32_t max_depth;    // levels of the emitted tree

@@ -414,7 +414,7 @@ int upload_packed(hala_rt_renderer* r, bool geometry = true) {
     r->scatter_media = false;
     for (const auto& m : hs.gpu_materials) r->scatter_media = r->scatter_media || m.medium_type == 2u;
     r->simple_materials = seen == (1u << kShadeKindFirst);  // nothing but untextured opaque DIFFUSE: the SIMPLE shade kernels (configs[1])
-    if (getenv("HALART_NO_SIMPLE_SHADE")) r->simple_materials = false;  // A/B knob
+    if (tune_env("HALART_NO_SIMPLE_SHADE")) r->simple_materials = false;
   }
   RT_HIP(r->d_instances.upload(hs.instances.data(), hs.instances.size(), r->stream));
   RT_HIP(r->d_inst_first_tri.upload(hs.inst_first_tri.data(), hs.inst_first_tri.size(), r->stream));
@@ -488,7 +488,7 @@ int configure_traversal(hala_rt_renderer* r) {
   // Whole BVH in LDS when it fits the budget (the STAGED kernel variants read it with ds_read only); otherwise nothing
   // is staged: a top-of-tree slice measured no gain (profiles/r01_h_experiments.txt), the caches already hold it.
   size_t budget = kLdsStageBudget;
-  if (const char* e = getenv("HALART_LDS_STAGE_BYTES")) budget = (size_t)strtoul(e, nullptr, 10);  // tuning knob
+  if (const char* e = tune_env("HALART_LDS_STAGE_BYTES")) budget = (size_t)strtoul(e, nullptr, 10);  // tuning knob
   r->staged = nb + tb <= budget;
   r->lds_nodes = r->staged ? r->bvh.node_count : 0u;
   r->lds_tris = r->staged ? r->bvh.tri_count : 0u;
@@ -497,13 +497,13 @@ int configure_traversal(hala_rt_renderer* r) {
   uint32_t per_cu = traverse_blocks_per_cu(smem, r->staged);
   if (per_cu == 0) RT_FAIL("The traversal kernel does not fit on a compute unit with the requested LDS staging.");
   per_cu = std::min(per_cu, 8u);
-  if (const char* e = getenv("HALART_BLOCKS_PER_CU")) per_cu = std::min(per_cu, std::max(1u, (uint32_t)atoi(e)));  // tuning knob
+  if (const char* e = tune_env("HALART_BLOCKS_PER_CU")) per_cu = std::min(per_cu, std::max(1u, (uint32_t)atoi(e)));  // tuning knob
   r->lcfg.persistent_blocks = r->cu_count * per_cu;
   r->lcfg.spill = nullptr;
   // measured (profiles/r01_c_refill_sweep.txt): whole-wave refills are best when the BVH lives in LDS (uniform, cheap rays);
   // refilling once half the wave is idle is best when node fetches go to L2 / Infinity Cache
   r->lcfg.refill = r->staged ? 64u : kRefillThreshold;
-  if (const char* e = getenv("HALART_REFILL")) r->lcfg.refill = std::min(64u, std::max(1u, (uint32_t)strtoul(e, nullptr, 10)));  // tuning knob
+  if (const char* e = tune_env("HALART_REFILL")) r->lcfg.refill = std::min(64u, std::max(1u, (uint32_t)strtoul(e, nullptr, 10)));  // tuning knob
   if (r->bvh.stack_need > traverse_stack_lds_levels(r->staged)) {
     if (r->bvh.stack_need > traverse_stack_lds_levels(r->staged) + traverse_stack_spill_levels()) {
       // 3 x levels is a loose bound (every node on the path deferring three siblings).  Before refusing the tree, take the exact
@@ -564,7 +564,7 @@ int build_bvh(hala_rt_renderer* r) {
   if (attach_any_triangles(r) != HALA_OK) return HALA_ERR;
   // a scene this small will be staged in LDS (configure_traversal: 48 B per triangle + at most ~32 B of nodes per triangle)
   uint32_t leaf_max = (size_t)n * 80 <= kLdsStageBudget ? kLeafMaxStaged : kLeafMax;
-  if (const char* ev = getenv("HALART_LEAF_MAX")) leaf_max = std::min(8u, std::max(1u, (uint32_t)atoi(ev)));  // tuning knob
+  if (const char* ev = tune_env("HALART_LEAF_MAX")) leaf_max = std::min(8u, std::max(1u, (uint32_t)atoi(ev)));  // tuning knob
   if ((size_t)n * 80 > kLdsStageBudget) leaf_max = std::min(leaf_max, traverse_max_leaf(false));  // one consumer lane per triangle of a leaf item
   const std::string e = bvh_build(r->bvh, leaf_max, r->stream);
   if (!e.empty()) RT_FAIL(e);
@@ -632,7 +632,7 @@ int hala_rt_create(const char* name, uint32_t width, uint32_t height, int device
   if (device_ordinal < 0 || device_ordinal >= count) RT_FAIL("The requested device ordinal does not exist.");
   RT_HIP(hipSetDevice(device_ordinal));
   std::unique_ptr<hala_rt_renderer> r(new hala_rt_renderer());
-  if (const char* ev = getenv("HALART_EVENT_PERIOD")) r->launch_event_period = (uint32_t)std::max(0, atoi(ev));  // tuning knob
+  if (const char* ev = tune_env("HALART_EVENT_PERIOD")) r->launch_event_period = (uint32_t)std::max(0, atoi(ev));  // tuning knob
   r->name = name ? name : "";
   r->width = width; r->height = height; r->device = device_ordinal;
   r->max_depth = max_depth; r->rr_depth = rr_depth;
@@ -642,7 +642,7 @@ int hala_rt_create(const char* name, uint32_t width, uint32_t height, int device
   RT_HIP(hipGetDeviceProperties(&prop, device_ordinal));
   r->cu_count = (uint32_t)prop.multiProcessorCount;
   RT_HIP(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
-  if (const char* ev = getenv("HALART_FUSE")) r->fuse_passes = atoi(ev) != 0;  // A/B knob
+  if (const char* ev = tune_env("HALART_FUSE")) r->fuse_passes = atoi(ev) != 0;  // A/B knob
   compute_tiling(r.get());
   // create_storage_images (src/rt_renderer.rs:818-917): final, accum, albedo, normal
   if (alloc_frame_buffers(r.get()) != HALA_OK) return HALA_ERR;
@@ -764,6 +764,16 @@ int hala_rt_commit(hala_rt_renderer* r) {
   if (build_bvh(r) != HALA_OK) return HALA_ERR;
   r->committed = true;
   r->reset_accumulation();
+  return HALA_OK;
+}
+
+int hala_rt_set_build_options(hala_rt_renderer* r, const hala_rt_build_options* o) {
+  if (!r) RT_FAIL("The renderer handle is null!");
+  if (!o) RT_FAIL("The build options are null!");
+  if (o->builder > 3u || o->ploc_tail > 2u) RT_FAIL("Invalid build options.");
+  for (uint32_t v : o->reserved) if (v != 0u) RT_FAIL("Invalid build options (reserved fields must be 0).");
+  r->bvh.opt.builder = o->builder; r->bvh.opt.ploc_tail = o->ploc_tail;
+  r->bvh.opt.ploc_look_every = o->ploc_look_every; r->bvh.opt.collapse_look_every = o->collapse_look_every;
   return HALA_OK;
 }
 

@@ -117,6 +117,14 @@ class HalaRenderer:
         """src/rt_renderer.rs:136-379"""
         self._check(self._lib.hala_rt_commit(self._h))
 
+    BUILDERS = {None: 0, "auto": 0, "sah": 1, "ploc": 2, "lbvh": 3}
+
+    def set_build_options(self, builder=None, ploc_tail=0, ploc_look_every=0, collapse_look_every=0):
+        """how the next commit() builds the acceleration structure (hala_rt_set_build_options): builder = None | "sah" | "ploc" | "lbvh";
+        the other fields only change how the host drives the build rounds (same tree)"""
+        o = A.BuildOptions(builder=self.BUILDERS[builder], ploc_tail=ploc_tail, ploc_look_every=ploc_look_every, collapse_look_every=collapse_look_every)
+        self._check(self._lib.hala_rt_set_build_options(self._h, C.byref(o)))
+
     def update(self, delta_time=0.0, width=None, height=None, ui_fn=None):
         """src/rt_renderer.rs:387-471 — one sample per pixel; `ui_fn` is dropped."""
         self._check(self._lib.hala_rt_update(self._h, C.c_double(delta_time), C.c_uint32(width or self.width), C.c_uint32(height or self.height)))

@@ -329,6 +329,17 @@ void hala_rt_set_exposure_value(hala_rt_renderer* r, float exposure_value);
  * reference hands to vkCmdBuildAccelerationStructuresKHR: gpu_uploader.rs:784-811, :937-959) and
  * allocates the wavefront queues. */
 int hala_rt_commit(hala_rt_renderer* r);
+/* How commit() builds the acceleration structure — the HalaAccelerationStructure build flags of gpu_uploader.rs:784-811 /
+ * :937-959 (PREFER_FAST_TRACE there).  Every field: 0 = the default.  The *_look_every / ploc_tail fields only change how the host
+ * drives the rounds of a build (test hooks: the tree is the same for every value).  Takes effect at the next commit. */
+typedef struct hala_rt_build_options {
+  uint32_t builder;             /* 0 auto: full-sweep SAH from 4096 triangles, LBVH below | 1 SAH (fast trace) | 2 PLOC (fast build) | 3 LBVH */
+  uint32_t ploc_tail;           /* 0 / 1: the last PLOC rounds in one workgroup | 2: every round its own launch */
+  uint32_t ploc_look_every;     /* PLOC rounds between two host looks at the device counters (default 6) */
+  uint32_t collapse_look_every; /* levels of the 4-wide collapse between two host looks (default 8) */
+  uint32_t reserved[4];         /* must be 0 */
+} hala_rt_build_options;
+int hala_rt_set_build_options(hala_rt_renderer* r, const hala_rt_build_options* options);
 
 /* update (src/rt_renderer.rs:387-471): pre_update bookkeeping (src/renderer.rs:266-281), the
  * `total_frames > max_frames` early-out (:394-396), the HalaGlobalUniform fill (:408-427) and one

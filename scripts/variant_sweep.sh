@@ -16,15 +16,18 @@ print(b['value'], b['ms_per_step'], 'closest', k['closest'], 'shade', k['shade']
       '| node lanes', s['closest']['node_path_lanes_of_64'], s['shadow']['node_path_lanes_of_64'])
 c=b.get('secondary',{}).get('configs1')
 if c: print('   cornell', c['value'], c['ms_per_frame'], 'batch', c['batch_kernel']['avg_launch_ms'], 'shadow', c['shadow_kernel']['avg_launch_ms'], 'shade', c['shade_kernel']['avg_launch_ms'], '| 4K on 1 GPU', b['secondary']['configs4_on_1_gpu']['ms_per_frame'])"; }
+# the HALART_* environment knobs only exist in -DHALART_TUNING builds (kernels.h: tune_env): every build of the sweep is one, the release
+# build is restored at the end
 build() { touch hala-renderer_amd/csrc/integrator.hip hala-renderer_amd/csrc/renderer.hip hala-renderer_amd/csrc/bvh_build.hip; make -C hala-renderer_amd/csrc -j16 EXTRA="$1" > gpurun_out/variant_make.log 2>&1 || { echo "build failed: $1"; tail -n 5 gpurun_out/variant_make.log; }; }
 mkdir -p gpurun_out
+build "-DHALART_TUNING"
 echo "default"; run ""
-rebuilt=0
+rebuilt=1
 for v in "$@"; do
   case "$v" in
     ENV:*) echo "$v"; run "${v#ENV:}";;
-    BOTH:*) w="${v#BOTH:}"; build "${w%%|*}"; rebuilt=1; echo "$v"; run "${w#*|}";;
-    *) build "$v"; rebuilt=1; echo "$v"; run "";;
+    BOTH:*) w="${v#BOTH:}"; build "-DHALART_TUNING ${w%%|*}"; echo "$v"; run "${w#*|}";;
+    *) build "-DHALART_TUNING $v"; echo "$v"; run "";;
   esac
 done
 if [ $rebuilt = 1 ]; then build ""; fi

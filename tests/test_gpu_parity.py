@@ -19,8 +19,10 @@ pytestmark = pytest.mark.gpu
 f32 = np.float32
 
 
-def make_renderer(halart, scene, w, h, max_depth=5, rr_depth=3, tonemap=(False, False, False), max_frames=0, env=None, env_rot=0.0):
+def make_renderer(halart, scene, w, h, max_depth=5, rr_depth=3, tonemap=(False, False, False), max_frames=0, env=None, env_rot=0.0, build=None):
     r = halart.HalaRenderer("test", w, h, max_depth, rr_depth, *tonemap, max_frames)
+    if build is not None:
+        r.set_build_options(**build)
     if env is not None:
         r.set_envmap(env, env_rot)
     r.set_scene(scene)
@@ -434,18 +436,15 @@ def test_refit_after_vertex_deformation(halart, oracle):
     r.close()
 
 
-def test_ploc_drivers_build_the_same_tree(halart, oracle, monkeypatch):
-    """PLOC's rounds are driven three ways — every round looked at by the host (HALART_PLOC_LOOK_EVERY=1), several rounds between two
+def test_ploc_drivers_build_the_same_tree(halart, oracle):
+    """PLOC's rounds are driven three ways — every round looked at by the host (ploc_look_every = 1), several rounds between two
     looks with the counters on the device (the default, and an odd value), the last rounds (<= 512 clusters) inside one workgroup
-    (k_ploc_tail) or not (HALART_PLOC_TAIL=0): all of them must emit byte-identical nodes and triangle orders"""
+    (k_ploc_tail) or not (ploc_tail = 2): all of them must emit byte-identical nodes and triangle orders (hala_rt_set_build_options)"""
     s = scenes.sponza_class(target_triangles=60_000)
     trees = []
-    monkeypatch.setenv("HALART_BUILDER", "ploc")  # the fast large-scene build (the default at this size is the SAH one)
-    for tail, look, collapse_look in (("1", "6", "4"), ("0", "1", "1"), ("1", "1", "3"), ("0", "7", "9")):
-        monkeypatch.setenv("HALART_PLOC_TAIL", tail)
-        monkeypatch.setenv("HALART_PLOC_LOOK_EVERY", look)
-        monkeypatch.setenv("HALART_COLLAPSE_LOOK_EVERY", collapse_look)  # the 4-wide collapse walks its levels the same way
-        r = make_renderer(halart, s, 16, 16)
+    # builder "ploc": the fast large-scene build (the default at this size is the SAH one)
+    for tail, look, collapse_look in ((1, 6, 4), (2, 1, 1), (1, 1, 3), (2, 7, 9)):
+        r = make_renderer(halart, s, 16, 16, build=dict(builder="ploc", ploc_tail=tail, ploc_look_every=look, collapse_look_every=collapse_look))
         trees.append(r.download_bvh())
         info = r.bvh_info()
         r.close()
@@ -457,7 +456,7 @@ def test_ploc_drivers_build_the_same_tree(halart, oracle, monkeypatch):
     assert rc == 0
 
 
-def test_builders_differ_in_trees_not_in_results(halart, oracle, monkeypatch):
+def test_builders_differ_in_trees_not_in_results(halart, oracle):
     """the three hierarchy builders (full-sweep SAH: the default from 4096 triangles; PLOC; LBVH) over one scene: every tree passes the
     structural check, is rebuilt byte for byte, gives the oracle's hits (the oracle traverses its OWN tree) and the oracle's step counts
     on that very tree; the SAH tree is the one with the fewest node visits per ray"""
@@ -469,9 +468,7 @@ def test_builders_differ_in_trees_not_in_results(halart, oracle, monkeypatch):
     want_any = osc.trace(rays, 1)
     visits = {}
     for builder in ("sah", "ploc", "lbvh", None):
-        if builder is None: monkeypatch.delenv("HALART_BUILDER")
-        else: monkeypatch.setenv("HALART_BUILDER", builder)
-        r = make_renderer(halart, s, 16, 16)
+        r = make_renderer(halart, s, 16, 16, build=dict(builder=builder))
         nodes, tris = r.download_bvh()
         rc, depth = oracle.validate_bvh(nodes, tris, osc.triangles())
         assert rc == 0 and depth == r.bvh_info().max_depth, builder
@@ -483,7 +480,7 @@ def test_builders_differ_in_trees_not_in_results(halart, oracle, monkeypatch):
         assert np.array_equal(got_any["t"], want_any["t"]), builder
         assert cnt_any == oracle.trace_on_bvh(nodes, tris, rays, 1)[1], builder
         r.close()
-        r2 = make_renderer(halart, s, 16, 16)  # deterministic: atomics only carry min / max / integer sums
+        r2 = make_renderer(halart, s, 16, 16, build=dict(builder=builder))  # deterministic: atomics only carry min / max / integer sums
         n2, t2 = r2.download_bvh()
         r2.close()
         assert n2.tobytes() == nodes.tobytes() and t2.tobytes() == tris.tobytes(), builder
