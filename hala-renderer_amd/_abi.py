@@ -204,4 +204,5 @@ EXPORTS = [
     "hala_rtprog_push_constants_f32", "hala_rtprog_trace_rays", "hala_rtprog_trace_rays_indirect",
     "hala_rt_comm_unique_id", "hala_rt_comm_init_rank", "hala_rt_comm_attach", "hala_rt_comm_destroy",
     "hala_rt_tile_allgather", "hala_rt_tile_allgather_begin", "hala_rt_tile_allgather_finish", "hala_rt_get_gathered_buffer",
+    "hala_rt_tile_allgather_begin_external", "hala_rt_get_exchange_buffers",
 ]

@@ -417,3 +417,64 @@ std::string load_float_image(const char* path, HostImage* img) {
 }
 
 }  // namespace rt
+
+// ---- optional libraries, resolved on first use (dyn_api.h) -------------------------------------------------------------------------
+#include <dlfcn.h>
+
+#include <mutex>
+
+#include "dyn_api.h"
+
+namespace rt {
+namespace {
+void* open_first(const char* const* names, bool noload_first) {
+  if (noload_first)
+    for (const char* const* n = names; *n; ++n)
+      if (void* h = dlopen(*n, RTLD_NOW | RTLD_NOLOAD)) return h;
+  for (const char* const* n = names; *n; ++n)
+    if (void* h = dlopen(*n, RTLD_NOW | RTLD_LOCAL)) return h;
+  return nullptr;
+}
+}  // namespace
+
+const RcclApi* rccl_api(std::string* err) {
+  static RcclApi api{};
+  static std::string failure;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    static const char* const names[] = {"librccl.so.1", "librccl.so", nullptr};
+    void* h = open_first(names, true);
+    if (!h) { failure = std::string("RCCL is not available (dlopen librccl.so.1: ") + (dlerror() ? dlerror() : "not found") + ")"; return; }
+    struct { const char* name; void** slot; } syms[] = {
+        {"ncclGetUniqueId", (void**)&api.GetUniqueId}, {"ncclCommInitRank", (void**)&api.CommInitRank}, {"ncclCommUserRank", (void**)&api.CommUserRank},
+        {"ncclCommCount", (void**)&api.CommCount},     {"ncclCommDestroy", (void**)&api.CommDestroy},   {"ncclAllGather", (void**)&api.AllGather},
+        {"ncclGetErrorString", (void**)&api.GetErrorString}};
+    for (auto& s : syms) {
+      *s.slot = dlsym(h, s.name);
+      if (!*s.slot) { failure = std::string("RCCL lacks the symbol ") + s.name; return; }
+    }
+  });
+  if (!failure.empty()) { if (err) *err = failure; return nullptr; }
+  return &api;
+}
+
+namespace {
+struct RoctxApi { int (*push)(const char*) = nullptr; int (*pop)() = nullptr; };
+const RoctxApi& roctx_api() {
+  static RoctxApi api;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    static const char* const names[] = {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so", nullptr};
+    void* h = open_first(names, true);
+    if (!h) return;
+    api.push = (int (*)(const char*))dlsym(h, "roctxRangePushA");
+    api.pop = (int (*)())dlsym(h, "roctxRangePop");
+    if (!api.push || !api.pop) api.push = nullptr, api.pop = nullptr;
+  });
+  return api;
+}
+}  // namespace
+void roctx_push(const char* name) { const RoctxApi& a = roctx_api(); if (a.push) a.push(name); }
+void roctx_pop() { const RoctxApi& a = roctx_api(); if (a.pop) a.pop(); }
+
+}  // namespace rt

@@ -1,6 +1,5 @@
 // host_util.h — small host-side helpers of libhalart.so: error channel, RAII device buffers.
 #pragma once
-#include <rocprofiler-sdk-roctx/roctx.h>
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -76,9 +75,10 @@ std::string json_parse(const char* text, JsonValue* out);
 }  // namespace rt
 
 // roctx range around a host-side phase (rocprofv3 --marker-trace shows commit / update / refit / tile_allgather on the timeline)
+namespace rt { void roctx_push(const char* name); void roctx_pop(); }  // dyn_api.h: no-ops when the profiler SDK is not installed
 struct RtRange {
-  explicit RtRange(const char* name) { roctxRangePushA(name); }
-  ~RtRange() { roctxRangePop(); }
+  explicit RtRange(const char* name) { rt::roctx_push(name); }
+  ~RtRange() { rt::roctx_pop(); }
   RtRange(const RtRange&) = delete;
   RtRange& operator=(const RtRange&) = delete;
 };

@@ -3,7 +3,6 @@
 // wavefront kernel sequence of integrator.hip, timestamp queries become HIP events, staging buffers become
 // hipMemcpyAsync from the caller's memory.  Everything that computes runs on the GPU; this file only orchestrates.
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <cmath>
@@ -14,6 +13,7 @@
 #include <sys/stat.h>
 #include <vector>
 
+#include "dyn_api.h"
 #include "hala_types.h"
 #include "host_image.h"
 #include "host_scene.h"
@@ -212,7 +212,7 @@ struct hala_rt_renderer {
     if (batch_done) (void)hipEventDestroy(batch_done);
     if (gather_stream) { (void)hipStreamSynchronize(gather_stream); (void)hipStreamDestroy(gather_stream); }
     for (hipEvent_t e : {ev_rendered, ev_staged, ev_gathered}) if (e) (void)hipEventDestroy(e);
-    if (comm && comm_owned) (void)ncclCommDestroy(comm);
+    if (comm && comm_owned) { if (const RcclApi* api = rccl_api(nullptr)) (void)api->CommDestroy(comm); }
     // images first, then everything else (src/rt_renderer.rs:620-633)
     for (auto& i : img_local) i.release();
     for (auto& i : img_full) i.release();
@@ -1056,11 +1056,19 @@ int hala_rt_sample_texture_host(hala_rt_renderer* r, uint32_t texture, const flo
 }
 
 // ---- multi-GPU tiles ------------------------------------------------------------------------------------------------
+int hala_rt_tile_allgather_finish(hala_rt_renderer* r);
 int hala_rt_set_tile_shard(hala_rt_renderer* r, uint32_t rank, uint32_t world, uint32_t tile_size) {
   if (ensure_device(r) != HALA_OK) return HALA_ERR;
   if (world == 0 || rank >= world) RT_FAIL("Invalid rank / world size.");
   if (tile_size == 0 || tile_size > 256) RT_FAIL("Invalid tile size.");
+  // a collective in flight belongs to the old shard: complete it (its receive buffer is laid out for the old world size)
+  if (r->gather_pending && hala_rt_tile_allgather_finish(r) != HALA_OK) return HALA_ERR;
+  // a communicator is bound to (rank, world): gather_recv is sized by it and the de-interleave indexes it by the shard's world
+  if (r->comm && ((uint32_t)r->comm_rank != rank || (uint32_t)r->comm_world != world))
+    RT_FAIL("The renderer holds a communicator for rank " + std::to_string(r->comm_rank) + " of " + std::to_string(r->comm_world) +
+            ": call hala_rt_comm_destroy before changing the tile shard.");
   RT_HIP(hipStreamSynchronize(r->stream));
+  if (r->gather_stream) RT_HIP(hipStreamSynchronize(r->gather_stream));
   r->rank = rank; r->world = world; r->tile_size = tile_size;
   compute_tiling(r);
   if (alloc_frame_buffers(r) != HALA_OK) return HALA_ERR;
@@ -1099,18 +1107,30 @@ int hala_rt_scatter_gathered_tiles(hala_rt_renderer* r, int which, const void* d
 
 
 // ---- RCCL tile all-gather (BASELINE.json north_star: "RCCL all-gather of tiles over xGMI") -----------------------------------------
-#define RT_NCCL(expr)                                                                                         \
-  do {                                                                                                        \
-    const ncclResult_t _r = (expr);                                                                           \
-    if (_r != ncclSuccess) RT_FAIL(std::string("RCCL: ") + ncclGetErrorString(_r) + " (" #expr ")");         \
+// librccl is resolved on first use (dyn_api.h): a one-GPU host loads libhalart.so without it.
+#define RT_RCCL_API(api)                                   \
+  std::string _rccl_err;                                   \
+  const RcclApi* api = rccl_api(&_rccl_err);               \
+  if (!api) RT_FAIL(_rccl_err)
+#define RT_NCCL(api, expr)                                                                                         \
+  do {                                                                                                             \
+    const ncclResult_t _r = (expr);                                                                                \
+    if (_r != ncclSuccess) RT_FAIL(std::string("RCCL: ") + (api)->GetErrorString(_r) + " (" #expr ")");            \
   } while (0)
 
 int hala_rt_comm_unique_id(void* out_128_bytes) {
   if (!out_128_bytes) RT_FAIL("Invalid argument.");
   static_assert(sizeof(ncclUniqueId) == HALA_COMM_UNIQUE_ID_BYTES, "ncclUniqueId is 128 bytes");
+  RT_RCCL_API(api);
   ncclUniqueId id;
-  RT_NCCL(ncclGetUniqueId(&id));
+  RT_NCCL(api, api->GetUniqueId(&id));
   memcpy(out_128_bytes, &id, sizeof(id));
+  return HALA_OK;
+}
+// the side stream and the three hand-over events of the exchange (with or without a communicator)
+static int ensure_gather_resources(hala_rt_renderer* r) {
+  if (!r->gather_stream) RT_HIP(hipStreamCreateWithFlags(&r->gather_stream, hipStreamNonBlocking));
+  for (hipEvent_t* e : {&r->ev_rendered, &r->ev_staged, &r->ev_gathered}) if (!*e) RT_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
   return HALA_OK;
 }
 static int comm_common(hala_rt_renderer* r, int rank, int world) {
@@ -1118,18 +1138,17 @@ static int comm_common(hala_rt_renderer* r, int rank, int world) {
     RT_FAIL("The communicator's rank / size (" + std::to_string(rank) + " / " + std::to_string(world) + ") differ from the renderer's tile shard (" +
             std::to_string(r->rank) + " / " + std::to_string(r->world) + "): call hala_rt_set_tile_shard first.");
   r->comm_rank = rank; r->comm_world = world;
-  if (!r->gather_stream) RT_HIP(hipStreamCreateWithFlags(&r->gather_stream, hipStreamNonBlocking));
-  for (hipEvent_t* e : {&r->ev_rendered, &r->ev_staged, &r->ev_gathered}) if (!*e) RT_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
-  return HALA_OK;
+  return ensure_gather_resources(r);
 }
 int hala_rt_comm_init_rank(hala_rt_renderer* r, const void* unique_id_128_bytes, uint32_t rank, uint32_t world) {
   if (ensure_device(r) != HALA_OK) return HALA_ERR;
   if (!unique_id_128_bytes || world == 0 || rank >= world) RT_FAIL("Invalid argument.");
   if (r->comm) RT_FAIL("The renderer already has a communicator.");
+  RT_RCCL_API(api);
   if (comm_common(r, (int)rank, (int)world) != HALA_OK) return HALA_ERR;
   ncclUniqueId id;
   memcpy(&id, unique_id_128_bytes, sizeof(id));
-  RT_NCCL(ncclCommInitRank(&r->comm, (int)world, id, (int)rank));
+  RT_NCCL(api, api->CommInitRank(&r->comm, (int)world, id, (int)rank));
   r->comm_owned = true;
   return HALA_OK;
 }
@@ -1137,9 +1156,10 @@ int hala_rt_comm_attach(hala_rt_renderer* r, void* nccl_comm) {
   if (ensure_device(r) != HALA_OK) return HALA_ERR;
   if (!nccl_comm) RT_FAIL("Invalid argument.");
   if (r->comm) RT_FAIL("The renderer already has a communicator.");
+  RT_RCCL_API(api);
   int rank = 0, world = 0;
-  RT_NCCL(ncclCommUserRank(static_cast<ncclComm_t>(nccl_comm), &rank));
-  RT_NCCL(ncclCommCount(static_cast<ncclComm_t>(nccl_comm), &world));
+  RT_NCCL(api, api->CommUserRank(static_cast<ncclComm_t>(nccl_comm), &rank));
+  RT_NCCL(api, api->CommCount(static_cast<ncclComm_t>(nccl_comm), &world));
   if (comm_common(r, rank, world) != HALA_OK) return HALA_ERR;
   r->comm = static_cast<ncclComm_t>(nccl_comm);
   r->comm_owned = false;
@@ -1148,19 +1168,26 @@ int hala_rt_comm_attach(hala_rt_renderer* r, void* nccl_comm) {
 int hala_rt_comm_destroy(hala_rt_renderer* r) {
   if (ensure_device(r) != HALA_OK) return HALA_ERR;
   if (r->gather_stream) RT_HIP(hipStreamSynchronize(r->gather_stream));
-  if (r->comm && r->comm_owned) RT_NCCL(ncclCommDestroy(r->comm));
+  if (r->comm && r->comm_owned) {
+    RT_RCCL_API(api);
+    RT_NCCL(api, api->CommDestroy(r->comm));
+  }
   r->comm = nullptr; r->comm_owned = false; r->gather_pending = 0;
   return HALA_OK;
 }
 
 // finish(k - 1) -> [side stream waits for the renderer's stream: frame k is complete] -> staging <- tiles -> [renderer's stream waits
-// for that copy: frame k + 1 may overwrite the tiles] -> ncclAllGather(receive <- staging) on the side stream.  Nothing blocks the host.
-int hala_rt_tile_allgather_begin(hala_rt_renderer* r, uint32_t aov_mask) {
-  RtRange range("halart::tile_allgather_begin");
-  if (ensure_device(r) != HALA_OK) return HALA_ERR;
-  if (!r->comm) RT_FAIL("The renderer has no communicator: call hala_rt_comm_init_rank or hala_rt_comm_attach first.");
+// for that copy: frame k + 1 may overwrite the tiles] -> the exchange (receive <- every rank's staging) on the side stream.  Nothing
+// blocks the host.  external = false: the exchange is ncclAllGather on the renderer's communicator.  external = true
+// (hala_rt_tile_allgather_begin_external): the CALLER performs it — a host with another transport (MPI, a gloo rehearsal on one GPU,
+// tests that emulate the ranks) reads the staging buffer and fills the receive buffer on the exchange stream (hala_rt_get_exchange_buffers) —
+// everything else (staging copy, event order, de-interleave in finish) is this very code.
+static int allgather_begin(hala_rt_renderer* r, uint32_t aov_mask, bool external) {
   if (aov_mask == 0u || aov_mask > 15u) RT_FAIL("Invalid AOV mask.");
   if (hala_rt_tile_allgather_finish(r) != HALA_OK) return HALA_ERR;
+  if (ensure_gather_resources(r) != HALA_OK) return HALA_ERR;
+  const uint32_t world = external ? r->world : (uint32_t)r->comm_world;
+  if (world != r->world) RT_FAIL("The communicator's size differs from the renderer's tile shard.");  // (set_tile_shard refuses the change)
   const size_t n = r->image_pixels();
   hipStream_t g = r->gather_stream;
   RT_HIP(hipEventRecord(r->ev_rendered, r->stream));
@@ -1168,15 +1195,39 @@ int hala_rt_tile_allgather_begin(hala_rt_renderer* r, uint32_t aov_mask) {
   for (int which = 0; which < 4; ++which) {
     if (!(aov_mask & (1u << which))) continue;
     RT_HIP(r->gather_stage[which].resize(n));
-    RT_HIP(r->gather_recv[which].resize(n * (size_t)r->comm_world));
+    RT_HIP(r->gather_recv[which].resize(n * (size_t)world));
     RT_HIP(hipMemcpyAsync(r->gather_stage[which].ptr, r->img_local[which].ptr, n * sizeof(float4), hipMemcpyDeviceToDevice, g));
   }
   RT_HIP(hipEventRecord(r->ev_staged, g));
   RT_HIP(hipStreamWaitEvent(r->stream, r->ev_staged, 0));
-  for (int which = 0; which < 4; ++which)
-    if (aov_mask & (1u << which))
-      RT_NCCL(ncclAllGather(r->gather_stage[which].ptr, r->gather_recv[which].ptr, n * 4, ncclFloat, r->comm, g));
+  if (!external) {
+    RT_RCCL_API(api);
+    for (int which = 0; which < 4; ++which)
+      if (aov_mask & (1u << which))
+        RT_NCCL(api, api->AllGather(r->gather_stage[which].ptr, r->gather_recv[which].ptr, n * 4, ncclFloat, r->comm, g));
+  }
   r->gather_pending = aov_mask;
+  return HALA_OK;
+}
+int hala_rt_tile_allgather_begin(hala_rt_renderer* r, uint32_t aov_mask) {
+  RtRange range("halart::tile_allgather_begin");
+  if (ensure_device(r) != HALA_OK) return HALA_ERR;
+  if (!r->comm) RT_FAIL("The renderer has no communicator: call hala_rt_comm_init_rank or hala_rt_comm_attach first.");
+  return allgather_begin(r, aov_mask, false);
+}
+int hala_rt_tile_allgather_begin_external(hala_rt_renderer* r, uint32_t aov_mask) {
+  RtRange range("halart::tile_allgather_begin_external");
+  if (ensure_device(r) != HALA_OK) return HALA_ERR;
+  return allgather_begin(r, aov_mask, true);
+}
+int hala_rt_get_exchange_buffers(hala_rt_renderer* r, int which, void** d_staged, size_t* staged_bytes, void** d_receive, size_t* receive_bytes, void** hip_stream) {
+  if (!r || which < 0 || which > 3) RT_FAIL("Invalid argument.");
+  if (!(r->gather_pending & (1u << which))) RT_FAIL("No exchange of this image is in flight: call hala_rt_tile_allgather_begin_external first.");
+  if (d_staged) *d_staged = r->gather_stage[which].ptr;
+  if (staged_bytes) *staged_bytes = r->gather_stage[which].bytes();
+  if (d_receive) *d_receive = r->gather_recv[which].ptr;
+  if (receive_bytes) *receive_bytes = r->gather_recv[which].bytes();
+  if (hip_stream) *hip_stream = static_cast<void*>(r->gather_stream);
   return HALA_OK;
 }
 // de-interleave on the side stream (beside the rendering of the next frame), then whatever the renderer's stream does next — and
@@ -1192,6 +1243,7 @@ int hala_rt_tile_allgather_finish(hala_rt_renderer* r) {
     const FrameConst fc = r->frame_const(r->last_uniform);
     for (int which = 0; which < 4; ++which) {
       if (!(mask & (1u << which))) continue;
+      if (r->gather_recv[which].count != r->image_pixels() * (size_t)r->world) RT_FAIL("The receive buffer does not match the tile shard.");
       RT_HIP(r->img_full[which].resize((size_t)r->width * r->height));
       launch_scatter_tiles(fc, r->gather_recv[which].ptr, r->img_full[which].ptr, g);
       r->full_valid[which] = true;

@@ -95,14 +95,17 @@ class TileGather:
         g.gather()            # accum, albedo, normal are now complete row-major images on every rank
     or pipelined, one frame deep: g.begin() after frame k's updates, g.finish() before the images of frame k are read.
 
-    backend "gloo" (CPU collectives; several ranks rehearsed on ONE GPU, which RCCL refuses): the same buffers travel through
-    torch.distributed.all_gather on the host instead, and only the de-interleave runs in the library.
+    backend "gloo" (CPU collectives; several ranks rehearsed on ONE GPU, which RCCL refuses): the library's own pipeline runs
+    unchanged — staging copy, event order, de-interleave of the receive buffer in finish() — and only the exchange itself is swapped:
+    hala_rt_tile_allgather_begin_external leaves it to the caller, who moves the staging buffers through
+    torch.distributed.all_gather on the host into the library's receive buffer, on the library's exchange stream.
     """
 
     def __init__(self, renderer, device_index, aovs=(0, 1, 2), group=None):
         import torch
         import torch.distributed as dist
         self.r, self.dist, self.group, self.torch, self.aovs = renderer, dist, group, torch, tuple(aovs)
+        self.device = f"cuda:{device_index}"
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self._gloo = dist.get_backend(group) == "gloo"
@@ -111,24 +114,13 @@ class TileGather:
             ident = [renderer.comm_unique_id() if self.rank == 0 else None]
             dist.broadcast_object_list(ident, src=0, group=group)
             renderer.comm_init_rank(ident[0], self.rank, self.world)
-            return
-        self.bufs = []
-        for which in self.aovs:
-            ptr, nbytes = renderer.tile_buffer(which)
-            src = torch.as_tensor(_DeviceView(ptr, nbytes // 4), device=f"cuda:{device_index}")
-            if src.data_ptr() != ptr:
-                raise RuntimeError("TileGather: torch copied the tile buffer instead of aliasing it")
-            dst = torch.empty(self.world * (nbytes // 4), dtype=torch.float32, device=f"cuda:{device_index}")
-            self.bufs.append((which, src, dst, nbytes))
 
     def begin(self):
         if not self._gloo:
             self.r.tile_allgather_begin(self.aovs)
             return
         self.finish()
-        self.r.wait_idle()
-        self._stage = [src.clone() for _, src, _, _ in self.bufs]  # the next frame overwrites the tile buffer
-        self.torch.cuda.synchronize()
+        self.r.tile_allgather_begin_external(self.aovs)  # stream-ordered snapshot of the tile buffers: the next frame may overwrite them
         self._pending = True
 
     def finish(self):
@@ -138,12 +130,23 @@ class TileGather:
         if not self._pending:
             return
         self._pending = False
-        for (which, _, dst, nbytes), stage in zip(self.bufs, self._stage):
-            self.dist.all_gather(list(dst.view(self.world, -1).unbind(0)), stage, group=self.group)
-        self.torch.cuda.synchronize()
-        if self.world > 1:
-            for which, _, dst, nbytes in self.bufs:
-                self.r.scatter_gathered_tiles(which, dst.data_ptr(), nbytes * self.world)
+        torch = self.torch
+        for which in self.aovs:
+            sp, sn, rp, rn, stream = self.r.exchange_buffers(which)
+            if rn != sn * self.world:
+                raise RuntimeError("TileGather: the receive buffer is not world x the staging buffer")
+            ext = torch.cuda.ExternalStream(stream, device=self.device)
+            with torch.cuda.stream(ext):  # the library's exchange stream: behind the staging copy, before finish()'s de-interleave
+                staged = torch.as_tensor(_DeviceView(sp, sn // 4), device=self.device)
+                recv = torch.as_tensor(_DeviceView(rp, rn // 4), device=self.device)
+                if staged.data_ptr() != sp or recv.data_ptr() != rp:
+                    raise RuntimeError("TileGather: torch copied an exchange buffer instead of aliasing it")
+                mine = staged.to("cpu")  # waits for the staging copy on this stream
+                parts = [torch.empty_like(mine) for _ in range(self.world)]
+                self.dist.all_gather(parts, mine, group=self.group)
+                recv.copy_(torch.cat(parts).to(self.device, non_blocking=False))
+            ext.synchronize()
+        self.r.tile_allgather_finish()
 
     def gather(self):
         self.begin()

@@ -314,6 +314,16 @@ class HalaRenderer:
     def tile_allgather_finish(self):
         self._check(self._lib.hala_rt_tile_allgather_finish(self._h))
 
+    def tile_allgather_begin_external(self, aovs=(0,)):
+        """the pipeline of tile_allgather_begin with the exchange left to the caller (exchange_buffers); no communicator needed"""
+        self._check(self._lib.hala_rt_tile_allgather_begin_external(self._h, C.c_uint32(sum(1 << a for a in aovs))))
+
+    def exchange_buffers(self, which=0):
+        """-> (staged ptr, staged bytes, receive ptr, receive bytes, exchange hipStream_t) of the exchange in flight"""
+        a = C.c_void_p(); na = C.c_size_t(); b = C.c_void_p(); nb = C.c_size_t(); st = C.c_void_p()
+        self._check(self._lib.hala_rt_get_exchange_buffers(self._h, C.c_int(which), C.byref(a), C.byref(na), C.byref(b), C.byref(nb), C.byref(st)))
+        return a.value, na.value, b.value, nb.value, st.value
+
     def gathered_buffer(self, which=0):
         p = C.c_void_p(); n = C.c_size_t()
         self._check(self._lib.hala_rt_get_gathered_buffer(self._h, C.c_int(which), C.byref(p), C.byref(n)))

@@ -458,7 +458,9 @@ int hala_rt_get_stream(hala_rt_renderer* r, void** hip_stream);
 int hala_rt_scatter_gathered_tiles(hala_rt_renderer* r, int which, const void* d_gathered, size_t bytes);
 
 /* The exchange step itself (ncclAllGather over xGMI), inside the library so that a Rust / C host has a multi-GPU
- * path without any Python: libhalart.so links librccl.  One process (or thread) per GPU; every rank calls the same sequence.
+ * path without any Python.  librccl is resolved on the first hala_rt_comm_* call (dlopen; the instance already in the process is
+ * preferred, so a communicator handed to hala_rt_comm_attach meets the RCCL it came from): a host that renders on one GPU loads
+ * libhalart.so without RCCL installed.  One process (or thread) per GPU; every rank calls the same sequence.
  *   hala_rt_comm_unique_id   : ncclGetUniqueId — rank 0 makes the 128-byte id and hands it to the other ranks over the host
  *                               application's own channel (MPI, a socket, torch.distributed.broadcast ...)
  *   hala_rt_comm_init_rank   : ncclCommInitRank on the renderer's device; rank / world must equal hala_rt_set_tile_shard's.
@@ -471,7 +473,13 @@ int hala_rt_scatter_gathered_tiles(hala_rt_renderer* r, int which, const void* d
  *                               starts the collective; it runs beside the rendering of frame k + 1 until finish() — called by the
  *                               next begin(), or explicitly — de-interleaves.  xGMI is point-to-point: a ring all-gather of
  *                               N x 33 MB is bound by one link per hop and can take as long as rendering a rank's share.
- *   hala_rt_get_gathered_buffer: the [world][tiles_per_rank][ts][ts][4] receive buffer of the last collective (tests). */
+ *   hala_rt_get_gathered_buffer: the [world][tiles_per_rank][ts][ts][4] receive buffer of the last collective (tests).
+ *   hala_rt_tile_allgather_begin_external + hala_rt_get_exchange_buffers: the same pipeline with the exchange done by the CALLER —
+ *                               another transport (MPI, a CPU rehearsal of N ranks on one GPU), no communicator needed: begin_external
+ *                               snapshots the tile buffers exactly like _begin; the caller then moves every rank's staging buffer
+ *                               (rank k's at offset k x staged_bytes) into the receive buffer, stream-ordered on the exchange stream
+ *                               the call returns, and calls _finish.
+ * hala_rt_set_tile_shard completes a collective in flight and refuses to change rank / world while a communicator is attached. */
 #define HALA_COMM_UNIQUE_ID_BYTES 128
 int hala_rt_comm_unique_id(void* out_128_bytes);
 int hala_rt_comm_init_rank(hala_rt_renderer* r, const void* unique_id_128_bytes, uint32_t rank, uint32_t world);
@@ -481,6 +489,9 @@ int hala_rt_tile_allgather(hala_rt_renderer* r, uint32_t aov_mask);
 int hala_rt_tile_allgather_begin(hala_rt_renderer* r, uint32_t aov_mask);
 int hala_rt_tile_allgather_finish(hala_rt_renderer* r);
 int hala_rt_get_gathered_buffer(hala_rt_renderer* r, int which, void** d_ptr, size_t* bytes);
+int hala_rt_tile_allgather_begin_external(hala_rt_renderer* r, uint32_t aov_mask);
+int hala_rt_get_exchange_buffers(hala_rt_renderer* r, int which, void** d_staged, size_t* staged_bytes, void** d_receive, size_t* receive_bytes,
+                                 void** hip_stream);
 /* the same launched on a stream of the caller's (NULL: the renderer's): the de-interleave of frame k can then run beside the rendering
  * of frame k + 1.  The caller orders it against the renderer's stream (hala_rt_get_stream) before anything reads the images. */
 int hala_rt_scatter_gathered_tiles_on_stream(hala_rt_renderer* r, int which, const void* d_gathered, size_t bytes, void* hip_stream);
@@ -491,7 +502,8 @@ int hala_rt_scatter_gathered_tiles_on_stream(hala_rt_renderer* r, int which, con
  * ---------------------------------------------------------------------------------------------- */
 typedef struct hala_ray {
   float origin[3];
-  float tmin;
+  float tmin;        /* a negative tmin is clamped to +0 when the ray is set up (RENDER_SPEC 4.2: rays start at or after their origin) —
+                      * in every traversal variant, whatever the scene's size */
   float direction[3];
   float tmax;
 } hala_ray; /* 32 B */

@@ -262,3 +262,83 @@ def test_sharded_render_equals_unsharded(halart, world):
         last.scatter_gathered_tiles(k, gathered.data_ptr(), gathered.numel() * 4)
         assert np.array_equal(last.read_image(k), ref_imgs[k])
     last.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 8])
+def test_emulated_ranks_through_the_librarys_own_exchange_pipeline(halart, world):
+    """the world > 1 leg of hala_rt_tile_allgather_begin / _finish on a one-GPU box: every emulated rank renders its share; on ONE of
+    them the library's own pipeline runs — begin_external (stream-ordered snapshot into the staging buffer, receive buffer sized
+    world x n), the exchange done by the test (device-to-device copies of every rank's staging buffer into the receive buffer, on the
+    library's exchange stream), finish() (de-interleave of the receive buffer by k_scatter_tiles on that stream, full_valid, the
+    renderer's stream waits) — pipelined: the next frame is enqueued before finish().  read_image must equal the unsharded frame."""
+    import torch
+    w, h, ts = 200, 120, 32
+    scene = scenes.cornell_box(aspect=w / h)
+    ref = halart.HalaRenderer("ref", w, h, 5, 3, False, False, False, 0)
+    ref.set_scene(scene); ref.commit()
+    ranks = []
+    for rank in range(world):
+        r = halart.HalaRenderer("shard", w, h, 5, 3, False, False, False, 0)
+        r.set_tile_shard(rank, world, ts)
+        r.set_scene(scene); r.commit()
+        ranks.append(r)
+    me = ranks[world - 1]
+    want = []
+    for frame, spp in enumerate((2, 1, 3)):
+        ref.reset_accumulation(); ref.update_batch(spp)
+        want.append([ref.read_image(k) for k in (ref.ACCUM, ref.NORMAL)])
+    for frame, spp in enumerate((2, 1, 3)):
+        for r in ranks:
+            r.reset_accumulation(); r.update_batch(spp)
+        aovs = (me.ACCUM, me.NORMAL)
+        for r in ranks:
+            r.tile_allgather_begin_external(aovs)  # every rank snapshots; `me` is the one whose receive buffer is filled
+        if frame + 1 < 3:  # the next frame overwrites the tile buffers while the exchange is still open
+            me.reset_accumulation(); me.update_batch(1)
+        for which in aovs:
+            _, sn, rp, rn, stream = me.exchange_buffers(which)
+            assert rn == sn * world
+            ext = torch.cuda.ExternalStream(stream, device="cuda:0")
+            recv = torch.as_tensor(halart.dist._DeviceView(rp, rn // 4), device="cuda:0")
+            for k, r in enumerate(ranks):
+                sp, sn_k, _, _, stream_k = r.exchange_buffers(which)
+                torch.cuda.ExternalStream(stream_k, device="cuda:0").synchronize()  # rank k's snapshot is complete
+                staged = torch.as_tensor(halart.dist._DeviceView(sp, sn_k // 4), device="cuda:0")
+                with torch.cuda.stream(ext):
+                    recv[k * (sn // 4):(k + 1) * (sn // 4)].copy_(staged)
+        for r in ranks:
+            r.tile_allgather_finish()
+        for j, which in enumerate(aovs):
+            assert np.array_equal(me.read_image(which), want[frame][j]), (frame, which)
+    with pytest.raises(halart.HalaRendererError, match="No exchange of this image is in flight"):
+        me.exchange_buffers(me.ACCUM)
+    for r in ranks:
+        r.close()
+    ref.close()
+
+
+@pytest.mark.gpu
+def test_tile_shard_change_with_a_communicator_or_a_gather_in_flight(halart):
+    """hala_rt_set_tile_shard: a communicator is bound to (rank, world) — changing them under it is refused (the receive buffer is sized
+    by the communicator, the de-interleave indexes it by the shard); a gather in flight is completed before the buffers are re-laid"""
+    r = halart.HalaRenderer("reshard", 96, 64, 4, 2, False, False, False, 0)
+    r.set_scene(scenes.cornell_box(aspect=1.5)); r.commit()
+    r.comm_init_rank(halart.HalaRenderer.comm_unique_id(), 0, 1)
+    with pytest.raises(halart.HalaRendererError, match="call hala_rt_comm_destroy before changing the tile shard"):
+        r.set_tile_shard(0, 2, 32)
+    r.set_tile_shard(0, 1, 16)  # same rank / world: allowed
+    r.commit()
+    r.update()
+    r.tile_allgather_begin((r.ACCUM,))
+    r.comm_destroy()
+    r.set_tile_shard(1, 2, 32)  # completes / drops what was pending, re-lays the buffers
+    r.commit()
+    r.update()
+    r.tile_allgather_begin_external((r.ACCUM,))
+    _, sn, _, rn, _ = r.exchange_buffers(r.ACCUM)
+    assert rn == 2 * sn
+    r.set_tile_shard(0, 4, 32)  # finishes the open exchange first (its receive buffer belongs to the old world size)
+    with pytest.raises(halart.HalaRendererError, match="No exchange of this image is in flight"):
+        r.exchange_buffers(r.ACCUM)
+    r.close()

@@ -103,3 +103,13 @@ def test_rtprog_desc_parser(halart):
         halart.HalaRayTracingProgramDesc.from_json('{"raygen_shader_file_paths": ["r"]}')
     with pytest.raises(halart.HalaRendererError):
         halart.HalaRayTracingProgramDesc.from_json('{"raygen_shader_file_paths": ["r"], "hit_shader_file_paths": [] trailing')
+
+
+def test_library_has_no_load_time_dependency_on_rccl_or_roctx():
+    """RCCL and the profiler's marker library are resolved on first use (csrc/dyn_api.h): a one-GPU host loads libhalart.so without
+    either installed"""
+    import subprocess
+    import hala_renderer_amd as H
+    out = subprocess.run(["readelf", "-d", H.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    needed = [l.split("[")[1].split("]")[0] for l in out.splitlines() if "(NEEDED)" in l]
+    assert needed and not [n for n in needed if "rccl" in n or "roctx" in n or "rocprofiler" in n], needed
