@@ -113,8 +113,11 @@ class Run:
             self.dist.barrier()
         self.torch.cuda.synchronize()
 
-    def measure(self, steps, warmup, timing_period=1):
+    def measure(self, steps, warmup, timing_period=1, fusion=2):
+        """fusion 2: the timed frames run the same fused launches as the untimed ones (traverse_fused_* statistics);
+        fusion 0: one launch per pass (traverse_closest_* / traverse_shadow_*: each symbol with the chip to itself)"""
         r = self.r
+        r.set_pass_fusion(fusion)
         r.set_launch_timing_period(timing_period)
         for _ in range(warmup):
             self.step()
@@ -131,6 +134,7 @@ class Run:
     def count(self):
         """one extra frame with the counting kernels (identical traversal; tests pin those counts to the oracle's)"""
         r = self.r
+        r.set_pass_fusion(0)
         r.set_launch_timing_period(1)
         r.set_counting(True)
         c0 = r.statistics()
@@ -144,11 +148,15 @@ class Run:
         self.r.close()
 
 
-def kernel_report(dt_stats, counts, staged):
-    """per-kernel-symbol figures from the timed launches (s0, s1) and the counting frame (c0, c1)"""
-    s0, s1 = dt_stats
+def kernel_report(timed_stats, unfused_stats, counts, staged, steps):
+    """per-kernel-symbol figures.  timed_stats (s0, s1): the timed region — its timed frames ran fused launches (traverse_fused_*);
+    unfused_stats (u0, u1): frames with one launch per pass (each symbol with the chip to itself); counts (c0, c1): the counting frame
+    (nodes visited / triangles tested per ray kind; same traversal)"""
+    s0, s1 = timed_stats
+    u0, u1 = unfused_stats
     c0, c1 = counts
-    d = lambda name: getattr(s1, name) - getattr(s0, name)  # noqa: E731
+    f = lambda name: getattr(s1, name) - getattr(s0, name)  # noqa: E731
+    d = lambda name: getattr(u1, name) - getattr(u0, name)  # noqa: E731
     c = lambda name: getattr(c1, name) - getattr(c0, name)  # noqa: E731
     st = "true" if staged else "false"
     out = {}
@@ -163,22 +171,36 @@ def kernel_report(dt_stats, counts, staged):
     ms_b = d("traverse_closest_ms_total") - d("traverse_primary_ms_total")
     l_b = d("traverse_closest_launches") - d("traverse_primary_launches")
     rays_b = d("rays_closest_timed") - d("rays_primary_timed")
+    bpr = lambda fixed, nodes, tris: fixed + 64.0 * nodes + 48.0 * tris  # noqa: E731  (algorithmic bytes per ray)
 
     def entry(symbol, what, fixed_bytes, nodes, tris, ms, launches, rays):
-        bpr = fixed_bytes + 64.0 * nodes + 48.0 * tris
+        b = bpr(fixed_bytes, nodes, tris)
         avg = ms / max(launches, 1)
         rpl = rays / max(launches, 1)
-        ach = bpr * rpl / (avg * 1e-3) / 1e9 if avg > 0 else 0.0
-        return {"kernel": symbol, "what": what, "bytes_per_ray": round(bpr, 1), "nodes_per_ray": round(nodes, 3), "tris_per_ray": round(tris, 3),
+        ach = b * rpl / (avg * 1e-3) / 1e9 if avg > 0 else 0.0
+        return {"kernel": symbol, "what": what, "bytes_per_ray": round(b, 1), "nodes_per_ray": round(nodes, 3), "tris_per_ray": round(tris, 3),
                 "avg_launch_ms": round(avg, 5), "launches": int(launches), "rays_per_launch": round(rpl, 1),
                 "grays_per_s_in_kernel": round(rays / max(ms, 1e-9) / 1e6, 3), "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4)}
 
     out["batch"] = entry(f"rt::k_trace_batch<false, false, {st}, false>", "closest-hit traversal of the bounce-ray queues (depth >= 1): 32 B ray read + 16 B hit write per ray",
                          48.0, nodes_b, tris_b, ms_b, l_b, rays_b)
     out["primary"] = entry(f"rt::k_trace_primary<false, {st}>", "depth 0: camera rays generated in the lanes that trace them, 16 B hit write per ray",
-                           16.0, nodes_p, tris_p, d("traverse_primary_ms_total"), d("traverse_primary_launches"), d("rays_primary_timed"))
+                           16.0, nodes_p, tris_p, f("traverse_primary_ms_total") + d("traverse_primary_ms_total"),
+                           f("traverse_primary_launches") + d("traverse_primary_launches"), f("rays_primary_timed") + d("rays_primary_timed"))
     out["shadow"] = entry(f"rt::k_trace_shadow<false, {st}, false>", "any-hit traversal of the NEE connections: 48 B entry + 12 B radiance read per connection (+ 12 B add when unoccluded)",
                           60.0, nodes_s, tris_s, d("traverse_shadow_ms_total"), d("traverse_shadow_launches"), d("rays_shadow_timed"))
+    # the fused launch: both shadow passes of bounce d + the closest-hit pass of bounce d + 1 — the symbol that dominates a frame
+    rfc, rfs = f("rays_fused_closest_timed"), f("rays_fused_shadow_timed")
+    ms_f, l_f = f("traverse_fused_ms_total"), f("traverse_fused_launches")
+    bytes_f = rfc * bpr(48.0, nodes_b, tris_b) + rfs * bpr(60.0, nodes_s, tris_s)
+    ach_f = bytes_f / (ms_f * 1e-3) / 1e9 if ms_f > 0 else 0.0
+    out["fused"] = {"kernel": f"rt::k_trace_shadow_then_batch<{st}, false>",
+                    "what": "ONE persistent launch per bounce: the light and environment connections of bounce d (any hit) and the bounce rays of bounce d + 1 (closest hit)",
+                    "bytes_per_ray": {"bounce_ray": round(bpr(48.0, nodes_b, tris_b), 1), "connection": round(bpr(60.0, nodes_s, tris_s), 1)},
+                    "rays_per_launch": {"bounce_rays": round(rfc / max(l_f, 1), 1), "connections": round(rfs / max(l_f, 1), 1)},
+                    "algorithmic_bytes_per_launch": round(bytes_f / max(l_f, 1), 1),
+                    "avg_launch_ms": round(ms_f / max(l_f, 1), 5), "launches": int(l_f),
+                    "grays_per_s_in_kernel": round((rfc + rfs) / max(ms_f, 1e-9) / 1e6, 3), "achieved": round(ach_f, 1), "frac": round(ach_f / HBM_PEAK_GBS, 4)}
     simt = {}
     for kind in ("closest", "shadow"):
         ws = max(c(f"wave_steps_{kind}_total"), 1)
@@ -186,11 +208,27 @@ def kernel_report(dt_stats, counts, staged):
         simt[kind] = {"node_path_lanes_of_64": round(c(f"nodes_{kind}_total") / ws, 1), "leaf_passes_per_wave_step": round(c(f"leaf_passes_{kind}_total") / ws, 2),
                       "leaf_path_lanes_of_64": round(c(f"leaf_lanes_{kind}_total") / lp, 1)}
     out["simt"] = simt
-    out["shade"] = {"kernel": "rt::k_shade<PRIMARY>", "avg_launch_ms": round(d("shade_ms_total") / max(d("shade_launches"), 1), 5), "launches": int(d("shade_launches"))}
-    frames = max(d("traverse_primary_launches"), 1)  # one depth-0 launch per timed wavefront pass (= frame)
-    out["ms_per_frame_by_kernel"] = {"closest": round(d("traverse_closest_ms_total") / frames, 4), "shade": round(d("shade_ms_total") / frames, 4),
-                                      "shadow": round(d("traverse_shadow_ms_total") / frames, 4), "gpu_total": round(d("gpu_ms_total") / frames, 4)}
+    sh_ms, sh_l = f("shade_ms_total") + d("shade_ms_total"), f("shade_launches") + d("shade_launches")
+    out["shade"] = {"kernel": "rt::k_shade<PRIMARY>", "avg_launch_ms": round(sh_ms / max(sh_l, 1), 5), "launches": int(sh_l)}
+    uf = max(d("traverse_primary_launches"), 1)  # frames with one launch per pass
+    ff = max(f("traverse_primary_launches"), 1)  # timed frames of the timed region (fused launches)
+    out["ms_per_frame_by_kernel"] = {
+        "one_launch_per_pass": {"closest": round(d("traverse_closest_ms_total") / uf, 4), "shade": round(d("shade_ms_total") / uf, 4),
+                                "shadow": round(d("traverse_shadow_ms_total") / uf, 4), "frames": int(uf)},
+        "fused_launches": {"primary": round(f("traverse_primary_ms_total") / ff, 4), "shade": round(f("shade_ms_total") / ff, 4),
+                           "fused_traversal": round(ms_f / ff, 4), "last_bounce_shadow": round(f("traverse_shadow_ms_total") / ff, 4), "frames": int(ff)},
+        "gpu_total": round(f("gpu_ms_total") / max(steps, 1), 4)}  # frame begin -> frame end events, all frames of the timed region
     return out
+
+
+def valu_note(counters):
+    """what binds the traversal kernels: VALU issue slots x active lanes (PMC, committed with the source hash it was collected from)"""
+    if not counters or counters.get("valu_issue_utilisation") is None or counters.get("active_lanes_per_valu_instruction") is None:
+        return None
+    util, lanes = counters["valu_issue_utilisation"], counters["active_lanes_per_valu_instruction"]
+    return {"issue_utilisation": util, "active_lanes_of_64": lanes, "lane_issue_frac": round(util * lanes / 64.0, 4),
+            "note": "SQ_ACTIVE_INST_VALU / (4 x SQ_BUSY_CU_CYCLES) x SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU / 64: the share of the chip's vector "
+                    "lane-issue capacity doing work — the limit that binds these kernels (the tree is cache-resident)"}
 
 
 def main():
@@ -202,12 +240,24 @@ def main():
     ap.add_argument("--no-secondary", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python3 bench.py --gpus N` from a bare shell: start the N ranks ourselves, exactly as the driver would (one process per GPU
+        # under torch.distributed.run, rendezvous on 127.0.0.1).  This parent never touches the GPU (no torch import, no HIP call): it
+        # only waits for the launcher — a child process, not an exec — and passes rank 0's JSON line and the exit code on.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if args.gpus != 1 or world != 1:
-            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node must equal --gpus")
 
     import torch
 
@@ -239,7 +289,7 @@ def main():
     # issues one launch per pass, the others fuse the shadow passes of a bounce with the next bounce's closest-hit pass (renderer.hip)
     # (two timed frames from 8 steps on, else exactly one: any `p` consecutive updates hold one multiple of `p`)
     period = int(os.environ.get("BENCH_TIMING_PERIOD", str(args.steps // 2 if args.steps >= 8 else max(1, args.steps))))
-    dt, s0, s1 = run.measure(args.steps, args.warmup, timing_period=period)
+    dt, s0, s1 = run.measure(args.steps, args.warmup, timing_period=period, fusion=2)
     rays_local = s1.rays_total - s0.rays_total
     t_local = torch.tensor([dt, float(rays_local)], dtype=torch.float64, device=f"cuda:{local_rank}")
     if dist is not None:
@@ -252,16 +302,20 @@ def main():
         dt_all, rays_all = dt, float(rays_local)
 
     # ---- roofline of the dominant kernel (rank 0's launches), from this run's own counts and launch times --------------
+    # outside the timed region: two frames with one launch per pass (every traversal symbol timed with the chip to itself), then one
+    # frame with the counting kernels
+    _, u0, u1 = run.measure(2, 0, timing_period=1, fusion=0)
     counts = run.count()
     info = run.r.bvh_info()
     staged = info.lds_node_count > 0
-    kr = kernel_report((s0, s1), counts, staged)
+    kr = kernel_report((s0, s1), (u0, u1), counts, staged, args.steps)
 
     out = None
     if rank == 0:
         traffic = None
-        tnote = "not collected in this run (PMC counters need rocprofv3: scripts/profile_round.sh writes profiles/r02_traffic_config3.json)"
-        tpath = os.path.join(ROOT, "profiles", "r02_traffic_config3.json")
+        tfile = "profiles/r03_traffic_config3.json"
+        tnote = f"not collected in this run (PMC counters need rocprofv3: scripts/profile_round.sh writes {tfile})"
+        tpath = os.path.join(ROOT, tfile)
         if index == 3 and os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
@@ -269,29 +323,35 @@ def main():
                     traffic = tj
                     tnote = f"collected by scripts/profile_round.sh from this exact source (hash {tj.get('source_hash')}, commit {tj.get('commit')}), separate --pmc passes, guide's gfx950 correction"
                 else:
-                    tnote = f"profiles/r02_traffic_config3.json was collected from other sources (hash {tj.get('source_hash')} != {source_hash()}): not quoted"
+                    tnote = f"{tfile} was collected from other sources (hash {tj.get('source_hash')} != {source_hash()}): not quoted"
             except Exception as e:  # noqa: BLE001
                 tnote = f"unreadable: {e}"
-        b = kr["batch"]
-        tb = traffic["hbm_bytes_per_launch"] if traffic else None
+        # the symbol that dominates a frame: the fused launch (both shadow passes of bounce d + the closest-hit pass of bounce d + 1),
+        # timed by HIP events on the renderer's stream inside the timed region; the unfused symbols are listed beside it
+        b = kr["fused"] if kr["fused"]["launches"] else kr["batch"]
+        tb = traffic["hbm_bytes_per_launch"] if traffic and traffic.get("kernel", "").startswith(b["kernel"].split("<")[0]) else None
+        counters = ({k: traffic.get(k) for k in ("l2_hit_rate", "valu_issue_utilisation", "active_lanes_per_valu_instruction", "wait_any_share_of_wave_cycles",
+                                                "FETCH_SIZE_KB_per_launch", "WRITE_SIZE_KB_per_launch")} if traffic else None)
         roof = {"bound": "hbm", "kernel": b["kernel"] + " — " + b["what"],
                 "achieved": b["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b["frac"],
                 "traffic": tb, "traffic_note": tnote,
                 "traffic_GBps": (round(tb / (b["avg_launch_ms"] * 1e-3) / 1e9, 1) if tb and b["avg_launch_ms"] > 0 else None),
                 "traffic_frac_of_peak": (round(tb / (b["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if tb and b["avg_launch_ms"] > 0 else None),
-                "counters": ({k: traffic.get(k) for k in ("l2_hit_rate", "valu_issue_utilisation", "active_lanes_per_valu_instruction", "FETCH_SIZE_KB_per_launch", "WRITE_SIZE_KB_per_launch")} if traffic else None),
-                "note": "achieved = ALGORITHMIC bytes per ray (SURVEY 8d formula with this library's formats: 64 B per 4-wide node visited, 48 B per "
-                        "triangle tested, + the ray / hit record bytes) x rays per launch / average launch time of this kernel symbol; node and triangle counts "
-                        "come from one extra frame with the counting kernels in this run; avg_launch_ms from HIP events on the renderer's stream around "
-                        "every launch of every `timing_period`-th frame of the timed region (`launches` = the launches so measured; "
-                        "profiles/r02_*_kernel_stats_bench.csv holds the rocprofv3 average of the same command). The tree "
+                "counters": counters,
+                "valu": valu_note(counters),
+                "note": "achieved = ALGORITHMIC bytes (SURVEY 8d formula with this library's formats: 64 B per 4-wide node visited, 48 B per triangle tested, "
+                        "+ the ray / hit / connection record bytes; per ray kind) x the rays the launches traced from each queue / the time of those launches: "
+                        "HIP events on the renderer's stream around every launch of every `timing_period`-th frame of the timed region (`launches` = the "
+                        "launches so measured; profiles/r03_*_kernel_stats_bench.csv holds the rocprofv3 average of the same command).  Node and "
+                        "triangle counts per ray kind come from one extra frame with the counting kernels in this run.  The tree "
                         f"({info.node_count * 64 / 1e6:.0f} MB of nodes + {info.triangle_count * 48 / 1e6:.0f} MB of triangles) sits in L2 / Infinity Cache, so `traffic` (fabric bytes by PMC) is far below the algorithmic bytes: "
-                        "frac prices useful work against the HBM peak, traffic_frac_of_peak is what the memory side really carries; the kernels are "
-                        "VALU-issue bound (`simt`: active lanes per wave on the two code paths).",
-                "bytes_per_ray": b["bytes_per_ray"], "nodes_per_ray": b["nodes_per_ray"], "tris_per_ray": b["tris_per_ray"],
-                "avg_launch_ms": b["avg_launch_ms"], "launches": b["launches"], "timing_period": period, "rays_per_launch": b["rays_per_launch"],
-                "grays_per_s_in_kernel": b["grays_per_s_in_kernel"], "simt": kr["simt"],
-                "primary_kernel": kr["primary"], "shadow_kernel": kr["shadow"], "shade_kernel": kr["shade"],
+                        "frac prices useful work against the HBM peak — a work rate, not a distance to a hardware limit; traffic_frac_of_peak is what the memory side really carries; "
+                        "`valu` is the limit that binds (vector issue slots x active lanes); `simt`: active lanes per wave on the two code paths.",
+                "bytes_per_ray": b["bytes_per_ray"], "avg_launch_ms": b["avg_launch_ms"], "launches": b["launches"], "timing_period": period,
+                "rays_per_launch": b["rays_per_launch"], "grays_per_s_in_kernel": b["grays_per_s_in_kernel"], "simt": kr["simt"],
+                "unfused_kernels": {"note": "two extra frames with one launch per pass (hala_rt_set_pass_fusion 0), outside the timed region: every symbol timed with the chip to itself",
+                                    "batch": kr["batch"], "shadow": kr["shadow"]},
+                "primary_kernel": kr["primary"], "shade_kernel": kr["shade"],
                 "ms_per_frame_by_kernel": kr["ms_per_frame_by_kernel"]}
         out = {
             "metric": "Mrays/s", "value": round(rays_all / dt_all / 1e6, 2), "unit": "Mrays/s",
@@ -318,15 +378,15 @@ def main():
             c4 = workloads.baseline_config(4)
             c4["scene"], c4["env"] = cfg["scene"], cfg["env"]  # same scene objects (16:9 either way)
             r4 = Run(H, c4, local_rank, 0, 1, None, torch)
-            d4, a0, a1 = r4.measure(3, 1)
+            d4, a0, a1 = r4.measure(3, 1, timing_period=0)
             secondary["configs4_on_1_gpu"] = {"workload": c4["name"] + " on ONE GPU (no shard, no collective)", "steps": 3,
                                               "value": round((a1.rays_total - a0.rays_total) / d4 / 1e6, 2), "unit": "Mrays/s", "ms_per_frame": round(d4 / 3 * 1e3, 3)}
             r4.close()
             # configs[1]: the 32-triangle Cornell box whose BVH lives in LDS (round 1's headline)
             c1 = workloads.baseline_config(1)
             r1 = Run(H, c1, local_rank, 0, 1, None, torch)
-            d1, b0, b1 = r1.measure(20, 3, timing_period=4)
-            k1 = kernel_report((b0, b1), r1.count(), True)
+            d1, b0, b1 = r1.measure(20, 3, timing_period=4, fusion=1)  # its timed frames: one launch per pass
+            k1 = kernel_report((b0, b0), (b0, b1), r1.count(), True, 20)
             secondary["configs1"] = {"workload": c1["name"], "steps": 20, "value": round((b1.rays_total - b0.rays_total) / d1 / 1e6, 2), "unit": "Mrays/s",
                                      "ms_per_frame": round(d1 / 20 * 1e3, 4),
                                      "batch_kernel": k1["batch"], "shadow_kernel": k1["shadow"], "shade_kernel": k1["shade"], "simt": k1["simt"],

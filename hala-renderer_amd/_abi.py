@@ -155,7 +155,9 @@ class RtStatistics(C.Structure):
                 ("nodes_primary_total", C.c_uint64), ("tris_primary_total", C.c_uint64), ("rays_primary_counted", C.c_uint64),
                 ("rays_primary_total", C.c_uint64),
                 ("rays_closest_timed", C.c_uint64), ("rays_primary_timed", C.c_uint64), ("rays_shadow_timed", C.c_uint64),
-                ("shade_ms_total", C.c_double), ("shade_launches", C.c_uint64)]
+                ("shade_ms_total", C.c_double), ("shade_launches", C.c_uint64),
+                ("traverse_fused_ms_total", C.c_double), ("traverse_fused_launches", C.c_uint64),
+                ("rays_fused_closest_timed", C.c_uint64), ("rays_fused_shadow_timed", C.c_uint64)]
 
 
 class BuildOptions(C.Structure):  # hala_rt_build_options
@@ -191,7 +193,7 @@ EXPORTS = [
     "hala_rt_set_envmap_file", "hala_rt_set_ground_color", "hala_rt_set_sky_color",
     "hala_rt_set_env_intensity", "hala_rt_set_exposure_value", "hala_rt_commit", "hala_rt_set_build_options", "hala_rt_update", "hala_rt_update_batch",
     "hala_rt_render", "hala_rt_wait_idle", "hala_rt_save_images", "hala_rt_read_image",
-    "hala_rt_get_info", "hala_rt_get_statistics", "hala_rt_set_counting", "hala_rt_set_launch_timing_period", "hala_rt_reset_accumulation", "hala_rt_get_global_uniform",
+    "hala_rt_get_info", "hala_rt_get_statistics", "hala_rt_set_counting", "hala_rt_set_launch_timing_period", "hala_rt_set_pass_fusion", "hala_rt_reset_accumulation", "hala_rt_get_global_uniform",
     "hala_rt_get_packed_cameras", "hala_rt_get_packed_lights", "hala_rt_get_packed_materials",
     "hala_rt_get_packed_primitives", "hala_rt_get_env_distribution", "hala_rt_get_texture_info",
     "hala_rt_read_texture_level", "hala_rt_sample_texture_host", "hala_rt_set_tile_shard",

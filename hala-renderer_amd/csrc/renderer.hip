@@ -87,6 +87,10 @@ struct TraceEvents {
   bool pending = false, counted = false;
   uint32_t samples = 1;  // frames rendered by this wavefront pass
   uint32_t shadow_launches = 0;  // k_trace_shadow launches inside the timed brackets of this pass (0, 1 or 2 per depth)
+  // timed passes: bit d of fused_mask = the third bracket of depth d holds a fused launch (k_trace_shadow_then_batch); bit d of
+  // traced_mask = the closest-hit pass of depth d ran inside depth d - 1's fused launch (its own bracket is empty)
+  unsigned long long fused_mask = 0, traced_mask = 0;
+  uint32_t* host_queue_sizes = nullptr;  // pinned: the head of the control block (n_active | n_shadow) as the pass left it
   unsigned long long* host_counts = nullptr;  // pinned: rays_closest, rays_shadow, steps[2][2], probe[2][3]
 };
 
@@ -140,7 +144,7 @@ struct hala_rt_renderer {
   float ray_eps = 0.0f;
   DeviceArray<uint2> d_spill;
   LaunchCfg lcfg{};
-  bool fuse_passes = true;  // untimed updates: shadow pass of bounce d + closest-hit pass of bounce d + 1 in one launch
+  uint32_t fuse_mode = 1;  // hala_rt_set_pass_fusion: 0 never, 1 untimed updates, 2 always (shadow passes of bounce d + closest-hit pass of bounce d + 1 in one launch)
 
   bool has_env = false;
   uint32_t env_w = 0, env_h = 0;
@@ -179,7 +183,7 @@ struct hala_rt_renderer {
   bool any_translucent = false; // ... translucent ones: the ALPHA variants of the any-hit kernels
   DeviceArray<uint8_t> d_material_any_class;
   std::vector<uint8_t> material_any_class;
-  uint32_t launch_event_period = 1;  // per-launch timing events on every n-th update (hala_rt_set_launch_timing_period)
+  uint32_t launch_event_period = 0;  // per-launch timing events on every n-th update (hala_rt_set_launch_timing_period; 0: none)
   unsigned long long update_counter = 0;
   hala_rt_statistics stats{};
   // update() and trace_rays() share per-renderer scratch (work counters, step counters, the stack spill area): launches that use it
@@ -208,6 +212,7 @@ struct hala_rt_renderer {
       if (t.frame_begin) (void)hipEventDestroy(t.frame_begin);
       if (t.frame_end) (void)hipEventDestroy(t.frame_end);
       if (t.host_counts) (void)hipHostFree(t.host_counts);
+      if (t.host_queue_sizes) (void)hipHostFree(t.host_queue_sizes);
     }
     if (batch_done) (void)hipEventDestroy(batch_done);
     if (gather_stream) { (void)hipStreamSynchronize(gather_stream); (void)hipStreamDestroy(gather_stream); }
@@ -266,24 +271,38 @@ struct hala_rt_renderer {
     (void)hipEventSynchronize(t.frame_end);
     float ms = 0.0f;
     if (hipEventElapsedTime(&ms, t.frame_begin, t.frame_end) == hipSuccess) { stats.last_gpu_ms = ms; stats.gpu_ms_total += ms; }
-    // four events per depth: a | closest-hit launch | b | shade launch | c | shadow launch(es) | d
-    double tr[2] = {0.0, 0.0}, sh = 0.0;
-    for (size_t k = 0; k + 3 < t.used; k += 4) {
+    // four events per depth: a | closest-hit launch | b | shade launch | c | shadow launch(es) or the fused launch | d
+    double tr[3] = {0.0, 0.0, 0.0}, sh = 0.0;  // closest-hit launches, shadow launches, fused launches
+    unsigned long long rays[3] = {0, 0, 0}, launches[3] = {0, 0, 0};
+    const uint32_t* qn = t.host_queue_sizes;  // Control::n_active[kMaxDepth + 1] | n_shadow[2][kMaxDepth] of this pass (timed passes only)
+    for (size_t k = 0, depth = 0; k + 3 < t.used; k += 4, ++depth) {
       float m = 0.0f;
-      if (hipEventElapsedTime(&m, t.ev[k], t.ev[k + 1]) == hipSuccess) {
-        tr[0] += m;
-        if (k == 0) { stats.traverse_primary_ms_total += m; stats.traverse_primary_launches += 1; }  // depth 0: k_trace_primary
+      const bool own_closest = depth == 0 || !((t.traced_mask >> depth) & 1ull);  // else: it ran inside the previous depth's fused launch
+      if (own_closest && hipEventElapsedTime(&m, t.ev[k], t.ev[k + 1]) == hipSuccess) {
+        const unsigned long long n = depth == 0 ? (unsigned long long)real_pixels * t.samples : qn[depth];
+        tr[0] += m; rays[0] += n; launches[0] += 1;
+        if (depth == 0) { stats.traverse_primary_ms_total += m; stats.traverse_primary_launches += 1; stats.rays_primary_timed += n; }  // k_trace_primary
       }
       if (hipEventElapsedTime(&m, t.ev[k + 1], t.ev[k + 2]) == hipSuccess) sh += m;
-      if (hipEventElapsedTime(&m, t.ev[k + 2], t.ev[k + 3]) == hipSuccess) tr[1] += m;
+      if (hipEventElapsedTime(&m, t.ev[k + 2], t.ev[k + 3]) == hipSuccess) {
+        const unsigned long long ns = (unsigned long long)qn[kMaxDepth + 1 + depth] + qn[kMaxDepth + 1 + kMaxDepth + depth];
+        if ((t.fused_mask >> depth) & 1ull) {
+          tr[2] += m; launches[2] += 1;
+          stats.rays_fused_shadow_timed += ns;
+          if ((t.traced_mask >> (depth + 1)) & 1ull) stats.rays_fused_closest_timed += qn[depth + 1];
+        } else { tr[1] += m; rays[1] += ns; }
+      }
     }
-    stats.traverse_ms_last_update = tr[0] + tr[1];
+    stats.traverse_ms_last_update = tr[0] + tr[1] + tr[2];
     stats.traverse_closest_ms_total += tr[0];
     stats.traverse_shadow_ms_total += tr[1];
+    stats.traverse_fused_ms_total += tr[2];
     stats.shade_ms_total += sh;
-    stats.traverse_closest_launches += t.used / 4;
+    stats.traverse_closest_launches += launches[0];
+    stats.traverse_fused_launches += launches[2];
     stats.shade_launches += t.used / 4;
     stats.traverse_shadow_launches += t.used ? t.shadow_launches : 0;  // as issued: one per connection kind the scene has, per depth
+    stats.rays_closest_timed += rays[0]; stats.rays_shadow_timed += rays[1];
     stats.updates_rendered += t.samples;
     const unsigned long long rc = t.host_counts[0], rs = t.host_counts[1];
     stats.rays_last_update = rc + rs;
@@ -291,10 +310,6 @@ struct hala_rt_renderer {
     stats.rays_closest_total += rc;
     stats.rays_primary_total += (unsigned long long)real_pixels * t.samples;
     stats.rays_shadow_total += rs;
-    if (t.used > 0) {
-      stats.rays_closest_timed += rc; stats.rays_shadow_timed += rs;
-      stats.rays_primary_timed += (unsigned long long)real_pixels * t.samples;
-    }
     if (t.counted) {
       stats.nodes_closest_total += t.host_counts[2]; stats.tris_closest_total += t.host_counts[3];
       stats.nodes_shadow_total += t.host_counts[4]; stats.tris_shadow_total += t.host_counts[5];
@@ -642,7 +657,7 @@ int hala_rt_create(const char* name, uint32_t width, uint32_t height, int device
   RT_HIP(hipGetDeviceProperties(&prop, device_ordinal));
   r->cu_count = (uint32_t)prop.multiProcessorCount;
   RT_HIP(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
-  if (const char* ev = tune_env("HALART_FUSE")) r->fuse_passes = atoi(ev) != 0;  // A/B knob
+  if (const char* ev = tune_env("HALART_FUSE")) r->fuse_mode = (uint32_t)std::max(0, std::min(2, atoi(ev)));
   compute_tiling(r.get());
   // create_storage_images (src/rt_renderer.rs:818-917): final, accum, albedo, normal
   if (alloc_frame_buffers(r.get()) != HALA_OK) return HALA_ERR;
@@ -812,7 +827,7 @@ static int update_impl(hala_rt_renderer* r, uint32_t frames) {
   r->ring_pos = (r->ring_pos + 1) % kStatRing;
   r->resolve_slot(te);
   if (!te.frame_begin) { RT_HIP(hipEventCreate(&te.frame_begin)); RT_HIP(hipEventCreate(&te.frame_end)); RT_HIP(hipHostMalloc(reinterpret_cast<void**>(&te.host_counts), 14 * sizeof(unsigned long long), hipHostMallocDefault)); }
-  te.used = 0; te.counted = r->counting; te.shadow_launches = 0;
+  te.used = 0; te.counted = r->counting; te.shadow_launches = 0; te.fused_mask = 0; te.traced_mask = 0;
 
   te.samples = samples;
   const FrameConst fc = r->frame_const(u, samples);
@@ -831,7 +846,9 @@ static int update_impl(hala_rt_renderer* r, uint32_t frames) {
   // The shadow passes of bounce d and the closest-hit traversal of bounce d + 1 are independent: untimed updates issue them as ONE
   // persistent launch (k_trace_shadow_then_batch: one tail of long rays instead of three).  Updates that carry per-launch timing events or
   // counting kernels keep one launch per pass, so that every measured launch is one kernel symbol with the chip to itself.
-  const bool fuse = r->fuse_passes && !timed && !r->counting && (u.num_of_lights > 0 || u.env_type == 1u);
+  const bool fuse = (r->fuse_mode == 2u || (r->fuse_mode == 1u && !timed)) && !r->counting && (u.num_of_lights > 0 || u.env_type == 1u);
+  constexpr size_t kQueueSizeWords = (kMaxDepth + 1) + 2 * kMaxDepth;
+  if (timed && !te.host_queue_sizes) RT_HIP(hipHostMalloc(reinterpret_cast<void**>(&te.host_queue_sizes), kQueueSizeWords * sizeof(uint32_t), hipHostMallocDefault));
   bool traced = false;  // the closest-hit pass of this depth already ran inside the previous depth's fused launch
   for (uint32_t depth = 0; depth < r->max_depth; ++depth) {
     if (timed) { hipEvent_t a = r->next_event(te); RT_HIP(hipEventRecord(a, s)); }
@@ -849,7 +866,10 @@ static int update_impl(hala_rt_renderer* r, uint32_t frames) {
     // other and of the next bounce's closest-hit pass
     const uint32_t kinds = (u.num_of_lights > 0 ? 1u : 0u) | (u.env_type == 1u ? 2u : 0u);
     const bool last = depth + 1u >= r->max_depth;  // no closest-hit pass follows: only worth one launch when there are two shadow passes
-    if (fuse && kinds && (!last || kinds == 3u) && launch_trace_shadow_then_batch(r->lcfg, sv, q, ps, ctl, depth, kinds, !last, s)) traced = !last;
+    if (fuse && kinds && (!last || kinds == 3u) && launch_trace_shadow_then_batch(r->lcfg, sv, q, ps, ctl, depth, kinds, !last, s)) {
+      traced = !last;
+      if (timed) { te.fused_mask |= 1ull << depth; if (traced) te.traced_mask |= 1ull << (depth + 1u); }
+    }
     else
       for (uint32_t kind = 0; kind < 2u; ++kind) {
         if (!((kinds >> kind) & 1u)) continue;
@@ -860,6 +880,7 @@ static int update_impl(hala_rt_renderer* r, uint32_t frames) {
   }
   launch_resolve(fc, ps, r->img_local[0].ptr, r->img_local[1].ptr, r->img_local[2].ptr, r->img_local[3].ptr, s);
   RT_HIP(hipMemcpyAsync(te.host_counts, &ctl->rays_closest, 14 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  if (timed) RT_HIP(hipMemcpyAsync(te.host_queue_sizes, ctl->n_active, kQueueSizeWords * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   RT_HIP(hipEventRecord(te.frame_end, s));
   r->scratch_event = te.frame_end; r->scratch_stream = s;
   RT_HIP(hipGetLastError());
@@ -950,6 +971,12 @@ int hala_rt_set_launch_timing_period(hala_rt_renderer* r, uint32_t period) {
   if (!r) RT_FAIL("The renderer handle is null!");
   r->launch_event_period = period;
   r->update_counter = 0;
+  return HALA_OK;
+}
+int hala_rt_set_pass_fusion(hala_rt_renderer* r, uint32_t mode) {
+  if (!r) RT_FAIL("The renderer handle is null!");
+  if (mode > 2u) RT_FAIL("Invalid pass fusion mode.");
+  r->fuse_mode = mode;
   return HALA_OK;
 }
 int hala_rt_set_counting(hala_rt_renderer* r, int enable) {

@@ -166,6 +166,10 @@ class HalaRenderer:
         """count BVH nodes visited / triangles tested in update() (inputs of the algorithmic-bytes figure)"""
         self._check(self._lib.hala_rt_set_counting(self._h, C.c_int(bool(enable))))
 
+    def set_pass_fusion(self, mode):
+        """0: one launch per pass; 1 (default): fused launches except in timed updates; 2: always (timed updates fill traverse_fused_*)"""
+        self._check(self._lib.hala_rt_set_pass_fusion(self._h, C.c_uint32(mode)))
+
     def set_launch_timing_period(self, period):
         """per-launch HIP events on every `period`-th update (1: all, the default; 0: none) — see include/halart.h"""
         self._check(self._lib.hala_rt_set_launch_timing_period(self._h, C.c_uint32(period)))

@@ -408,6 +408,12 @@ typedef struct hala_rt_statistics {
    * miss, NEE set-up, BSDF sampling, queue compaction) */
   double shade_ms_total;
   uint64_t shade_launches;
+  /* timed updates that ran with fused passes (hala_rt_set_pass_fusion(r, 2)): the launches of k_trace_shadow_then_batch — the shadow
+   * passes of bounce d and the closest-hit pass of bounce d + 1 in one persistent launch — and the rays they traced from each queue
+   * (bounce rays / connections).  Such updates add nothing to traverse_shadow_* and only their depth-0 launch to traverse_closest_*. */
+  double traverse_fused_ms_total;
+  uint64_t traverse_fused_launches;
+  uint64_t rays_fused_closest_timed, rays_fused_shadow_timed;
 } hala_rt_statistics;
 int hala_rt_get_info(hala_rt_renderer* r, hala_rt_info* out);
 int hala_rt_get_statistics(hala_rt_renderer* r, hala_rt_statistics* out);
@@ -419,9 +425,14 @@ int hala_rt_reset_accumulation(hala_rt_renderer* r);
  * triangles tested per ray — the inputs of the algorithmic-bytes figure). Slower; off by default. */
 int hala_rt_set_counting(hala_rt_renderer* r, int enable);
 /* Per-launch timing (the traverse_*_ms_total statistics) brackets every traversal launch with two HIP events, i.e. ~22 barrier
- * packets per update (70 us of a 2.25 ms frame on MI355X).  period = 1 (default): every update is timed; n > 1: every n-th;
- * 0: none.  The frame-level figures (last_gpu_ms, gpu_ms_total, ray counts) are always collected. */
+ * packets per update (70 us of a 2.25 ms frame on MI355X).  period = 0 (default): none; 1: every update is timed; n > 1: every n-th.
+ * The frame-level figures (last_gpu_ms, gpu_ms_total, ray counts) are always collected. */
 int hala_rt_set_launch_timing_period(hala_rt_renderer* r, uint32_t period);
+/* Pass fusion: the shadow passes of bounce d and the closest-hit pass of bounce d + 1 are independent and can run as ONE persistent
+ * launch (one tail of long rays per bounce instead of three).  mode 0: never; 1 (default): every update except the timed ones, which
+ * keep one launch per pass so that every measured launch is one kernel symbol with the chip to itself; 2: always — timed updates then
+ * fill the traverse_fused_* statistics.  Counting updates (hala_rt_set_counting) never fuse.  Images do not depend on the mode. */
+int hala_rt_set_pass_fusion(hala_rt_renderer* r, uint32_t mode);
 /* the 112-B record the last update uploaded (src/rt_renderer.rs:408-427) */
 int hala_rt_get_global_uniform(hala_rt_renderer* r, hala_global_uniform* out);
 

@@ -25,6 +25,7 @@ def run(name, scene, w, h, spp, env=None, max_depth=5, rr_depth=3, steps=8):
     t1 = time.perf_counter()
     r.commit()
     t2 = time.perf_counter()
+    r.set_launch_timing_period(1)  # every update timed: one launch per pass (the per-kernel columns below)
     info = r.bvh_info()
     for _ in range(spp):  # warm-up frame
         r.update()

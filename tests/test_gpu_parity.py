@@ -293,29 +293,44 @@ def test_rtprog_trace_rays_and_indirect(halart, oracle):
     r.close()
 
 
-def test_launch_timing_period(halart):
-    """hala_rt_set_launch_timing_period: per-launch events on every n-th update only; ray totals and frame times are always
-    collected, the *_timed ray counters follow the timed updates, and the image does not depend on it"""
+def test_launch_timing_period_and_pass_fusion(halart):
+    """hala_rt_set_launch_timing_period: per-launch events on every n-th update only (default: none); ray totals and frame times are
+    always collected, the *_timed ray counters follow the timed updates.  hala_rt_set_pass_fusion: 0 one launch per pass, 1 (default)
+    fused launches except in timed updates, 2 always — timed updates then fill traverse_fused_* (the closest-hit pass of depth d + 1
+    runs inside depth d's fused launch; the Cornell box has light connections only, so the last depth keeps its plain shadow launch).
+    The image depends on neither."""
     s = scenes.cornell_box()
     imgs = []
-    for period, timed_updates in ((1, 6), (3, 2), (0, 0)):
+    for period, fusion, timed_updates in ((1, 1, 6), (3, 1, 2), (0, 1, 0), (None, 1, 0), (1, 2, 6), (2, 2, 3), (1, 0, 6), (0, 0, 0)):
         r = make_renderer(halart, s, 64, 48)
-        r.set_launch_timing_period(period)
+        if period is not None:
+            r.set_launch_timing_period(period)
+        r.set_pass_fusion(fusion)
         for _ in range(6):
             r.update(); r.render()
         st = r.statistics()
         imgs.append(r.read_image(0))
         assert st.total_frames == 6 and st.rays_total == st.rays_closest_total + st.rays_shadow_total and st.gpu_ms_total > 0.0
-        assert st.traverse_primary_launches == timed_updates
-        assert st.traverse_closest_launches == timed_updates * 5 and st.traverse_shadow_launches == timed_updates * 5  # max_depth 5
+        assert st.traverse_primary_launches == timed_updates and st.shade_launches == timed_updates * 5  # max_depth 5
         assert st.rays_primary_timed == timed_updates * 64 * 48
-        if period == 1:
-            assert (st.rays_closest_timed, st.rays_shadow_timed) == (st.rays_closest_total, st.rays_shadow_total)
-            assert st.traverse_closest_ms_total > 0.0
-        if period == 0:
+        if fusion == 2:  # timed AND fused: depth 0 has its own closest-hit launch, depths 0..3 end in a fused launch, depth 4 in a shadow launch
+            assert st.traverse_closest_launches == timed_updates and st.traverse_fused_launches == timed_updates * 4
+            assert st.traverse_shadow_launches == timed_updates
+            assert st.rays_closest_timed == st.rays_primary_timed
+            if period == 1:
+                assert st.rays_closest_timed + st.rays_fused_closest_timed == st.rays_closest_total
+                assert st.rays_shadow_timed + st.rays_fused_shadow_timed == st.rays_shadow_total
+                assert st.traverse_fused_ms_total > 0.0 and st.rays_fused_shadow_timed > st.rays_shadow_timed > 0
+        else:
+            assert st.traverse_closest_launches == timed_updates * 5 and st.traverse_shadow_launches == timed_updates * 5
+            assert st.traverse_fused_launches == 0 and st.traverse_fused_ms_total == 0.0 and st.rays_fused_closest_timed == 0
+            if period == 1:
+                assert (st.rays_closest_timed, st.rays_shadow_timed) == (st.rays_closest_total, st.rays_shadow_total)
+                assert st.traverse_closest_ms_total > 0.0
+        if not timed_updates:
             assert st.traverse_closest_ms_total == 0.0 and st.rays_closest_timed == 0
         r.close()
-    assert imgs[0].tobytes() == imgs[1].tobytes() == imgs[2].tobytes()
+    assert all(i.tobytes() == imgs[0].tobytes() for i in imgs[1:])
 
 
 def test_load_blue_noise_texture_from_file(halart, tmp_path):
