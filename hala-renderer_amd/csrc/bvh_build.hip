@@ -259,10 +259,14 @@ __global__ void __launch_bounds__(256) k_hierarchy(const unsigned long long* __r
 __global__ void __launch_bounds__(256) k_leaf_boxes(const Box6* __restrict__ tri_box, const uint32_t* __restrict__ sorted_ids, uint32_t n,
                                                      Box6* __restrict__ leaf_box, const Tri* __restrict__ tris_by_id, Tri* __restrict__ tris, float pad,
                                                      Tri* __restrict__ tris_any, const ShadeTri* __restrict__ shade_tris,
-                                                     const uint8_t* __restrict__ any_class, uint32_t material_count) {
+                                                     const uint8_t* __restrict__ any_class, uint32_t material_count,
+                                                     const uint8_t* __restrict__ material_kind) {
   const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
   const uint32_t id = sorted_ids[k];
+  const uint32_t mat = shade_tris[id].material;
+  // word 11: the shading kind of the triangle's material; the closest-hit traversal puts it into the hit record (hala_types.h: hit_encode)
+  const float kind_word = __uint_as_float(material_kind && mat < material_count ? (uint32_t)material_kind[mat] : kShadeKindSpecial);
   // The slab test's plane distances carry a rounding error of a few ulp of the largest coordinate involved, like the triangle
   // test's own; quantisation usually adds far more slack, but a plane that falls exactly on the grid gets none.  `pad` (2^-19 of
   // the scene's largest coordinate) keeps a hit that lies exactly on a box face inside its box.
@@ -272,17 +276,16 @@ __global__ void __launch_bounds__(256) k_leaf_boxes(const Box6* __restrict__ tri
   leaf_box[k] = b;
   const float4* src = reinterpret_cast<const float4*>(tris_by_id + id);
   float4* dst = reinterpret_cast<float4*>(tris + k);
-  dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+  dst[0] = src[0]; dst[1] = src[1]; dst[2] = make_float4(src[2].x, src[2].y, src[2].z, kind_word);
   if (tris_any) {  // RENDER_SPEC 7.1d: any-hit rays do not see surfaces of opacity exactly 0 — their triangles are degenerate in this copy —
                    // and decide per (ray key, triangle) whether a translucent one blocks them: those carry a flag in word 7
-    const uint32_t mi = shade_tris[id].material;
-    const uint32_t cls = mi < material_count ? any_class[mi] : 0u;
+    const uint32_t cls = mat < material_count ? any_class[mat] : 0u;
     const bool gone = cls == 1u;
     float4* da = reinterpret_cast<float4*>(tris_any + k);
     da[0] = src[0];
     const uint32_t flag = cls == 2u ? 1u : (cls == 3u ? 2u : (cls == 4u ? 3u : 0u));  // bit 0: translucent, bit 1: boundary of a medium (7.1g)
     da[1] = gone ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : make_float4(src[1].x, src[1].y, src[1].z, __uint_as_float(flag));
-    da[2] = gone ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : src[2];
+    da[2] = gone ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : make_float4(src[2].x, src[2].y, src[2].z, kind_word);
   }
 }
 
@@ -948,7 +951,7 @@ static std::string flatten_and_bounds(BvhBuffers& b, BvhTopology& t, hipStream_t
 static std::string fit_and_emit(BvhBuffers& b, BvhTopology& t, hipStream_t s) {
   const uint32_t n = b.tri_count;
   if (n) hipLaunchKernelGGL(k_leaf_boxes, dim3(nblk(n)), dim3(256), 0, s, t.tri_box.as<Box6>(), t.sorted_ids.as<uint32_t>(), n,
-                            t.leaf_box.as<Box6>(), b.tris_by_id, b.tris, box_pad(b), b.tris_any, b.shade_tris, b.material_any_class, b.material_count);
+                            t.leaf_box.as<Box6>(), b.tris_by_id, b.tris, box_pad(b), b.tris_any, b.shade_tris, b.material_any_class, b.material_count, b.material_kind);
   if (n <= t.leaf_max || n < 2) {
     hipLaunchKernelGGL(k_emit_single4, dim3(1), dim3(64), 0, s, t.leaf_box.as<Box6>(), n, b.nodes);
     b.node_count = 1;

@@ -49,10 +49,21 @@ constexpr uint32_t kLeafRef = 0x80000000u;
 // 48-B triangle (RENDER_SPEC §4.1): v0|global id, e1 = v1-v0, e2 = v2-v0 in world space.
 struct alignas(16) Tri {
   float v0[3]; uint32_t id;
-  float e1[3]; uint32_t pad1;
-  float e2[3]; uint32_t pad2;
+  float e1[3]; uint32_t pad1;  // any-hit copy: bit 0 translucent, bit 1 boundary of a medium (RENDER_SPEC 7.1d / 7.1g)
+  float e2[3]; uint32_t pad2;  // BVH-order copies: the shading kind of the triangle's material (kShadeKind*, 1..7) — see hit_encode
 };
 static_assert(sizeof(Tri) == 48, "triangle is 48 B");
+
+// The renderer's own hit queue carries the shading kind of the hit triangle's material next to its id: prim word = id << 3 | kind.  The
+// closest-hit traversal has the triangle's three 16-B words in registers when it accepts a hit (the kind travels in word 11), so the
+// bounce shade can group its paths by kind without touching a shading record first.  id < 2^28 (leaf references), ids are distinct, so
+// encoded words order exactly like ids: the closest-hit tie rule (t, then lower id) is unchanged.  kAbsent (no hit) stays all ones.
+// Ray batches of the C ABI (hala_rt_trace_rays) get the plain id.
+constexpr uint32_t kHitKindBits = 3;
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline uint32_t hit_encode(uint32_t id, uint32_t kind) { return (id << kHitKindBits) | (kind & 7u); }
 
 // 128-B shading record of one triangle (global-id order), 128-B aligned: what the closest-hit stage interpolates, gathered once at
 // build time from the vertex / index arenas so that shading a hit costs ONE dependent 64-B line (untextured materials) or two
@@ -230,6 +241,7 @@ struct Queues {
   hala_ray* rays[2];  // bounce rays; tmin / tmax are implied (0 / FLT_MAX): their fields carry the path slot / the RNG counter
   float4* state[2];  // throughput.xyz | pdf of the last BSDF sample, next to the ray of the same queue entry
   hala_hit* hits;
+  uint32_t* perm;  // bounce launches of multi-kind scenes: the order in which k_shade takes the queue's entries (k_shade_sort: by shading kind inside windows)
   // compact connection queues of the current bounce: [0] light NEE, [1] environment NEE.  A path owns at most one entry
   // per queue, the two queues are traced by consecutive launches, so contributions land in spec order without atomics.
   ShadowEntry* shadow[2];

@@ -219,7 +219,8 @@ struct BatchSource {
     const bool found = t.best.prim != kAbsent;
     float4 out;
     if (any) out = make_float4(found ? 1.0f : -1.0f, 0.0f, 0.0f, __uint_as_float(kAbsent));
-    else out = found ? make_float4(t.best.t, t.best.u, t.best.v, __uint_as_float(t.best.prim)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(kAbsent));
+    // the renderer's own queue keeps id << 3 | shading kind (hala_types.h: hit_encode); a caller's batch gets the plain triangle id
+    else out = found ? make_float4(t.best.t, t.best.u, t.best.v, __uint_as_float(queue ? t.best.prim : t.best.prim >> kHitKindBits)) : make_float4(-1.0f, 0.0f, 0.0f, __uint_as_float(kAbsent));
     if (streaming) st4(reinterpret_cast<float4*>(hits) + i, out);
     else reinterpret_cast<float4*>(hits)[i] = out;
   }
@@ -404,6 +405,68 @@ k_trace_shadow_then_batch(SceneView sv, const Tri* __restrict__ tris_any, Queues
 #define RT_SHADE_WAVES_SIMPLE 6  // 80 VGPRs, no scratch (8 waves: 32-44 B of scratch per lane and slower; profiles/r02_experiments.txt)
 #endif
 // SCATTER: some material holds a scattering medium (§7.1f): only then does the kernel carry the free-flight / phase-function code
+// Bounce launches of scenes whose materials span several shading kinds: the paths of a WINDOW of kSortWindow consecutive queue entries
+// are shaded in the order of their shading kind, so that a wave runs one flavour of the BSDF code.  k_shade_sort writes the order (a
+// permutation of each window: counting sort through LDS; the kind sits in the low bits of the hit record's prim word, so the sort reads
+// nothing but the hit queue), k_shade reads it.  Sorting inside each 256-path workgroup of k_shade left 36 of 64 lanes per vector
+// instruction — a partial wave at every kind boundary of every 4-wave block (profiles/r02_w_pmc_config4.txt); a window of 4096 has the
+// same boundaries per 64 waves.  Which lane shades which path is not observable: every output is indexed by path slot or comes out
+// of the block compaction.
+#ifndef RT_SORT_ROUNDS
+#define RT_SORT_ROUNDS 16
+#endif
+constexpr uint32_t kSortThreads = 256, kSortRounds = RT_SORT_ROUNDS, kSortWindow = kSortThreads * kSortRounds;
+static_assert(kSortWindow <= 65536, "window-relative positions are 16-bit in LDS");
+__global__ void __launch_bounds__(kSortThreads) k_shade_sort(Queues q, const Control* __restrict__ ctl, uint32_t depth) {
+  const uint32_t n = ctl->n_active[depth];
+  const uint32_t base = blockIdx.x * kSortWindow;
+  if (base >= n) return;
+  const uint32_t live = min(kSortWindow, n - base);
+  constexpr uint32_t kWaves = kSortThreads / 64, kCells = kShadeKinds * kSortRounds * kWaves;
+  __shared__ uint32_t s_bin[kCells];  // [kind][round][wave]: entries of that kind among the 64 the wave looked at in that round
+  const uint32_t w = threadIdx.x >> 6, l = lane_id();
+  uint32_t kr[kSortRounds];  // kind | rank << 4 of this thread's entry of round j
+#pragma unroll
+  for (uint32_t j = 0; j < kSortRounds; ++j) {
+    const uint32_t e = j * kSortThreads + threadIdx.x;
+    uint32_t kind = kShadeKinds - 1u;  // no path
+    if (e < live) {
+      const uint32_t pw = reinterpret_cast<const uint32_t*>(q.hits + base + e)[3];
+      kind = pw == kAbsent ? kShadeKindMiss : (pw & 7u);
+    }
+    uint32_t rank = 0;
+#pragma unroll
+    for (uint32_t b = 0; b < kShadeKinds; ++b) {
+      const unsigned long long m = __ballot(kind == b);
+      if (kind == b) rank = mbcnt64(m);
+      if (l == 0u) s_bin[(b * kSortRounds + j) * kWaves + w] = (uint32_t)__popcll(m);
+    }
+    kr[j] = kind | (rank << 4);
+  }
+  __syncthreads();
+  if (w == 0u) {  // exclusive prefix over the cells in (kind, round, wave) order, by one wave: each lane folds a run of cells, the runs are scanned with shuffles
+    constexpr uint32_t kRun = (kCells + 63u) / 64u;
+    uint32_t v[kRun], sum = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kRun; ++k) { const uint32_t c = l * kRun + k; v[k] = c < kCells ? s_bin[c] : 0u; sum += v[k]; }
+    uint32_t incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, off); if (l >= (uint32_t)off) incl += o; }
+    uint32_t run = incl - sum;
+#pragma unroll
+    for (uint32_t k = 0; k < kRun; ++k) { const uint32_t c = l * kRun + k; if (c < kCells) s_bin[c] = run; run += v[k]; }
+  }
+  __syncthreads();
+  // "no path" entries (beyond the queue's end) sort last: positions >= live, never read
+#pragma unroll
+  for (uint32_t j = 0; j < kSortRounds; ++j) {
+    const uint32_t e = j * kSortThreads + threadIdx.x;
+    if (e >= live) continue;
+    const uint32_t kind = kr[j] & 15u, rank = kr[j] >> 4;
+    q.perm[base + s_bin[(kind * kSortRounds + j) * kWaves + w] + rank] = base + e;
+  }
+}
+
 template <bool PRIMARY, bool SIMPLE, bool SCATTER>
 __global__ void __launch_bounds__(SIMPLE ? kShadeThreads : kShadeThreadsGeneric, SIMPLE ? RT_SHADE_WAVES_SIMPLE : RT_SHADE_WAVES) k_shade(FrameConst fc, SceneView sv, Queues q, PathState ps, Control* __restrict__ ctl, uint32_t depth) {
   __shared__ BlockCompact s_compact;
@@ -416,8 +479,19 @@ __global__ void __launch_bounds__(SIMPLE ? kShadeThreads : kShadeThreadsGeneric,
     ctl->work_shadow[1].c[threadIdx.x * kWorkStride] = 0u;
     if (threadIdx.x == 0u) { ctl->work_closest.dry[0] = 0ull; ctl->work_shadow[0].dry[0] = 0ull; ctl->work_shadow[1].dry[0] = 0ull; }
   }
-  if (blockIdx.x * blockDim.x >= n) return;  // whole workgroup beyond the queue (uniform exit: barriers below)
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t blk = blockIdx.x;
+#if !defined(RT_SHADE_NOSORT) && !defined(RT_SHADE_NO_XCD_MAP)
+  if (!PRIMARY && !SIMPLE && sv.shade_sort) {
+    // The workgroups that share a sort window read the same lines of the ray / state / hit queues (each takes a kind-slice of the
+    // window's paths).  Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one, each XCD has its own L2): give every
+    // window to ONE XCD — hardware blocks x, x + 8, x + 16, ... of a group of 8 windows take the consecutive logical blocks of window x.
+    constexpr uint32_t kBPW = kSortWindow / kShadeThreadsGeneric, kGroup = 8u * kBPW;  // (the launcher rounds the grid up to whole groups)
+    const uint32_t wi = blk % kGroup;
+    blk = blk - wi + (wi & 7u) * kBPW + (wi >> 3);
+  }
+#endif
+  if (blk * blockDim.x >= n) return;  // whole workgroup beyond the queue (uniform exit: barriers below)
+  uint32_t i = blk * blockDim.x + threadIdx.x;
   // the texel decode table in LDS (shading.h::tex8_fetch); the barriers of the block compaction come long after every read of it
   __shared__ float s_tex_lut[SIMPLE ? 1 : kTexLutEntries];
   const RT_LDS float* lut = (const RT_LDS float*)s_tex_lut;
@@ -426,42 +500,12 @@ __global__ void __launch_bounds__(SIMPLE ? kShadeThreads : kShadeThreadsGeneric,
     __syncthreads();
   }
 #ifndef RT_SHADE_NOSORT
-  if (!PRIMARY && sv.shade_sort) {
-    // Bounce paths arrive in no particular order and the BSDF code is a forest of branches (miss / diffuse / Disney / glass /
-    // textured ...): a wave ran its VALU instructions at 21 of 64 lanes on the 1 M-triangle scene (profiles/r02_a_pmc_config4.txt).
-    // Regroup the workgroup's paths by shading kind first (counting sort through LDS: 9 ballots, one pass): a wave then
-    // shades (mostly) one kind.  Which lane shades which path is not observable: every output is indexed by path slot or comes
-    // out of the block compaction below.
-    __shared__ uint16_t s_perm[kShadeThreads];
-    __shared__ uint32_t s_bin[kShadeKinds][kShadeThreads / 64 + 1];
-    uint32_t kind = kShadeKinds - 1u;
-    if (i < n) {
-      const uint32_t prim = reinterpret_cast<const uint32_t*>(q.hits + i)[3];
-      kind = kShadeKindMiss;
-      if (prim != kAbsent) kind = sv.material_kind[sv.shade_tris[prim].material];
-    }
-    const uint32_t w = threadIdx.x >> 6, l = lane_id();
-    uint32_t rank = 0;
-#pragma unroll
-    for (uint32_t b = 0; b < kShadeKinds; ++b) {
-      const unsigned long long m = __ballot(kind == b);
-      if (kind == b) rank = mbcnt64(m);
-      if (l == 0u) s_bin[b][w] = (uint32_t)__popcll(m);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0u) {  // exclusive prefix in (kind, wave) order: 72 serial adds
-      uint32_t run = 0;
-      for (uint32_t b = 0; b < kShadeKinds; ++b)
-        for (uint32_t j = 0; j < (blockDim.x >> 6); ++j) { const uint32_t c = s_bin[b][j]; s_bin[b][j] = run; run += c; }
-    }
-    __syncthreads();
-    s_perm[s_bin[kind][w] + rank] = (uint16_t)threadIdx.x;
-    __syncthreads();
-    i = blockIdx.x * blockDim.x + s_perm[threadIdx.x];
-  }
+  if (!PRIMARY && !SIMPLE && sv.shade_sort && i < n) i = q.perm[i];  // kind order inside the window (k_shade_sort)
 #endif
-  const bool active = i < n;
   const uint32_t in = depth & 1u, out = in ^ 1u;
+  {
+  const bool active = i < n;
+
   bool keep[3] = {false, false, false};  // path survives, light connection, environment connection
   f3 no = splat3(0.0f), nd = splat3(0.0f);
   float4 conn[2][3];  // the two NEE connections of this path, written to the compact queues after the block scan
@@ -492,7 +536,8 @@ __global__ void __launch_bounds__(SIMPLE ? kShadeThreads : kShadeThreadsGeneric,
       T = mk3(st.x, st.y, st.z); prev_pdf = st.w;
     }
     const float4 hv = reinterpret_cast<const float4*>(q.hits)[i];
-    const uint32_t hit_prim = __float_as_uint(hv.w);
+    const uint32_t hit_word = __float_as_uint(hv.w);  // id << 3 | shading kind (hala_types.h: hit_encode) or kAbsent
+    const uint32_t hit_prim = hit_word == kAbsent ? kAbsent : hit_word >> kHitKindBits;
     const uint32_t nl = fc.u.num_of_lights;
     const float t_surf = hit_prim != kAbsent ? hv.x : kTMax;
 
@@ -672,9 +717,10 @@ __global__ void __launch_bounds__(SIMPLE ? kShadeThreads : kShadeThreadsGeneric,
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     if (keep[1 + k]) {
-      float4* e = reinterpret_cast<float4*>(q.shadow[k] + pos[1 + k]);
-      st4(e, conn[k][0]); st4(e + 1, conn[k][1]); st4(e + 2, conn[k][2]);
+      float4* ce = reinterpret_cast<float4*>(q.shadow[k] + pos[1 + k]);
+      st4(ce, conn[k][0]); st4(ce + 1, conn[k][1]); st4(ce + 2, conn[k][2]);
     }
+  }
   }
 }
 
@@ -833,7 +879,15 @@ void launch_trace_primary(const LaunchCfg& lc, const SceneView& sv, const FrameC
 }
 void launch_shade(const FrameConst& fc, const SceneView& sv, const Queues& q, const PathState& ps, Control* ctl, uint32_t depth, hipStream_t s) {
   const uint32_t threads = sv.simple_materials ? (uint32_t)kShadeThreads : (uint32_t)kShadeThreadsGeneric;
-  const dim3 grid(blocks_for(fc.slot_count, threads)), block(threads);
+  dim3 grid(blocks_for(fc.slot_count, threads)), block(threads);
+#ifndef RT_SHADE_NOSORT
+  // bounce launches of multi-kind scenes shade their paths in kind order inside windows of the queue
+  if (depth != 0u && !sv.simple_materials && sv.shade_sort) {
+    hipLaunchKernelGGL(k_shade_sort, dim3(blocks_for(fc.slot_count, kSortWindow)), dim3(kSortThreads), 0, s, q, ctl, depth);
+    const uint32_t group = 8u * (kSortWindow / threads);  // whole groups of 8 windows: k_shade's window -> XCD mapping permutes the blocks of a group
+    grid.x = blocks_for(grid.x, group) * group;
+  }
+#endif
   if (sv.simple_materials) {
     if (depth == 0u) hipLaunchKernelGGL((k_shade<true, true, false>), grid, block, 0, s, fc, sv, q, ps, ctl, depth);
     else hipLaunchKernelGGL((k_shade<false, true, false>), grid, block, 0, s, fc, sv, q, ps, ctl, depth);

@@ -72,6 +72,7 @@ struct BvhBuffers {
                            // null: the scene has neither
   const uint8_t* material_any_class = nullptr;  // per material: 0 blocks always, 1 invisible, 2 translucent (for tris_any)
   uint32_t material_count = 0;
+  const uint8_t* material_kind = nullptr;       // per material: shading kind (hala_types.h: shade_kind_of), stamped into word 11 of the BVH-order triangles
   ShadeTri* shade_tris;    // [tri_count] global-id order
   uint32_t* tri_instance;  // [tri_count]
   BvhNode4* nodes;         // capacity >= max(tri_count - 1, 1)

@@ -123,6 +123,7 @@ struct hala_rt_renderer {
   DeviceArray<hala_gpu_light> d_lights;
   DeviceArray<hala_gpu_material> d_materials;
   DeviceArray<uint8_t> d_material_kind;
+  std::vector<uint8_t> material_kind;  // host copy: a refit restamps the triangles when an edit changed a material's shading kind
   bool shade_sort = false, simple_materials = false, scatter_media = false;
   DeviceArray<hala_gpu_mesh_data> d_instances;
   DeviceArray<uint32_t> d_inst_first_tri;
@@ -168,6 +169,7 @@ struct hala_rt_renderer {
   DeviceArray<hala_ray> q_rays[2];
   DeviceArray<float4> q_state[2];
   DeviceArray<hala_hit> q_hits;
+  DeviceArray<uint32_t> q_perm;
   DeviceArray<ShadowEntry> q_shadow[2];
   DeviceArray<Control> d_ctl;
   DeviceArray<WorkCounters> d_batch_work;
@@ -240,7 +242,7 @@ struct hala_rt_renderer {
   Queues queues() const {
     Queues q{};
     q.rays[0] = q_rays[0].ptr; q.rays[1] = q_rays[1].ptr; q.state[0] = q_state[0].ptr; q.state[1] = q_state[1].ptr;
-    q.hits = q_hits.ptr; q.shadow[0] = q_shadow[0].ptr; q.shadow[1] = q_shadow[1].ptr;
+    q.hits = q_hits.ptr; q.perm = q_perm.ptr; q.shadow[0] = q_shadow[0].ptr; q.shadow[1] = q_shadow[1].ptr;
     return q;
   }
   PathState path_state() const { return PathState{ps_lr.ptr, ps_le.ptr, ps_alb.ptr, ps_nrm.ptr}; }
@@ -375,7 +377,7 @@ int alloc_wavefront(hala_rt_renderer* r, uint32_t samples) {
   if (n > 0xfffffff0ull) RT_FAIL("The sample batch is too large for 32-bit path slots.");
   RT_HIP(r->ps_lr.resize(n)); RT_HIP(r->ps_le.resize(n)); RT_HIP(r->ps_alb.resize(n)); RT_HIP(r->ps_nrm.resize(n));
   RT_HIP(r->q_rays[0].resize(n)); RT_HIP(r->q_rays[1].resize(n)); RT_HIP(r->q_state[0].resize(n)); RT_HIP(r->q_state[1].resize(n));
-  RT_HIP(r->q_hits.resize(n)); RT_HIP(r->q_shadow[0].resize(n)); RT_HIP(r->q_shadow[1].resize(n));
+  RT_HIP(r->q_hits.resize(n)); RT_HIP(r->q_perm.resize(n)); RT_HIP(r->q_shadow[0].resize(n)); RT_HIP(r->q_shadow[1].resize(n));
   r->batch_capacity = samples;
   return HALA_OK;
 }
@@ -423,6 +425,7 @@ int upload_packed(hala_rt_renderer* r, bool geometry = true) {
     std::vector<uint8_t> kind(hs.gpu_materials.size());
     for (size_t i = 0; i < kind.size(); ++i) kind[i] = shade_kind_of(hs.gpu_materials[i], (uint32_t)hs.texture_image.size());
     RT_HIP(r->d_material_kind.upload(kind.data(), kind.size(), r->stream));
+    r->material_kind = kind;
     uint32_t seen = 0;
     for (uint8_t k : kind) seen |= 1u << k;
     r->shade_sort = (seen & (seen - 1u)) != 0u;  // two kinds or more (a one-kind scene like the Cornell box only pays for the sort)
@@ -565,6 +568,7 @@ int attach_any_triangles(hala_rt_renderer* r) {
   if (r->any_invisible) RT_HIP(r->d_tris_any.resize(r->hs.triangle_count));
   r->bvh.tris_any = r->any_invisible ? r->d_tris_any.ptr : nullptr;
   r->bvh.material_any_class = r->d_material_any_class.ptr;
+  r->bvh.material_kind = r->d_material_kind.ptr;
   r->bvh.material_count = (uint32_t)r->hs.gpu_materials.size();
   return HALA_OK;
 }
@@ -1352,7 +1356,11 @@ int hala_rt_download_bvh(hala_rt_renderer* r, void* nodes_64B, void* triangles_4
   if (!r->committed) RT_FAIL("The top level acceleration structure is none!");
   RT_HIP(hipStreamSynchronize(r->stream));
   if (nodes_64B) RT_HIP(hipMemcpy(nodes_64B, r->d_nodes.ptr, (size_t)r->bvh.node_count * 64, hipMemcpyDeviceToHost));
-  if (triangles_48B && r->bvh.tri_count) RT_HIP(hipMemcpy(triangles_48B, r->d_tris.ptr, (size_t)r->bvh.tri_count * 48, hipMemcpyDeviceToHost));
+  if (triangles_48B && r->bvh.tri_count) {
+    RT_HIP(hipMemcpy(triangles_48B, r->d_tris.ptr, (size_t)r->bvh.tri_count * 48, hipMemcpyDeviceToHost));
+    Tri* t = static_cast<Tri*>(triangles_48B);
+    for (uint32_t i = 0; i < r->bvh.tri_count; ++i) t[i].pad2 = 0u;  // word 11 is the library's own (shading kind for the hit queue): not part of the 48-B format
+  }
   return HALA_OK;
 }
 
@@ -1394,6 +1402,7 @@ int hala_rt_refit(hala_rt_renderer* r) {
   if (!r->committed) RT_FAIL("The top level acceleration structure is none!");
   RT_HIP(hipStreamSynchronize(r->stream));
   const std::vector<hala_gpu_mesh_data> before = r->hs.instances;  // object -> world of every instance as the tree was fitted to it
+  const std::vector<uint8_t> kinds_before = r->material_kind;
   r->hs.update_node_hierarchies();
   const std::string e = r->hs.pack();
   if (!e.empty()) RT_FAIL(e);
@@ -1405,7 +1414,9 @@ int hala_rt_refit(hala_rt_renderer* r) {
   if (attach_any_triangles(r) != HALA_OK) return HALA_ERR;
   if (classes_before != r->material_any_class) r->materials_dirty_any = true;  // the any-hit copy of the triangles must be rewritten
   // (a material edit can change which triangles the shadow rays see: their copy is rewritten by the refit pass)
-  bool geometry_moved = r->vertices_dirty || r->materials_dirty_any || had_invisible != r->any_invisible || before.size() != r->hs.instances.size();
+  // (the BVH-order triangles carry their material's shading kind: rewritten by the refit pass as well)
+  bool geometry_moved = r->vertices_dirty || r->materials_dirty_any || had_invisible != r->any_invisible || before.size() != r->hs.instances.size() ||
+                        kinds_before != r->material_kind;
   r->materials_dirty_any = false;
   for (size_t i = 0; i < before.size() && !geometry_moved; ++i) geometry_moved = memcmp(before[i].transform, r->hs.instances[i].transform, 64) != 0;
   if (geometry_moved) {

@@ -201,8 +201,10 @@ RT_DI bool leaf_test_staged(const SceneView& sv, const TraverseLds& lds, const R
           }
           best.t = tt[j]; best.u = uu[j]; best.v = vv[j]; best.prim = id; return true;
         }
-      } else if (tt[j] > r.tmin && (tt[j] < best.t || (tt[j] == best.t && id < best.prim))) {
-        best.t = tt[j]; best.u = uu[j]; best.v = vv[j]; best.prim = id;
+      } else {
+        // closest hit: the record carries id << 3 | shading kind (hala_types.h: hit_encode; ordered like the ids)
+        const uint32_t enc = hit_encode(id, __float_as_uint(j ? c1.w : c0.w));
+        if (tt[j] > r.tmin && (tt[j] < best.t || (tt[j] == best.t && enc < best.prim))) { best.t = tt[j]; best.u = uu[j]; best.v = vv[j]; best.prim = enc; }
       }
     }
   }
@@ -377,7 +379,7 @@ RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, 
               }
             }
             else {
-              mine = ((unsigned long long)__float_as_uint(tt) << 32) | (unsigned long long)__float_as_uint(a.w);
+              mine = ((unsigned long long)__float_as_uint(tt) << 32) | (unsigned long long)hit_encode(__float_as_uint(a.w), __float_as_uint(c.w));  // id << 3 | shading kind
               __hip_atomic_fetch_min(okey, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             }
           }

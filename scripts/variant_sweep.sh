@@ -10,8 +10,9 @@ STEPS=${SWEEP_STEPS:-20}
 SEC=${SWEEP_SECONDARY:---no-secondary}
 run() { env $1 timeout -k 10 300 python3 bench.py --steps $STEPS --warmup 3 --no-cpu-baseline $SEC 2>/dev/null | python3 -c "
 import sys,json
-b=json.loads(sys.stdin.read()); r=b['roofline']; k=r['ms_per_frame_by_kernel']; s=r['simt']
-print(b['value'], b['ms_per_step'], 'closest', k['closest'], 'shade', k['shade'], 'shadow', k['shadow'], '| nodes/tris per bounce ray', r['nodes_per_ray'], r['tris_per_ray'],
+b=json.loads(sys.stdin.read()); r=b['roofline']; k=r['ms_per_frame_by_kernel']; u=k['one_launch_per_pass']; f=k['fused_launches']; s=r['simt']; ub=r['unfused_kernels']['batch']
+print(b['value'], b['ms_per_step'], '| per pass: closest', u['closest'], 'shade', u['shade'], 'shadow', u['shadow'], '| fused frames: primary', f['primary'], 'shade', f['shade'], 'fused', f['fused_traversal'],
+      '| nodes/tris per bounce ray', ub['nodes_per_ray'], ub['tris_per_ray'],
       '| leaf passes/step @ lanes', s['closest']['leaf_passes_per_wave_step'], s['closest']['leaf_path_lanes_of_64'], s['shadow']['leaf_passes_per_wave_step'], s['shadow']['leaf_path_lanes_of_64'],
       '| node lanes', s['closest']['node_path_lanes_of_64'], s['shadow']['node_path_lanes_of_64'])
 c=b.get('secondary',{}).get('configs1')
