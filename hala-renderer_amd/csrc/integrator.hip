@@ -617,6 +617,9 @@ __global__ void __launch_bounds__(SIMPLE ? kShadeThreads : kShadeThreadsGeneric,
         if (em.x > 0.0f || em.y > 0.0f || em.z > 0.0f) L = L + T * em;
       }
       const f3 wo = -d;
+      // the tangent frame, wo in it and the lobe weights of this vertex: shared by the two connections and the sampled continuation
+      BsdfCtx bc{};
+      if (!scattered) bc = bsdf_prepare(sf.mat, wo, sf.ns);
       if (nl > 0u) {  // NEE: one light
         const float rl = rng_next(rng), r1 = rng_next(rng), r2 = rng_next(rng);
         const uint32_t idx = min((uint32_t)(rl * (float)nl), nl - 1u);
@@ -624,7 +627,7 @@ __global__ void __launch_bounds__(SIMPLE ? kShadeThreads : kShadeThreadsGeneric,
         if (ls.valid) {
           f3 fb; float pdf_b;
           if (scattered) { pdf_b = hg_phase(hg_g, dot3(d, ls.wi)); fb = splat3(pdf_b); }
-          else bsdf_eval(sf.mat, wo, ls.wi, sf.ns, &fb, &pdf_b);
+          else bsdf_eval(sf.mat, bc, wo, ls.wi, sf.ns, &fb, &pdf_b);
           if (pdf_b > 0.0f) {
             const float side = dot3(ls.wi, sf.ng) >= 0.0f ? sv.ray_eps : -sv.ray_eps;
             const f3 so = scattered ? pm : madd3(sf.ng, side, sf.P);
@@ -651,7 +654,7 @@ __global__ void __launch_bounds__(SIMPLE ? kShadeThreads : kShadeThreadsGeneric,
         if (env_map_sample(fc, sv, r1, r2, &wi, &pdf_e)) {
           f3 fb; float pdf_b;
           if (scattered) { pdf_b = hg_phase(hg_g, dot3(d, wi)); fb = splat3(pdf_b); }
-          else bsdf_eval(sf.mat, wo, wi, sf.ns, &fb, &pdf_b);
+          else bsdf_eval(sf.mat, bc, wo, wi, sf.ns, &fb, &pdf_b);
           if (pdf_b > 0.0f) {
             const float side = dot3(wi, sf.ng) >= 0.0f ? sv.ray_eps : -sv.ray_eps;
             const f3 so = scattered ? pm : madd3(sf.ng, side, sf.P);
@@ -676,7 +679,7 @@ __global__ void __launch_bounds__(SIMPLE ? kShadeThreads : kShadeThreadsGeneric,
       } else {
         const float r1 = rng_next(rng), r2 = rng_next(rng), r3 = rng_next(rng);
         f3 fb; float pdf_b;
-        sampled = bsdf_sample(sf.mat, wo, sf.ns, r1, r2, r3, &wi, &fb, &pdf_b);
+        sampled = bsdf_sample(sf.mat, bc, wo, sf.ns, r1, r2, r3, &wi, &fb, &pdf_b);
         if (sampled) { T = T * fb * (fabsf(dot3(sf.ns, wi)) / pdf_b); prev_pdf = pdf_b; }
       }
       if (sampled) {

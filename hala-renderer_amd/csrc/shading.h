@@ -83,9 +83,14 @@ RT_DI void camera_ray(const FrameConst& fc, const hala_gpu_camera& cam, uint32_t
 
 // ---- §7.3 environment ----------------------------------------------------------------------------------------
 RT_DI int wrapi(int i, int n) {
+  // REPEAT addressing: i mod n in [0, n).  Power-of-two sizes (every mip level of a power-of-two image, the usual case) take the mask —
+  // the same integer for negative i too — and skip the ~35-instruction division sequence; a wave without odd sizes never runs it.
+  if ((n & (n - 1)) == 0) return i & (n - 1);
   int m = i % n;
   return m < 0 ? m + n : m;
 }
+// i + 1 wrapped, for 0 <= i < n: no division at all
+RT_DI int wrap_next(int i, int n) { return i + 1 == n ? 0 : i + 1; }
 RT_DI f3 env_texel(const SceneView& sv, int w, int x, int y) {
   const float4 p = reinterpret_cast<const float4*>(sv.env_pixels)[(size_t)y * w + x];
   return mk3(p.x, p.y, p.z);
@@ -104,7 +109,7 @@ RT_DI f3 env_map_eval(const FrameConst& fc, const SceneView& sv, f3 d) {
   float x0 = floorf(x), y0 = floorf(y);
   float fx = x - x0, fy = y - y0;
   int ix0 = wrapi((int)x0, W), iy0 = wrapi((int)y0, H);
-  int ix1 = wrapi(ix0 + 1, W), iy1 = wrapi(iy0 + 1, H);
+  int ix1 = wrap_next(ix0, W), iy1 = wrap_next(iy0, H);
   f3 c00 = env_texel(sv, W, ix0, iy0), c10 = env_texel(sv, W, ix1, iy0), c01 = env_texel(sv, W, ix0, iy1), c11 = env_texel(sv, W, ix1, iy1);
   f3 top = c00 * (1.0f - fx) + c10 * fx;
   f3 bot = c01 * (1.0f - fx) + c11 * fx;
@@ -239,13 +244,36 @@ RT_DI DisneyLobes disney_lobes(const MatView& m, float nv) {
   d.pd = wd * inv; d.ps = ws * inv; d.pc = wc * inv; d.pt = wt * inv;
   return d;
 }
-RT_DI void disney_eval(const MatView& m, f3 wo, f3 wi, f3 n, f3* f, float* pdf) {
-  float nl = dot3(n, wi), nv = dot3(n, wo);
+// What every evaluation of a vertex's BSDF shares — the light connection, the environment connection and the sampled continuation all
+// look at the same (material, wo, n): the tangent frame, wo in it, the lobe weights and the wo-side masking terms are computed ONCE per
+// vertex (the same expressions as before, so the same bits) instead of up to three times.
+struct BsdfCtx {
+  f3 t, b, lo;   // onb(n) and wo in that frame (lo.z = nv)
+  float nv;
+  DisneyLobes d; // DISNEY only (valid when nv > 0)
+  float fv, g1o, c1o;
+};
+RT_DI BsdfCtx bsdf_prepare(const MatView& m, f3 wo, f3 n) {
+  BsdfCtx c;
+  c.nv = dot3(n, wo);
+  onb(n, &c.t, &c.b);
+  c.lo = mk3(dot3(wo, c.t), dot3(wo, c.b), c.nv);
+  c.fv = 0.0f; c.g1o = 0.0f; c.c1o = 0.0f;
+  c.d.pd = c.d.ps = c.d.pc = c.d.pt = 0.0f; c.d.cspec0 = splat3(0.0f); c.d.csheen = splat3(0.0f); c.d.cc_alpha = 0.0f;
+  if (m.type == 1u && c.nv > 0.0f) {
+    c.d = disney_lobes(m, c.nv);
+    c.fv = schlick5(c.nv);
+    c.g1o = ggx_g1(c.lo, m.ax, m.ay);
+    c.c1o = ggx_g1(c.lo, c.d.cc_alpha, c.d.cc_alpha);
+  }
+  return c;
+}
+RT_DI void disney_eval(const MatView& m, const BsdfCtx& c, f3 wi, f3 n, f3* f, float* pdf) {
+  const float nl = dot3(n, wi), nv = c.nv;
   *f = splat3(0.0f); *pdf = 0.0f;
   if (!(nv > 0.0f)) return;
-  f3 t, b;
-  onb(n, &t, &b);
-  f3 lo = mk3(dot3(wo, t), dot3(wo, b), nv), li = mk3(dot3(wi, t), dot3(wi, b), nl);
+  const f3 lo = c.lo, li = mk3(dot3(wi, c.t), dot3(wi, c.b), nl);
+  const DisneyLobes& d = c.d;
   if (nl < 0.0f) {  // §7.1c: refraction through the microfacet with half vector h = -(lo + eta*li), flipped to the upper side
     if (!(m.trans > 0.0f)) return;
     f3 h = lo + li * m.eta;
@@ -255,10 +283,9 @@ RT_DI void disney_eval(const MatView& m, f3 wo, f3 wi, f3 n, f3* f, float* pdf) 
     if (h.z < 0.0f) h = -h;
     float odh = dot3(lo, h), idh = dot3(li, h);
     if (!(odh > 0.0f && idh < 0.0f)) return;  // both directions must see the front / the back of the same facet
-    DisneyLobes d = disney_lobes(m, nv);
     float fr = fresnel_dielectric(odh, m.eta);
     float ds = ggx_d(h, m.ax, m.ay);
-    float g1o = ggx_g1(lo, m.ax, m.ay), g1i = ggx_g1(li, m.ax, m.ay);
+    float g1o = c.g1o, g1i = ggx_g1(li, m.ax, m.ay);
     float den = odh + m.eta * idh;
     float jac = m.eta * m.eta * (-idh) / (den * den);  // |dh/dwi|
     float w = m.trans * (1.0f - fr) * ds * g1o * g1i * odh * jac / (-nl * nv);
@@ -269,8 +296,7 @@ RT_DI void disney_eval(const MatView& m, f3 wo, f3 wi, f3 n, f3* f, float* pdf) 
   if (!(nl > 0.0f)) return;
   f3 h = normalize3(lo + li);
   float ldh = dot3(li, h);
-  DisneyLobes d = disney_lobes(m, nv);
-  float fl = schlick5(nl), fv = schlick5(nv), fh = schlick5(ldh);
+  float fl = schlick5(nl), fv = c.fv, fh = schlick5(ldh);
   float fd90 = 0.5f + 2.0f * sqrtf(m.roughness) * ldh * ldh;
   float fd = mixf(1.0f, fd90, fl) * mixf(1.0f, fd90, fv);
   float dw = (1.0f - m.metallic) * (1.0f - m.trans);
@@ -278,11 +304,11 @@ RT_DI void disney_eval(const MatView& m, f3 wo, f3 wi, f3 n, f3* f, float* pdf) 
   if (m.trans > 0.0f) fs = mix3(fs, splat3(fresnel_dielectric(ldh, m.eta)), m.trans);  // §7.1c: pairs with the (1 - F) of the refraction lobe
   f3 fr = m.base * (splat3(1.0f) - fs) * (kInvPi * fd * dw) + d.csheen * (m.sheen * fh * dw);
   float ds = ggx_d(h, m.ax, m.ay);
-  float g1o = ggx_g1(lo, m.ax, m.ay), g1i = ggx_g1(li, m.ax, m.ay);
+  float g1o = c.g1o, g1i = ggx_g1(li, m.ax, m.ay);
   float denom = 4.0f * nl * nv;
   fr = fr + fs * (ds * g1o * g1i / denom);
   float dc = ggx_d(h, d.cc_alpha, d.cc_alpha);
-  float c1o = ggx_g1(lo, d.cc_alpha, d.cc_alpha), c1i = ggx_g1(li, d.cc_alpha, d.cc_alpha);
+  float c1o = c.c1o, c1i = ggx_g1(li, d.cc_alpha, d.cc_alpha);
   float fc = mixf(0.04f, 1.0f, fh);
   fr = fr + splat3(0.25f * m.clearcoat * fc * dc * c1o * c1i / denom);
   *f = fr;
@@ -290,9 +316,9 @@ RT_DI void disney_eval(const MatView& m, f3 wo, f3 wi, f3 n, f3* f, float* pdf) 
   *pdf = d.pd * (nl * kInvPi) + d.ps * (g1o * ds * inv4nv) + d.pc * (c1o * dc * inv4nv);
 }
 
-RT_DI void bsdf_eval(const MatView& m, f3 wo, f3 wi, f3 n, f3* f, float* pdf) {
-  if (m.type == 1u) { disney_eval(m, wo, wi, n, f, pdf); return; }
-  float nl = dot3(n, wi), nv = dot3(n, wo);
+RT_DI void bsdf_eval(const MatView& m, const BsdfCtx& c, f3 wo, f3 wi, f3 n, f3* f, float* pdf) {
+  if (m.type == 1u) { disney_eval(m, c, wi, n, f, pdf); return; }
+  float nl = dot3(n, wi), nv = c.nv;
   if (!(nl > 0.0f && nv > 0.0f)) { *f = splat3(0.0f); *pdf = 0.0f; return; }
   float s = dot3(wi, wo) - nl * nv;
   float tterm = maxf(0.0f, s) / maxf(nl, nv);
@@ -300,39 +326,38 @@ RT_DI void bsdf_eval(const MatView& m, f3 wo, f3 wi, f3 n, f3* f, float* pdf) {
   *f = m.base * k;
   *pdf = nl * kInvPi;
 }
-RT_DI bool bsdf_sample(const MatView& m, f3 wo, f3 n, float r1, float r2, float r3, f3* wi, f3* f, float* pdf) {
-  f3 t, b;
-  onb(n, &t, &b);
+RT_DI bool bsdf_sample(const MatView& m, const BsdfCtx& c, f3 wo, f3 n, float r1, float r2, float r3, f3* wi, f3* f, float* pdf) {
+  const f3 t = c.t, b = c.b;
   if (m.type == 1u) {
-    float nv = dot3(n, wo);
+    float nv = c.nv;
     if (!(nv > 0.0f)) { *f = splat3(0.0f); *pdf = 0.0f; return false; }
-    DisneyLobes d = disney_lobes(m, nv);
+    const DisneyLobes& d = c.d;
     if (r3 < d.pd) {
       *wi = to_world(cosine_hemisphere(r1, r2), t, b, n);
     } else if (r3 >= d.pd + d.ps + d.pc) {  // §7.1c: refract through a VNDF-sampled facet (nothing when totally reflected)
-      f3 lo = mk3(dot3(wo, t), dot3(wo, b), nv);
+      f3 lo = c.lo;
       f3 h = ggx_sample_vndf(lo, m.ax, m.ay, r1, r2);
-      float c = dot3(lo, h);
+      float cc = dot3(lo, h);
       float ie = 1.0f / m.eta;
-      float k = 1.0f - (1.0f - c * c) * (ie * ie);
+      float k = 1.0f - (1.0f - cc * cc) * (ie * ie);
       if (!(k > 0.0f)) { *f = splat3(0.0f); *pdf = 0.0f; return false; }
-      f3 li = h * (c * ie - sqrtf(k)) - lo * ie;
+      f3 li = h * (cc * ie - sqrtf(k)) - lo * ie;
       *wi = to_world(li, t, b, n);
     } else {
       bool spec = r3 < d.pd + d.ps;
       float ax = spec ? m.ax : d.cc_alpha, ay = spec ? m.ay : d.cc_alpha;
-      f3 lo = mk3(dot3(wo, t), dot3(wo, b), nv);
+      f3 lo = c.lo;
       f3 h = ggx_sample_vndf(lo, ax, ay, r1, r2);
       float k = 2.0f * dot3(lo, h);
       f3 li = h * k - lo;
       *wi = to_world(li, t, b, n);
     }
-    disney_eval(m, wo, *wi, n, f, pdf);
+    disney_eval(m, c, *wi, n, f, pdf);
     return *pdf > 0.0f;
   }
   f3 l = cosine_hemisphere(r1, r2);
   *wi = to_world(l, t, b, n);
-  bsdf_eval(m, wo, *wi, n, f, pdf);
+  bsdf_eval(m, c, wo, *wi, n, f, pdf);
   return *pdf > 0.0f;
 }
 
@@ -479,7 +504,7 @@ RT_DI float4 tex_bilinear(const SceneView& sv, LUT lut, const TexDesc& td, uint3
   const float x0 = floorf(x), y0 = floorf(y);
   const float fx = x - x0, fy = y - y0;
   const int ix0 = wrapi((int)x0, w), iy0 = wrapi((int)y0, h);  // REPEAT (gpu_uploader.rs:346)
-  const int ix1 = wrapi(ix0 + 1, w), iy1 = wrapi(iy0 + 1, h);
+  const int ix1 = wrap_next(ix0, w), iy1 = wrap_next(iy0, h);
   float4 c00, c10, c01, c11;
   if (td.format == kTexFloat) {
     const float4* base = sv.tex_arena + td.mip_offset[level];
