@@ -413,9 +413,12 @@ k_trace_shadow_then_batch(SceneView sv, const Tri* __restrict__ tris_any, Queues
 // same boundaries per 64 waves.  Which lane shades which path is not observable: every output is indexed by path slot or comes out
 // of the block compaction.
 #ifndef RT_SORT_ROUNDS
-#define RT_SORT_ROUNDS 16
+#define RT_SORT_ROUNDS 4
 #endif
-constexpr uint32_t kSortThreads = 256, kSortRounds = RT_SORT_ROUNDS, kSortWindow = kSortThreads * kSortRounds;
+#ifndef RT_SORT_THREADS
+#define RT_SORT_THREADS 1024  // a window is one workgroup of the sort kernel: 16 waves x 4 entries per lane (256 x 16: 27 us per launch instead of ~12)
+#endif
+constexpr uint32_t kSortThreads = RT_SORT_THREADS, kSortRounds = RT_SORT_ROUNDS, kSortWindow = kSortThreads * kSortRounds;
 static_assert(kSortWindow <= 65536, "window-relative positions are 16-bit in LDS");
 __global__ void __launch_bounds__(kSortThreads) k_shade_sort(Queues q, const Control* __restrict__ ctl, uint32_t depth) {
   const uint32_t n = ctl->n_active[depth];
