@@ -162,13 +162,14 @@ class RtStatistics(C.Structure):
 
 class BuildOptions(C.Structure):  # hala_rt_build_options
     _fields_ = [("builder", C.c_uint32), ("ploc_tail", C.c_uint32), ("ploc_look_every", C.c_uint32),
-                ("collapse_look_every", C.c_uint32), ("reserved", C.c_uint32 * 4)]
+                ("collapse_look_every", C.c_uint32), ("instancing", C.c_uint32), ("reserved", C.c_uint32 * 3)]
 
 
 class BvhInfo(C.Structure):
     _fields_ = [("node_count", C.c_uint32), ("triangle_count", C.c_uint32), ("max_depth", C.c_uint32),
                 ("lds_node_count", C.c_uint32), ("scene_min", C.c_float * 3), ("scene_max", C.c_float * 3),
-                ("node_width", C.c_uint32)]
+                ("node_width", C.c_uint32), ("stored_triangle_count", C.c_uint32), ("instance_node_count", C.c_uint32),
+                ("instance_ref_count", C.c_uint32), ("tree_bytes", C.c_uint64)]
 
 
 class RtProgDescInfo(C.Structure):
@@ -198,7 +199,7 @@ EXPORTS = [
     "hala_rt_get_packed_primitives", "hala_rt_get_env_distribution", "hala_rt_get_texture_info",
     "hala_rt_read_texture_level", "hala_rt_sample_texture_host", "hala_rt_set_tile_shard",
     "hala_rt_tile_buffer", "hala_rt_get_stream", "hala_rt_scatter_gathered_tiles", "hala_rt_scatter_gathered_tiles_on_stream", "hala_rt_trace_rays",
-    "hala_rt_trace_rays_host", "hala_rt_trace_rays_indirect", "hala_rt_get_bvh_info", "hala_rt_download_bvh",
+    "hala_rt_trace_rays_host", "hala_rt_trace_rays_indirect", "hala_rt_get_bvh_info", "hala_rt_download_bvh", "hala_rt_download_instance_refs",
     "hala_rt_update_node_transform", "hala_rt_update_vertices", "hala_rt_update_material", "hala_rt_refit", "hala_envmap_build_distribution",
     "hala_tonemap_pixels", "hala_write_pfm", "hala_rtprog_parse_desc", "hala_version",
     "hala_scene_load_gltf", "hala_scene_get_desc", "hala_scene_free", "hala_load_float_image",

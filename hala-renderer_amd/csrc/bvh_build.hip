@@ -61,8 +61,9 @@ RT_DI f3 transform_point(const float* m, f3 p) {
 // line held this kernel at 1.07 ms per million triangles; each block leaves its bounds in block_ord and k_bounds_reduce folds them.
 __global__ void __launch_bounds__(256) k_flatten(const hala_gpu_mesh_data* __restrict__ prims, const uint32_t* __restrict__ first_tri,
                                                   uint32_t inst_count, uint32_t n, Tri* __restrict__ tris_by_id, ShadeTri* __restrict__ shade_tris,
-                                                  uint32_t* __restrict__ tri_instance, Box6* __restrict__ tri_box,
-                                                  uint32_t* __restrict__ block_ord /* [gridDim.x][6] min xyz, max xyz */) {
+                                                  Box6* __restrict__ tri_box,
+                                                  uint32_t* __restrict__ block_ord /* [gridDim.x][6] min xyz, max xyz */,
+                                                  const uint32_t* __restrict__ gid_first, const uint32_t* __restrict__ inst_index, int object_space) {
   __shared__ float4 stage[256 * 8];
   __shared__ uint32_t wave_ord[4][6];
   const uint32_t tid = threadIdx.x, base = blockIdx.x * 256u, g = base + tid;
@@ -85,20 +86,20 @@ __global__ void __launch_bounds__(256) k_flatten(const hala_gpu_mesh_data* __res
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const hala_vertex& vx = vb[idx[c]];
-      v[c] = transform_point(md.transform, ld3(vx.position));
+      v[c] = object_space ? ld3(vx.position) : transform_point(md.transform, ld3(vx.position));  // RENDER_SPEC 4.5: an instanced primitive keeps its local positions
       float* nc = c == 0 ? st.n0 : (c == 1 ? st.n1 : st.n2);
 #pragma unroll
       for (int k = 0; k < 3; ++k) { nc[k] = vx.normal[k]; st.tg[c][k] = vx.tangent[k]; }
       st.uv[c][0] = vx.tex_coord[0]; st.uv[c][1] = vx.tex_coord[1];
     }
-    st.inst = lo; st.material = md.material_index;
+    const uint32_t inst = inst_index ? inst_index[lo] : lo;
+    st.inst = inst; st.material = md.material_index;
     const f3 e1 = v[1] - v[0], e2 = v[2] - v[0];
     const f3 gc = cross3(e1, e2);  // RENDER_SPEC 6: the geometric normal is normalize(cross(e1, e2)) of the stored world-space edges
     st.gcross[0] = gc.x; st.gcross[1] = gc.y; st.gcross[2] = gc.z;
-    tri[0] = make_float4(v[0].x, v[0].y, v[0].z, __uint_as_float(g));
+    tri[0] = make_float4(v[0].x, v[0].y, v[0].z, __uint_as_float(gid_first ? gid_first[lo] + lt : g));
     tri[1] = make_float4(e1.x, e1.y, e1.z, 0.0f);
     tri[2] = make_float4(e2.x, e2.y, e2.z, 0.0f);
-    tri_instance[g] = lo;
     b.mn[0] = fminf(v[0].x, fminf(v[1].x, v[2].x)); b.mx[0] = fmaxf(v[0].x, fmaxf(v[1].x, v[2].x));
     b.mn[1] = fminf(v[0].y, fminf(v[1].y, v[2].y)); b.mx[1] = fmaxf(v[0].y, fmaxf(v[1].y, v[2].y));
     b.mn[2] = fminf(v[0].z, fminf(v[1].z, v[2].z)); b.mx[2] = fmaxf(v[0].z, fmaxf(v[1].z, v[2].z));
@@ -935,7 +936,7 @@ static std::string flatten_and_bounds(BvhBuffers& b, BvhTopology& t, hipStream_t
   const uint32_t n = b.tri_count;
   if (n) {
     hipLaunchKernelGGL(k_flatten, dim3(nblk(n)), dim3(256), 0, s, b.primitives, b.inst_first_tri, b.instance_count, n, b.tris_by_id, b.shade_tris,
-                       b.tri_instance, t.tri_box.as<Box6>(), t.block_ord.as<uint32_t>());
+                       t.tri_box.as<Box6>(), t.block_ord.as<uint32_t>(), b.gid_first, b.inst_index, b.object_space ? 1 : 0);
     hipLaunchKernelGGL(k_bounds_reduce, dim3(1), dim3(256), 0, s, t.block_ord.as<uint32_t>(), nblk(n), t.scene_ord.as<uint32_t>());
   }
   uint32_t ord[6];
@@ -1269,6 +1270,21 @@ std::string bvh_build(BvhBuffers& b, uint32_t leaf_max, hipStream_t s) {
     HIP_TRY(hipMemcpyAsync(t.sorted_ids.p, &zero, 4, hipMemcpyHostToDevice, s));
   }
   if (!(e = fit_and_emit(b, t, s)).empty()) return e;
+  return "";
+}
+
+__global__ void __launch_bounds__(256) k_relocate(BvhNode4* __restrict__ nodes, uint32_t count, uint32_t node_offset, uint32_t tri_offset) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count * 4u) return;
+  uint32_t& ref = nodes[i >> 2].ref[i & 3u];
+  if (ref == kAbsent) return;
+  ref += (ref & kLeafRef) ? tri_offset : node_offset;  // a leaf's first triangle sits in the low 28 bits: the sum stays below 2^28 (checked by the caller)
+}
+std::string bvh_relocate(BvhBuffers& b, uint32_t node_offset, uint32_t tri_offset, hipStream_t s) {
+  if (node_offset == 0u && tri_offset == 0u) return "";
+  if ((unsigned long long)tri_offset + b.tri_count >= (1ull << 28)) return "bvh_relocate: the scene holds 2^28 triangles or more";
+  hipLaunchKernelGGL(k_relocate, dim3(nblk(b.node_count * 4u)), dim3(256), 0, s, b.nodes, b.node_count, node_offset, tri_offset);
+  HIP_TRY(hipGetLastError());
   return "";
 }
 

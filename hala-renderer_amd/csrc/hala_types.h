@@ -45,6 +45,34 @@ struct alignas(16) BvhNode4 {
 };
 static_assert(sizeof(BvhNode4) == 64, "BVH4 node is 64 B");
 constexpr uint32_t kLeafRef = 0x80000000u;
+// Two-level trees (RENDER_SPEC 4.5): the top levels of the node array are a tree over INSTANCES.  A child reference with bit 31 set and
+// count bits 7 (large-scene builds emit leaves of <= 4 triangles, so the pattern is free) is an instance leaf: bits 27..0 index the
+// InstRef table; the traversal moves the ray into the instance's object space and goes on at the root of its primitive's own tree,
+// whose triangles are stored ONCE however many instances reference the primitive.
+constexpr uint32_t kInstLeafTag = 0xF0000000u;
+constexpr uint32_t kExitRef = 0xfffffffeu;  // stack sentinel: "leaving the instance" (the three entries below it hold the world-space ray)
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline bool is_inst_leaf(uint32_t ref) { return (ref & kInstLeafTag) == kInstLeafTag && ref < kExitRef; }
+// one instance of an instanced primitive: world -> object (rows of the inverse of the upper 3x3 of object -> world, and its translation:
+// p' = rows * (p - tr); RENDER_SPEC 4.5), where its primitive's tree starts, and what turns the tree's local triangle numbers into
+// global ids (instance order, RENDER_SPEC 3) and shading-record indices
+struct alignas(64) InstRef {
+  float r0[3], r1[3], r2[3], tr[3];
+  uint32_t root;        // node index of the primitive's tree
+  uint32_t gid_base;    // global id of the instance's first triangle
+  uint32_t shade_base;  // index of the primitive's first shading record
+  uint32_t inst;        // index into SceneView::primitives
+};
+static_assert(sizeof(InstRef) == 64, "instance reference is 64 B");
+// per instance, in instance order (= ascending first_tri): how a global triangle id finds its shading record
+struct InstInfo {
+  uint32_t first_tri;   // global id of the instance's first triangle
+  uint32_t shade_base;  // shading record of that triangle (shared by all instances of an instanced primitive)
+  uint32_t instanced;   // 1: intersected in object space; its shading records hold object-space geometry
+  uint32_t pad;
+};
 
 // 48-B triangle (RENDER_SPEC §4.1): v0|global id, e1 = v1-v0, e2 = v2-v0 in world space.
 struct alignas(16) Tri {
@@ -118,7 +146,6 @@ struct SceneView {
                                // whose triangles are degenerate (never hit) in this copy — no test in the kernels, the launcher swaps the pointer
   const Tri* tris_by_id;       // global-id order (for shading)
   const ShadeTri* shade_tris;  // global-id order: per-vertex attributes of the hit triangle in one record
-  const uint32_t* tri_instance;  // global id -> instance
   const uint32_t* inst_first_tri;
   const hala_gpu_mesh_data* primitives;  // set 1 binding 4
   const hala_gpu_material* materials;    // set 1 binding 3
@@ -129,6 +156,11 @@ struct SceneView {
   const float* env_marginal;     // set 0 binding 7[0]
   const float* env_conditional;  // set 0 binding 7[1]
   uint32_t node_count, tri_count, lds_nodes, lds_tris;
+  // two-level trees (RENDER_SPEC 4.5): 0 for scenes without instanced primitives — shading records are then indexed by global id
+  const InstRef* inst_refs;
+  const InstInfo* inst_info;
+  uint32_t instance_count;
+  uint32_t two_level;
   uint32_t any_translucent;   // 1: some material is translucent or bounds a medium (RENDER_SPEC 7.1d / 7.1g): the any-hit launches run their ALPHA variants
   uint32_t scatter_media;     // 1: some material holds a scattering medium (RENDER_SPEC 7.1f): the SCATTER shade kernels apply
   uint32_t simple_materials;  // 1: every material is an untextured, opaque DIFFUSE one without a medium (the SIMPLE shade kernels apply)

@@ -131,7 +131,7 @@ RT_DI uint32_t work_take(WorkCounters* wc, WorkCursor& c, uint32_t n, uint32_t w
 // (and the queue is not dry) the wave dequeues exactly that many rays and hands them to its idle lanes by ballot rank
 // — consecutive queue entries go to consecutive idle lanes, so refill loads stay as coalesced as the holes allow.
 // Source: load(i, &o, &d, &tmin, &tmax) fetches queue entry i (false: no ray there); done(i, trav, payload) consumes the result.
-template <bool ANY, bool COUNT, bool STAGED, bool ALPHA, class Source>
+template <bool ANY, bool COUNT, bool STAGED, bool ALPHA, bool INST, class Source>
 RT_DI void persistent_trace(const SceneView& sv, const TraverseLds& lds, uint2* spill, WorkCounters* work, uint32_t n, uint32_t refill,
                             Source& src, StepCounters& sc) {
   WorkCursor cur = work_begin(n);
@@ -187,9 +187,9 @@ RT_DI void persistent_trace(const SceneView& sv, const TraverseLds& lds, uint2* 
       if (COUNT && lane_id() == 0u) sc.wave_steps++;  // lane 0 runs every iteration of this wave-uniform loop
       // every lane calls it: the large-scene variant deals the wave's leaf work out over all 64 lanes (traverse.h)
 #ifdef RT_NO_DEFER
-      if (trav_step<ANY, COUNT, STAGED, ALPHA>(sv, lds, spill, t, has, sc)) { src.done(idx, t, pay); has = false; }
+      if (trav_step<ANY, COUNT, STAGED, ALPHA, INST>(sv, lds, spill, t, has, sc)) { src.done(idx, t, pay); has = false; }
 #else
-      if (trav_step<ANY, COUNT, STAGED, ALPHA>(sv, lds, spill, t, has, sc)) { fin = true; has = false; }
+      if (trav_step<ANY, COUNT, STAGED, ALPHA, INST>(sv, lds, spill, t, has, sc)) { fin = true; has = false; }
 #endif
       const uint32_t nidle = (uint32_t)__popcll(__ballot(!has));
       if (nidle == 64u || (more && nidle >= refill)) break;
@@ -312,7 +312,7 @@ RT_DI void flush_counters(Control* ctl, int kind, const StepCounters& sc) {
 // ---------------------------------------------------------------------------------------------------------
 // K5a: persistent closest-hit traversal over a compact ray queue (coalesced 32-B ray reads, 16-B hit writes)
 // ---------------------------------------------------------------------------------------------------------
-template <bool ANY, bool COUNT, bool STAGED, bool ALPHA>
+template <bool ANY, bool COUNT, bool STAGED, bool ALPHA, bool INST>
 __global__ void __launch_bounds__(kTraverseThreads, STAGED ? kTraverseWavesPerSimdStaged : kTraverseWavesPerSimd)
 k_trace_batch(SceneView sv, const hala_ray* __restrict__ rays, hala_hit* __restrict__ hits, const uint32_t* __restrict__ n_ptr,
               uint32_t n_imm, WorkCounters* __restrict__ work, uint2* __restrict__ spill_base, Control* __restrict__ ctl, int account,
@@ -325,13 +325,13 @@ k_trace_batch(SceneView sv, const hala_ray* __restrict__ rays, hala_hit* __restr
     if (ANY) ctl->rays_shadow += n; else ctl->rays_closest += n;
   }
   BatchSource src{rays, hits, ANY, account != 0, STAGED && refill == 64u};
-  persistent_trace<ANY, COUNT, STAGED, ALPHA>(sv, lds, spill, work, n, refill, src, sc);
+  persistent_trace<ANY, COUNT, STAGED, ALPHA, INST>(sv, lds, spill, work, n, refill, src, sc);
   if (COUNT) flush_counters(ctl, ANY ? 1 : 0, sc);
 }
 
 // K5a at depth 0: the camera rays are generated in the lanes that trace them (RENDER_SPEC §5) — no ray-generation kernel,
 // no primary-ray queue in HBM; entry i of the hit queue belongs to path slot i.  `n_account` = real (non-padding) paths.
-template <bool COUNT, bool STAGED>
+template <bool COUNT, bool STAGED, bool INST>
 __global__ void __launch_bounds__(kTraverseThreads, STAGED ? kTraverseWavesPerSimdStaged : kTraverseWavesPerSimd)
 k_trace_primary(SceneView sv, FrameConst fc, hala_hit* __restrict__ hits, WorkCounters* __restrict__ work, uint2* __restrict__ spill_base,
                 Control* __restrict__ ctl, uint32_t n_account, uint32_t refill) {
@@ -340,7 +340,7 @@ k_trace_primary(SceneView sv, FrameConst fc, hala_hit* __restrict__ hits, WorkCo
   StepCounters sc;
   if (blockIdx.x == 0 && threadIdx.x == 0) ctl->rays_closest += n_account;
   CameraSource src{fc, sv, hits, STAGED && refill == 64u};
-  persistent_trace<false, COUNT, STAGED, false>(sv, lds, spill, work, fc.slot_count, refill, src, sc);
+  persistent_trace<false, COUNT, STAGED, false, INST>(sv, lds, spill, work, fc.slot_count, refill, src, sc);
   if (COUNT) flush_counters(ctl, 0, sc);
 }
 
@@ -348,7 +348,7 @@ k_trace_primary(SceneView sv, FrameConst fc, hala_hit* __restrict__ hits, WorkCo
 // K5c: shadow traversal of the NEE connections of one bounce; unoccluded contributions are added to the
 // path's radiance in the fixed order light, environment (RENDER_SPEC §6)
 // ---------------------------------------------------------------------------------------------------------
-template <bool COUNT, bool STAGED, bool ALPHA>
+template <bool COUNT, bool STAGED, bool ALPHA, bool INST>
 __global__ void __launch_bounds__(kTraverseThreads, STAGED ? kTraverseWavesPerSimdStaged : kTraverseWavesPerSimd)
 k_trace_shadow(SceneView sv, Queues q, PathState ps, Control* __restrict__ ctl, uint32_t depth, uint32_t kind, uint2* __restrict__ spill_base,
                uint32_t refill) {
@@ -357,7 +357,7 @@ k_trace_shadow(SceneView sv, Queues q, PathState ps, Control* __restrict__ ctl, 
   uint2* spill = spill_base ? spill_base + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * kStackSpill : nullptr;
   StepCounters sc;
   ShadowSource<(STAGED || RT_SHADOW_PREFETCH), ALPHA> src{q.shadow[kind], kind ? ps.radiance_env : ps.radiance};
-  persistent_trace<true, COUNT, STAGED, ALPHA>(sv, lds, spill, &ctl->work_shadow[kind], n, refill, src, sc);
+  persistent_trace<true, COUNT, STAGED, ALPHA, INST>(sv, lds, spill, &ctl->work_shadow[kind], n, refill, src, sc);
   if (COUNT) flush_counters(ctl, 1, sc);
 }
 
@@ -370,7 +370,7 @@ k_trace_shadow(SceneView sv, Queues q, PathState ps, Control* __restrict__ ctl, 
 // do not achieve this: each takes the chip from the other all the time, profiles/r02_experiments.txt.)  Not used by updates that carry
 // per-launch timing events or counting kernels.
 // ---------------------------------------------------------------------------------------------------------
-template <bool STAGED, bool ALPHA>
+template <bool STAGED, bool ALPHA, bool INST>
 __global__ void __launch_bounds__(kTraverseThreads, STAGED ? kTraverseWavesPerSimdStaged : kTraverseWavesPerSimd)
 k_trace_shadow_then_batch(SceneView sv, const Tri* __restrict__ tris_any, Queues q, PathState ps, Control* __restrict__ ctl, uint32_t depth,
                           uint32_t kinds, const hala_ray* __restrict__ rays, hala_hit* __restrict__ hits, uint2* __restrict__ spill_base, uint32_t refill) {
@@ -383,14 +383,14 @@ k_trace_shadow_then_batch(SceneView sv, const Tri* __restrict__ tris_any, Queues
     for (uint32_t kind = 0; kind < 2u; ++kind) {  // bit 0: light connections, bit 1: environment connections
       if (!((kinds >> kind) & 1u)) continue;
       ShadowSource<(STAGED || RT_SHADOW_PREFETCH), ALPHA> src{q.shadow[kind], kind ? ps.radiance_env : ps.radiance};
-      persistent_trace<true, false, STAGED, ALPHA>(sva, lds, spill, &ctl->work_shadow[kind], ctl->n_shadow[kind][depth], refill, src, sc);
+      persistent_trace<true, false, STAGED, ALPHA, INST>(sva, lds, spill, &ctl->work_shadow[kind], ctl->n_shadow[kind][depth], refill, src, sc);
     }
   }
   if (rays == nullptr) return;  // the last bounce: its two shadow passes share the launch, no closest-hit pass follows
   const uint32_t n = ctl->n_active[depth + 1u];
   if (blockIdx.x == 0 && threadIdx.x == 0) ctl->rays_closest += n;
   BatchSource src{rays, hits, false, true, STAGED && refill == 64u};
-  persistent_trace<false, false, STAGED, false>(sv, lds, spill, &ctl->work_closest, n, refill, src, sc);
+  persistent_trace<false, false, STAGED, false, INST>(sv, lds, spill, &ctl->work_closest, n, refill, src, sc);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -797,10 +797,10 @@ uint32_t traverse_stack_spill_levels() { return kStackSpill; }
 uint32_t traverse_max_leaf(bool staged) { return staged ? 8u : (uint32_t)kLeafSlots; }
 uint32_t traverse_blocks_per_cu(size_t dynamic_lds_bytes, bool staged) {
   int a = 0, b = 0;
-  const hipError_t ea = staged ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_batch<false, false, true, false>, kTraverseThreads, dynamic_lds_bytes)
-                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_batch<false, false, false, false>, kTraverseThreads, dynamic_lds_bytes);
-  const hipError_t eb = staged ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_trace_shadow<false, true, false>, kTraverseThreads, dynamic_lds_bytes)
-                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_trace_shadow<false, false, false>, kTraverseThreads, dynamic_lds_bytes);
+  const hipError_t ea = staged ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_batch<false, false, true, false, false>, kTraverseThreads, dynamic_lds_bytes)
+                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_batch<false, false, false, false, false>, kTraverseThreads, dynamic_lds_bytes);
+  const hipError_t eb = staged ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_trace_shadow<false, true, false, false>, kTraverseThreads, dynamic_lds_bytes)
+                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_trace_shadow<false, false, false, false>, kTraverseThreads, dynamic_lds_bytes);
   if (ea != hipSuccess || eb != hipSuccess) return 0;
   return (uint32_t)std::max(0, std::min(a, b));
 }
@@ -809,45 +809,52 @@ static size_t traverse_smem(const SceneView& sv) {
 }
 
 // the traversal kernels are compiled per (any-hit, counting, BVH staged in LDS); all three are launch-time constants
-template <bool ANY, bool COUNT, bool STAGED, bool ALPHA>
+template <bool ANY, bool COUNT, bool STAGED, bool ALPHA, bool INST>
 static void launch_trace_batch_t(const LaunchCfg& lc, const SceneView& sv, const hala_ray* rays, hala_hit* hits, const uint32_t* n_ptr,
                                  uint32_t n_imm, WorkCounters* work, Control* ctl, int acc, size_t smem, hipStream_t s) {
-  hipLaunchKernelGGL((k_trace_batch<ANY, COUNT, STAGED, ALPHA>), dim3(lc.persistent_blocks), dim3(kTraverseThreads), smem, s, sv, rays, hits, n_ptr, n_imm,
+  hipLaunchKernelGGL((k_trace_batch<ANY, COUNT, STAGED, ALPHA, INST>), dim3(lc.persistent_blocks), dim3(kTraverseThreads), smem, s, sv, rays, hits, n_ptr, n_imm,
                      work, lc.spill, ctl, acc, lc.refill);
 }
-// the traversal kernels are compiled per (any-hit, counting, BVH staged in LDS) and, for the any-hit ones, per "the scene has translucent
-// materials" (RENDER_SPEC 7.1d: the ALPHA variants carry the texture fetch that decides whether a flagged triangle blocks); all launch-time constants
+// the traversal kernels are compiled per (any-hit, counting, BVH staged in LDS | tree with instance levels) and, for the any-hit ones, per
+// "the scene has translucent materials" (RENDER_SPEC 7.1d: the ALPHA variants carry the texture fetch that decides whether a flagged
+// triangle blocks); all launch-time constants
 void launch_trace_batch(const LaunchCfg& lc, const SceneView& sv, const hala_ray* rays, hala_hit* hits, const uint32_t* n_ptr,
                         uint32_t n_imm, WorkCounters* work, Control* ctl, bool any, bool count, bool account, hipStream_t s) {
   const int acc = account ? 1 : 0;
   using Fn = void (*)(const LaunchCfg&, const SceneView&, const hala_ray*, hala_hit*, const uint32_t*, uint32_t, WorkCounters*, Control*, int, size_t,
                       hipStream_t);
-  static const Fn table[12] = {launch_trace_batch_t<false, false, false, false>, launch_trace_batch_t<false, false, true, false>,
-                               launch_trace_batch_t<false, true, false, false>,  launch_trace_batch_t<false, true, true, false>,
-                               launch_trace_batch_t<true, false, false, false>,  launch_trace_batch_t<true, false, true, false>,
-                               launch_trace_batch_t<true, true, false, false>,   launch_trace_batch_t<true, true, true, false>,
-                               launch_trace_batch_t<true, false, false, true>,   launch_trace_batch_t<true, false, true, true>,
-                               launch_trace_batch_t<true, true, false, true>,    launch_trace_batch_t<true, true, true, true>};
+  // index: tree (0 large one-level, 1 LDS-staged, 2 two-level) + 3 * (count + 2 * ray kind (0 closest, 1 any, 2 any with ALPHA))
+  static const Fn table[18] = {
+      launch_trace_batch_t<false, false, false, false, false>, launch_trace_batch_t<false, false, true, false, false>, launch_trace_batch_t<false, false, false, false, true>,
+      launch_trace_batch_t<false, true, false, false, false>,  launch_trace_batch_t<false, true, true, false, false>,  launch_trace_batch_t<false, true, false, false, true>,
+      launch_trace_batch_t<true, false, false, false, false>,  launch_trace_batch_t<true, false, true, false, false>,  launch_trace_batch_t<true, false, false, false, true>,
+      launch_trace_batch_t<true, true, false, false, false>,   launch_trace_batch_t<true, true, true, false, false>,   launch_trace_batch_t<true, true, false, false, true>,
+      launch_trace_batch_t<true, false, false, true, false>,   launch_trace_batch_t<true, false, true, true, false>,   launch_trace_batch_t<true, false, false, true, true>,
+      launch_trace_batch_t<true, true, false, true, false>,    launch_trace_batch_t<true, true, true, true, false>,    launch_trace_batch_t<true, true, false, true, true>};
   SceneView sva = sv;
   if (any) sva.tris = sv.tris_any;  // RENDER_SPEC 7.1d
-  const int base = any ? (sv.any_translucent ? 8 : 4) : 0;
-  table[base | (count ? 2 : 0) | (sv.staged ? 1 : 0)](lc, sva, rays, hits, n_ptr, n_imm, work, ctl, acc, traverse_smem(sv), s);
+  const int kind = any ? (sv.any_translucent ? 2 : 1) : 0;
+  const int tree = sv.staged ? 1 : (sv.two_level ? 2 : 0);
+  table[tree + 3 * ((count ? 1 : 0) + 2 * kind)](lc, sva, rays, hits, n_ptr, n_imm, work, ctl, acc, traverse_smem(sv), s);
 }
 
-template <bool COUNT, bool STAGED, bool ALPHA>
+template <bool COUNT, bool STAGED, bool ALPHA, bool INST>
 static void launch_trace_shadow_t(const LaunchCfg& lc, const SceneView& sv, const Queues& q, const PathState& ps, Control* ctl, uint32_t depth, uint32_t kind,
                                   size_t smem, hipStream_t s) {
-  hipLaunchKernelGGL((k_trace_shadow<COUNT, STAGED, ALPHA>), dim3(lc.persistent_blocks), dim3(kTraverseThreads), smem, s, sv, q, ps, ctl, depth, kind, lc.spill, lc.refill);
+  hipLaunchKernelGGL((k_trace_shadow<COUNT, STAGED, ALPHA, INST>), dim3(lc.persistent_blocks), dim3(kTraverseThreads), smem, s, sv, q, ps, ctl, depth, kind, lc.spill, lc.refill);
 }
 void launch_trace_shadow(const LaunchCfg& lc, const SceneView& sv0, const Queues& q, const PathState& ps, Control* ctl, uint32_t depth,
                          uint32_t kind, bool count, hipStream_t s) {
   SceneView sv = sv0;
   sv.tris = sv0.tris_any;  // RENDER_SPEC 7.1d: shadow rays traverse the copy in which invisible surfaces are degenerate and translucent ones flagged
   using Fn = void (*)(const LaunchCfg&, const SceneView&, const Queues&, const PathState&, Control*, uint32_t, uint32_t, size_t, hipStream_t);
-  static const Fn table[8] = {launch_trace_shadow_t<false, false, false>, launch_trace_shadow_t<false, true, false>, launch_trace_shadow_t<true, false, false>,
-                              launch_trace_shadow_t<true, true, false>,   launch_trace_shadow_t<false, false, true>, launch_trace_shadow_t<false, true, true>,
-                              launch_trace_shadow_t<true, false, true>,   launch_trace_shadow_t<true, true, true>};
-  table[(sv.any_translucent ? 4 : 0) | (count ? 2 : 0) | (sv.staged ? 1 : 0)](lc, sv, q, ps, ctl, depth, kind, traverse_smem(sv0), s);
+  // index: tree (0 large one-level, 1 LDS-staged, 2 two-level) + 3 * (count + 2 * alpha)
+  static const Fn table[12] = {launch_trace_shadow_t<false, false, false, false>, launch_trace_shadow_t<false, true, false, false>, launch_trace_shadow_t<false, false, false, true>,
+                               launch_trace_shadow_t<true, false, false, false>,  launch_trace_shadow_t<true, true, false, false>,  launch_trace_shadow_t<true, false, false, true>,
+                               launch_trace_shadow_t<false, false, true, false>,  launch_trace_shadow_t<false, true, true, false>,  launch_trace_shadow_t<false, false, true, true>,
+                               launch_trace_shadow_t<true, false, true, false>,   launch_trace_shadow_t<true, true, true, false>,   launch_trace_shadow_t<true, false, true, true>};
+  const int tree = sv.staged ? 1 : (sv.two_level ? 2 : 0);
+  table[tree + 3 * ((count ? 1 : 0) + 2 * (sv.any_translucent ? 1 : 0))](lc, sv, q, ps, ctl, depth, kind, traverse_smem(sv0), s);
 }
 
 // the fused launch; false: the caller must issue the two launches separately (an LDS-staged scene whose any-hit rays traverse a
@@ -859,11 +866,14 @@ bool launch_trace_shadow_then_batch(const LaunchCfg& lc, const SceneView& sv, co
   const dim3 grid(lc.persistent_blocks), block(kTraverseThreads);
   const hala_ray* rays = with_closest ? q.rays[(depth + 1u) & 1u] : nullptr;
   if (sv.staged) {
-    if (sv.any_translucent) hipLaunchKernelGGL((k_trace_shadow_then_batch<true, true>), grid, block, smem, s, sv, sv.tris_any, q, ps, ctl, depth, kinds, rays, q.hits, lc.spill, lc.refill);
-    else hipLaunchKernelGGL((k_trace_shadow_then_batch<true, false>), grid, block, smem, s, sv, sv.tris_any, q, ps, ctl, depth, kinds, rays, q.hits, lc.spill, lc.refill);
+    if (sv.any_translucent) hipLaunchKernelGGL((k_trace_shadow_then_batch<true, true, false>), grid, block, smem, s, sv, sv.tris_any, q, ps, ctl, depth, kinds, rays, q.hits, lc.spill, lc.refill);
+    else hipLaunchKernelGGL((k_trace_shadow_then_batch<true, false, false>), grid, block, smem, s, sv, sv.tris_any, q, ps, ctl, depth, kinds, rays, q.hits, lc.spill, lc.refill);
+  } else if (sv.two_level) {
+    if (sv.any_translucent) hipLaunchKernelGGL((k_trace_shadow_then_batch<false, true, true>), grid, block, smem, s, sv, sv.tris_any, q, ps, ctl, depth, kinds, rays, q.hits, lc.spill, lc.refill);
+    else hipLaunchKernelGGL((k_trace_shadow_then_batch<false, false, true>), grid, block, smem, s, sv, sv.tris_any, q, ps, ctl, depth, kinds, rays, q.hits, lc.spill, lc.refill);
   } else {
-    if (sv.any_translucent) hipLaunchKernelGGL((k_trace_shadow_then_batch<false, true>), grid, block, smem, s, sv, sv.tris_any, q, ps, ctl, depth, kinds, rays, q.hits, lc.spill, lc.refill);
-    else hipLaunchKernelGGL((k_trace_shadow_then_batch<false, false>), grid, block, smem, s, sv, sv.tris_any, q, ps, ctl, depth, kinds, rays, q.hits, lc.spill, lc.refill);
+    if (sv.any_translucent) hipLaunchKernelGGL((k_trace_shadow_then_batch<false, true, false>), grid, block, smem, s, sv, sv.tris_any, q, ps, ctl, depth, kinds, rays, q.hits, lc.spill, lc.refill);
+    else hipLaunchKernelGGL((k_trace_shadow_then_batch<false, false, false>), grid, block, smem, s, sv, sv.tris_any, q, ps, ctl, depth, kinds, rays, q.hits, lc.spill, lc.refill);
   }
   return true;
 }
@@ -876,11 +886,14 @@ void launch_trace_primary(const LaunchCfg& lc, const SceneView& sv, const FrameC
   const uint32_t refill = refill_env ? refill_env : (sv.staged ? lc.refill : std::max(lc.refill, 40u));
   dim3 grid(lc.persistent_blocks), block(kTraverseThreads);
   if (sv.staged) {
-    if (count) hipLaunchKernelGGL((k_trace_primary<true, true>), grid, block, smem, s, sv, fc, hits, work, lc.spill, ctl, n_account, refill);
-    else hipLaunchKernelGGL((k_trace_primary<false, true>), grid, block, smem, s, sv, fc, hits, work, lc.spill, ctl, n_account, refill);
+    if (count) hipLaunchKernelGGL((k_trace_primary<true, true, false>), grid, block, smem, s, sv, fc, hits, work, lc.spill, ctl, n_account, refill);
+    else hipLaunchKernelGGL((k_trace_primary<false, true, false>), grid, block, smem, s, sv, fc, hits, work, lc.spill, ctl, n_account, refill);
+  } else if (sv.two_level) {
+    if (count) hipLaunchKernelGGL((k_trace_primary<true, false, true>), grid, block, smem, s, sv, fc, hits, work, lc.spill, ctl, n_account, refill);
+    else hipLaunchKernelGGL((k_trace_primary<false, false, true>), grid, block, smem, s, sv, fc, hits, work, lc.spill, ctl, n_account, refill);
   } else {
-    if (count) hipLaunchKernelGGL((k_trace_primary<true, false>), grid, block, smem, s, sv, fc, hits, work, lc.spill, ctl, n_account, refill);
-    else hipLaunchKernelGGL((k_trace_primary<false, false>), grid, block, smem, s, sv, fc, hits, work, lc.spill, ctl, n_account, refill);
+    if (count) hipLaunchKernelGGL((k_trace_primary<true, false, false>), grid, block, smem, s, sv, fc, hits, work, lc.spill, ctl, n_account, refill);
+    else hipLaunchKernelGGL((k_trace_primary<false, false, false>), grid, block, smem, s, sv, fc, hits, work, lc.spill, ctl, n_account, refill);
   }
 }
 void launch_shade(const FrameConst& fc, const SceneView& sv, const Queues& q, const PathState& ps, Control* ctl, uint32_t depth, hipStream_t s) {

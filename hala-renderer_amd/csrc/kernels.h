@@ -4,6 +4,7 @@
 
 #include <cstdlib>
 #include <string>
+#include <vector>
 
 #include "hala_types.h"
 
@@ -60,11 +61,15 @@ struct BuildOptions {
   uint32_t collapse_look_every = 0;  // levels of the 4-wide collapse between two looks (default 8)
 };
 struct BvhBuffers {
-  // inputs (device)
-  const hala_gpu_mesh_data* primitives;  // per instance
-  const uint32_t* inst_first_tri;        // [instance_count + 1] prefix of triangle counts
+  // inputs (device): the instances whose triangles this tree holds, in instance order
+  const hala_gpu_mesh_data* primitives;  // per listed instance
+  const uint32_t* inst_first_tri;        // [instance_count + 1] prefix of triangle counts WITHIN this tree
   uint32_t instance_count;
   uint32_t tri_count;
+  // trees over a subset of the scene (RENDER_SPEC 4.5): null = the whole scene, flattened (triangle k of the tree has global id k)
+  const uint32_t* gid_first = nullptr;   // per listed instance: global id of its first triangle
+  const uint32_t* inst_index = nullptr;  // per listed instance: its index in the scene's instance list (kAbsent: shared by several)
+  bool object_space = false;             // the tree of an instanced primitive: vertex positions as they are, triangle ids local
   // outputs (device, allocated by the caller)
   Tri* tris_by_id;         // [tri_count]
   Tri* tris;               // [tri_count] BVH order
@@ -74,7 +79,6 @@ struct BvhBuffers {
   uint32_t material_count = 0;
   const uint8_t* material_kind = nullptr;       // per material: shading kind (hala_types.h: shade_kind_of), stamped into word 11 of the BVH-order triangles
   ShadeTri* shade_tris;    // [tri_count] global-id order
-  uint32_t* tri_instance;  // [tri_count]
   BvhNode4* nodes;         // capacity >= max(tri_count - 1, 1)
   void* topology = nullptr;  // builder state kept for refit (freed with bvh_free_topology)
   BuildOptions opt;
@@ -88,7 +92,16 @@ struct BvhBuffers {
 std::string bvh_build(BvhBuffers& b, uint32_t leaf_max, hipStream_t s);
 // Re-flattens (instance transforms / vertices may have changed) and refits the existing topology bottom-up.
 std::string bvh_refit(BvhBuffers& b, hipStream_t s);
+// A tree built into a sub-range of the scene's node / triangle arrays numbers its nodes and triangles from 0: make its child references
+// absolute (inner: += node_offset, leaf: first triangle += tri_offset).  After every bvh_build / bvh_refit of such a tree.
+std::string bvh_relocate(BvhBuffers& b, uint32_t node_offset, uint32_t tri_offset, hipStream_t s);
 void bvh_free_topology(void* topology);
+
+// bvh_tlas.cpp — the instance levels of a two-level tree (RENDER_SPEC 4.5), built on the host.  An item is a world-space box with the
+// child reference a node slot gets for it: an instance leaf (kInstLeafTag | InstRef index) or the root node of a subtree that needs no
+// transform; `need` = traversal stack entries a ray can need behind it.  Returns the node count (nodes in breadth-first order, root 0).
+struct TlasItem { float mn[3], mx[3]; uint32_t ref, need; };
+uint32_t tlas_build(const std::vector<TlasItem>& items, std::vector<BvhNode4>& out, uint32_t* levels, uint32_t* stack_need);
 
 // envmap.hip — A1: EnvMap::build_distribution_maps (src/envmap.rs:239-388) on the GPU
 // d_rgba: W*H float4; outputs device pointers: total_sum[1], marginal[H], conditional[W*H]

@@ -134,10 +134,32 @@ struct hala_rt_renderer {
   std::vector<TexDesc> host_textures;
 
   BvhBuffers bvh{};
+  // two-level trees (RENDER_SPEC 4.5): scenes in which some primitive is referenced by several instances.  `bvh` then only carries the
+  // totals; the trees live in `blas` — [0] the world-space tree over the triangles of all instances that are NOT instanced (if any), then
+  // one object-space tree per instanced primitive — as sub-ranges of the node / triangle / shading-record arrays, behind the instance
+  // levels (the first tlas_capacity nodes), which are rebuilt on the host whenever a node moves.
+  struct Blas {
+    BvhBuffers b{};
+    uint32_t node_off = 0, tri_off = 0, node_cap = 0;
+    bool object_space = false;
+    uint32_t prim = 0;                      // object_space: the primitive (index into hs.prims)
+    std::vector<uint32_t> insts;            // world tree: the instances it holds, in instance order
+    DeviceArray<hala_gpu_mesh_data> d_md;
+    DeviceArray<uint32_t> d_first, d_gid, d_inst;
+    ~Blas() { if (b.topology) bvh_free_topology(b.topology); }
+  };
+  std::vector<std::unique_ptr<Blas>> blas;
+  bool two_level = false;
+  uint32_t instancing_mode = 0;            // hala_rt_build_options::instancing: 0 by the rule of RENDER_SPEC 4.5, 1 never (everything flattened)
+  std::vector<uint8_t> inst_instanced;     // per instance: intersected in object space
+  std::vector<int32_t> prim_blas;          // per primitive: index into blas, -1
+  uint32_t tlas_capacity = 0, tlas_nodes = 0, stored_tris = 0;
+  std::vector<InstRef> inst_refs;
+  DeviceArray<InstRef> d_inst_refs;
+  DeviceArray<InstInfo> d_inst_info;
   DeviceArray<Tri> d_tris_by_id, d_tris;
   DeviceArray<Tri> d_tris_any;
   DeviceArray<ShadeTri> d_shade_tris;
-  DeviceArray<uint32_t> d_tri_instance;
   DeviceArray<BvhNode4> d_nodes;
   uint32_t lds_nodes = 0, lds_tris = 0;
   bool staged = false;  // whole BVH staged in LDS by the traversal kernels
@@ -181,6 +203,7 @@ struct hala_rt_renderer {
   int ring_pos = 0;
   bool vertices_dirty = false;  // hala_rt_update_vertices since the last refit
   bool materials_dirty_any = false;  // a material edit touched an opacity-0 material (old or new)
+  bool materials_dirty_any_refit = false;  // ... as hala_rt_refit found it
   bool any_invisible = false;   // the scene has invisible or translucent materials: the any-hit launches traverse d_tris_any (RENDER_SPEC 7.1d)
   bool any_translucent = false; // ... translucent ones: the ALPHA variants of the any-hit kernels
   DeviceArray<uint8_t> d_material_any_class;
@@ -224,17 +247,19 @@ struct hala_rt_renderer {
     for (auto& i : img_local) i.release();
     for (auto& i : img_full) i.release();
     if (bvh.topology) bvh_free_topology(bvh.topology);
+    blas.clear();
     if (stream) (void)hipStreamDestroy(stream);
   }
 
   SceneView view() const {
     SceneView sv{};
-    sv.nodes = d_nodes.ptr; sv.tris = d_tris.ptr; sv.tris_any = any_invisible ? d_tris_any.ptr : d_tris.ptr; sv.tris_by_id = d_tris_by_id.ptr; sv.shade_tris = d_shade_tris.ptr; sv.tri_instance = d_tri_instance.ptr;
+    sv.nodes = d_nodes.ptr; sv.tris = d_tris.ptr; sv.tris_any = any_invisible ? d_tris_any.ptr : d_tris.ptr; sv.tris_by_id = d_tris_by_id.ptr; sv.shade_tris = d_shade_tris.ptr;
     sv.inst_first_tri = d_inst_first_tri.ptr; sv.primitives = d_instances.ptr; sv.materials = d_materials.ptr; sv.material_kind = d_material_kind.ptr;
     sv.lights = d_lights.ptr; sv.cameras = d_cameras.ptr;
     sv.textures = d_textures.ptr; sv.tex_arena = d_tex_arena.ptr; sv.tex_arena8 = d_tex_arena8.ptr; sv.tex_lut = d_srgb_lut.ptr; sv.texture_count = (uint32_t)host_textures.size(); sv.shade_sort = shade_sort ? 1u : 0u; sv.simple_materials = simple_materials ? 1u : 0u; sv.scatter_media = scatter_media ? 1u : 0u; sv.any_translucent = any_translucent ? 1u : 0u;
     sv.env_pixels = reinterpret_cast<const float*>(d_env.ptr); sv.env_marginal = d_marginal.ptr; sv.env_conditional = d_conditional.ptr;
     sv.node_count = bvh.node_count; sv.tri_count = bvh.tri_count; sv.lds_nodes = lds_nodes; sv.lds_tris = lds_tris;
+    sv.inst_refs = d_inst_refs.ptr; sv.inst_info = d_inst_info.ptr; sv.instance_count = (uint32_t)hs.instances.size(); sv.two_level = two_level ? 1u : 0u;
     sv.ray_eps = ray_eps;
     sv.staged = staged ? 1u : 0u;
     return sv;
@@ -507,7 +532,7 @@ int configure_traversal(hala_rt_renderer* r) {
   // is staged: a top-of-tree slice measured no gain (profiles/r01_h_experiments.txt), the caches already hold it.
   size_t budget = kLdsStageBudget;
   if (const char* e = tune_env("HALART_LDS_STAGE_BYTES")) budget = (size_t)strtoul(e, nullptr, 10);  // tuning knob
-  r->staged = nb + tb <= budget;
+  r->staged = !r->two_level && nb + tb <= budget;  // (the LDS-staged kernel variants know no instances)
   r->lds_nodes = r->staged ? r->bvh.node_count : 0u;
   r->lds_tris = r->staged ? r->bvh.tri_count : 0u;
   if (r->leaf_max_built > traverse_max_leaf(r->staged)) RT_FAIL("The BVH was built with larger leaves than the traversal variant for its size accepts.");
@@ -522,8 +547,8 @@ int configure_traversal(hala_rt_renderer* r) {
   // refilling once half the wave is idle is best when node fetches go to L2 / Infinity Cache
   r->lcfg.refill = r->staged ? 64u : kRefillThreshold;
   if (const char* e = tune_env("HALART_REFILL")) r->lcfg.refill = std::min(64u, std::max(1u, (uint32_t)strtoul(e, nullptr, 10)));  // tuning knob
-  if (r->bvh.stack_need > traverse_stack_lds_levels(r->staged)) {
-    if (r->bvh.stack_need > traverse_stack_lds_levels(r->staged) + traverse_stack_spill_levels()) {
+  if (r->two_level || r->bvh.stack_need > traverse_stack_lds_levels(r->staged)) {
+    if (r->two_level || r->bvh.stack_need > traverse_stack_lds_levels(r->staged) + traverse_stack_spill_levels()) {
       // 3 x levels is a loose bound (every node on the path deferring three siblings).  Before refusing the tree, take the exact
       // one: need(node) = (inner children - 1) + max need(inner child) — the worst order visits the child with the deepest
       // need first while all its siblings wait.  Nodes are in breadth-first order (children behind their parent): one reverse sweep.
@@ -533,7 +558,14 @@ int configure_traversal(hala_rt_renderer* r) {
       for (size_t i = nodes.size(); i-- > 0;) {
         uint32_t inner = 0, deepest = 0;
         for (uint32_t ref : nodes[i].ref) {
-          if (ref == kAbsent || (ref & kLeafRef)) continue;
+          if (ref == kAbsent) continue;
+          if (is_inst_leaf(ref)) {  // RENDER_SPEC 4.5: the world-space ray (3 entries) and the exit mark wait below the instance's own entries
+            const uint32_t k = ref & 0x0fffffffu;
+            ++inner;
+            if (k < r->inst_refs.size() && r->inst_refs[k].root < need.size()) deepest = std::max(deepest, 4u + need[r->inst_refs[k].root]);
+            continue;
+          }
+          if (ref & kLeafRef) continue;
           ++inner;
           if (ref < need.size()) deepest = std::max(deepest, need[ref]);
         }
@@ -565,7 +597,7 @@ int attach_any_triangles(hala_rt_renderer* r) {
   }
   r->material_any_class = cls;
   RT_HIP(r->d_material_any_class.upload(cls.data(), cls.size(), r->stream));
-  if (r->any_invisible) RT_HIP(r->d_tris_any.resize(r->hs.triangle_count));
+  if (r->any_invisible) RT_HIP(r->d_tris_any.resize(r->two_level ? r->stored_tris : r->hs.triangle_count));
   r->bvh.tris_any = r->any_invisible ? r->d_tris_any.ptr : nullptr;
   r->bvh.material_any_class = r->d_material_any_class.ptr;
   r->bvh.material_kind = r->d_material_kind.ptr;
@@ -573,13 +605,223 @@ int attach_any_triangles(hala_rt_renderer* r) {
   return HALA_OK;
 }
 
+// ---- two-level trees (RENDER_SPEC 4.5) ---------------------------------------------------------------------------------------------
+// world -> object of one instance: rows of the inverse of the upper 3x3 (cross products of its columns over the determinant) and the
+// translation; false: not invertible in float (the instance is flattened to world space like a primitive that is referenced once)
+static float h_dot3(const float* a, const float* b) { return std::fmaf(a[2], b[2], std::fmaf(a[1], b[1], a[0] * b[0])); }
+static void h_cross3(const float* a, const float* b, float* o) {
+  o[0] = std::fmaf(a[1], b[2], -(a[2] * b[1])); o[1] = std::fmaf(a[2], b[0], -(a[0] * b[2])); o[2] = std::fmaf(a[0], b[1], -(a[1] * b[0]));
+}
+static bool world_to_object(const float* m, InstRef* o) {
+  const float c0[3] = {m[0], m[1], m[2]}, c1[3] = {m[4], m[5], m[6]}, c2[3] = {m[8], m[9], m[10]};
+  float k0[3], k1[3], k2[3];
+  h_cross3(c1, c2, k0); h_cross3(c2, c0, k1); h_cross3(c0, c1, k2);
+  const float det = h_dot3(c0, k0);
+  if (!(det != 0.0f) || !std::isfinite(det)) return false;
+  const float inv = 1.0f / det;
+  for (int k = 0; k < 3; ++k) { o->r0[k] = k0[k] * inv; o->r1[k] = k1[k] * inv; o->r2[k] = k2[k] * inv; o->tr[k] = m[12 + k]; }
+  for (int k = 0; k < 3; ++k)
+    if (!std::isfinite(o->r0[k]) || !std::isfinite(o->r1[k]) || !std::isfinite(o->r2[k]) || !std::isfinite(o->tr[k])) return false;
+  return true;
+}
+static void h_transform_point(const float* m, const float* p, float* o) {  // RENDER_SPEC 3
+  for (int k = 0; k < 3; ++k) o[k] = std::fmaf(m[8 + k], p[2], std::fmaf(m[4 + k], p[1], m[k] * p[0])) + m[12 + k];
+}
+// which instances are intersected in object space: those of a primitive that several instances reference, if their transform can be inverted
+static void classify_instances(hala_rt_renderer* r, std::vector<uint8_t>* flags) {
+  const HostScene& hs = r->hs;
+  flags->assign(hs.instances.size(), 0);
+  if (r->instancing_mode == 1u) return;
+  std::vector<uint32_t> refs(hs.prims.size(), 0u);
+  for (uint32_t p : hs.instance_prim) refs[p]++;
+  for (size_t i = 0; i < hs.instances.size(); ++i) {
+    InstRef tmp;
+    (*flags)[i] = refs[hs.instance_prim[i]] >= 2u && hs.prims[hs.instance_prim[i]].indices.size() >= 3 && world_to_object(hs.instances[i].transform, &tmp) ? 1 : 0;
+  }
+}
+
+// the instance levels: InstRef per instanced instance, one item per instanced instance + one for the world tree, the host build, the upload;
+// also the scene bounds (RENDER_SPEC 4.5: world tree's exact bounds + the boxes of the transformed corners of the instanced primitives' bounds)
+int build_instance_levels(hala_rt_renderer* r) {
+  const HostScene& hs = r->hs;
+  std::vector<TlasItem> items;
+  r->inst_refs.clear();
+  std::vector<InstInfo> info(hs.instances.size());
+  float smin[3] = {INFINITY, INFINITY, INFINITY}, smax[3] = {-INFINITY, -INFINITY, -INFINITY};
+  uint32_t deepest = 0;
+  // shading records: the world tree's triangles in its own order (instance order), then every instanced primitive's
+  std::vector<uint32_t> flat_base(hs.instances.size(), 0u);
+  if (!r->blas.empty() && !r->blas[0]->object_space) {
+    const hala_rt_renderer::Blas& w = *r->blas[0];
+    uint32_t at = w.tri_off;
+    for (uint32_t i : w.insts) { flat_base[i] = at; at += hs.inst_first_tri[i + 1] - hs.inst_first_tri[i]; }
+    if (w.b.tri_count) {
+      TlasItem it{};
+      const float pad = std::max({std::fabs(w.b.scene_min[0]), std::fabs(w.b.scene_min[1]), std::fabs(w.b.scene_min[2]), std::fabs(w.b.scene_max[0]),
+                                  std::fabs(w.b.scene_max[1]), std::fabs(w.b.scene_max[2])}) * 1.9073486328125e-06f * 2.0f;
+      for (int k = 0; k < 3; ++k) { it.mn[k] = w.b.scene_min[k] - pad; it.mx[k] = w.b.scene_max[k] + pad; smin[k] = std::min(smin[k], w.b.scene_min[k]); smax[k] = std::max(smax[k], w.b.scene_max[k]); }
+      it.ref = w.node_off;  // its root: an inner child, no transform
+      it.need = w.b.stack_need;
+      deepest = std::max(deepest, w.b.max_depth);
+      items.push_back(it);
+    }
+  }
+  for (size_t i = 0; i < hs.instances.size(); ++i) {
+    info[i].first_tri = hs.inst_first_tri[i];
+    info[i].instanced = r->inst_instanced[i];
+    info[i].pad = 0;
+    if (!r->inst_instanced[i]) { info[i].shade_base = flat_base[i]; continue; }
+    const hala_rt_renderer::Blas& bl = *r->blas[(size_t)r->prim_blas[hs.instance_prim[i]]];
+    info[i].shade_base = bl.tri_off;
+    InstRef ref{};
+    if (!world_to_object(hs.instances[i].transform, &ref)) RT_FAIL("An instanced node's transform stopped being invertible: commit() again.");
+    ref.root = bl.node_off; ref.gid_base = hs.inst_first_tri[i]; ref.shade_base = bl.tri_off; ref.inst = (uint32_t)i;
+    // world box of the instance: the eight corners of its primitive's exact object-space bounds, moved to world space
+    TlasItem it{};
+    float wmn[3] = {INFINITY, INFINITY, INFINITY}, wmx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int c = 0; c < 8; ++c) {
+      const float p[3] = {(c & 1) ? bl.b.scene_max[0] : bl.b.scene_min[0], (c & 2) ? bl.b.scene_max[1] : bl.b.scene_min[1], (c & 4) ? bl.b.scene_max[2] : bl.b.scene_min[2]};
+      float q[3];
+      h_transform_point(hs.instances[i].transform, p, q);
+      for (int k = 0; k < 3; ++k) { wmn[k] = std::min(wmn[k], q[k]); wmx[k] = std::max(wmx[k], q[k]); }
+    }
+    // padded like every box (RENDER_SPEC 4.1b), twice: once for the rounding of the move to world space, once for the object-space pad of the leaves below
+    const float amax = std::max({std::fabs(wmn[0]), std::fabs(wmn[1]), std::fabs(wmn[2]), std::fabs(wmx[0]), std::fabs(wmx[1]), std::fabs(wmx[2])});
+    const float ext = std::max({wmx[0] - wmn[0], wmx[1] - wmn[1], wmx[2] - wmn[2]});
+    const float pad = (amax + ext) * 1.9073486328125e-06f * 2.0f;
+    for (int k = 0; k < 3; ++k) { it.mn[k] = wmn[k] - pad; it.mx[k] = wmx[k] + pad; smin[k] = std::min(smin[k], wmn[k]); smax[k] = std::max(smax[k], wmx[k]); }
+    it.ref = kInstLeafTag | (uint32_t)r->inst_refs.size();
+    it.need = 4u + bl.b.stack_need;  // the world-space ray (3 entries) and the exit mark wait below the instance's own entries
+    deepest = std::max(deepest, bl.b.max_depth);
+    if (r->inst_refs.size() >= 0x0ffffff0u) RT_FAIL("Too many instances.");
+    r->inst_refs.push_back(ref);
+    items.push_back(it);
+  }
+  if (items.size() > r->tlas_capacity) RT_FAIL("internal: instance levels larger than reserved");
+  std::vector<BvhNode4> nodes;
+  uint32_t levels = 0, need = 0;
+  r->tlas_nodes = tlas_build(items, nodes, &levels, &need);
+  RT_HIP(hipMemcpyAsync(r->d_nodes.ptr, nodes.data(), nodes.size() * sizeof(BvhNode4), hipMemcpyHostToDevice, r->stream));
+  RT_HIP(r->d_inst_refs.upload(r->inst_refs.data(), r->inst_refs.size(), r->stream));
+  RT_HIP(r->d_inst_info.upload(info.data(), info.size(), r->stream));
+  RT_HIP(hipStreamSynchronize(r->stream));  // `nodes`, `info` go out of scope
+  r->bvh.max_depth = levels + deepest;
+  r->bvh.stack_need = need;
+  for (int k = 0; k < 3; ++k) { r->bvh.scene_min[k] = items.empty() ? 0.0f : smin[k]; r->bvh.scene_max[k] = items.empty() ? 0.0f : smax[k]; }
+  return HALA_OK;
+}
+
+// builds / refits one tree of a two-level scene into its sub-ranges and makes its references absolute
+static int blas_build_or_refit(hala_rt_renderer* r, hala_rt_renderer::Blas& bl, bool refit) {
+  const HostScene& hs = r->hs;
+  std::vector<hala_gpu_mesh_data> md;
+  std::vector<uint32_t> first{0u}, gid, inst;
+  if (bl.object_space) {
+    hala_gpu_mesh_data m{};
+    uint32_t any = 0;
+    while (hs.instance_prim[any] != bl.prim) ++any;  // any instance of the primitive: material and buffer addresses are the primitive's
+    m = hs.instances[any];
+    const Mat4 id = Mat4::identity();
+    memcpy(m.transform, id.m, 64);
+    md.push_back(m); gid.push_back(0u); inst.push_back(kAbsent);
+    first.push_back((uint32_t)(hs.prims[bl.prim].indices.size() / 3));
+  } else {
+    for (uint32_t i : bl.insts) {
+      md.push_back(hs.instances[i]); gid.push_back(hs.inst_first_tri[i]); inst.push_back(i);
+      first.push_back(first.back() + (hs.inst_first_tri[i + 1] - hs.inst_first_tri[i]));
+    }
+  }
+  RT_HIP(bl.d_md.upload(md.data(), md.size(), r->stream));
+  RT_HIP(bl.d_first.upload(first.data(), first.size(), r->stream));
+  RT_HIP(bl.d_gid.upload(gid.data(), gid.size(), r->stream));
+  RT_HIP(bl.d_inst.upload(inst.data(), inst.size(), r->stream));
+  RT_HIP(hipStreamSynchronize(r->stream));
+  BvhBuffers& b = bl.b;
+  b.primitives = bl.d_md.ptr; b.inst_first_tri = bl.d_first.ptr; b.instance_count = (uint32_t)md.size(); b.tri_count = first.back();
+  b.gid_first = bl.d_gid.ptr; b.inst_index = bl.d_inst.ptr; b.object_space = bl.object_space;
+  b.tris_by_id = r->d_tris_by_id.ptr + bl.tri_off; b.tris = r->d_tris.ptr + bl.tri_off; b.shade_tris = r->d_shade_tris.ptr + bl.tri_off;
+  b.tris_any = r->any_invisible ? r->d_tris_any.ptr + bl.tri_off : nullptr;
+  b.material_any_class = r->d_material_any_class.ptr; b.material_kind = r->d_material_kind.ptr; b.material_count = (uint32_t)hs.gpu_materials.size();
+  b.nodes = r->d_nodes.ptr + bl.node_off;
+  b.opt = r->bvh.opt;
+  const std::string e = refit ? bvh_refit(b, r->stream) : bvh_build(b, kLeafMax, r->stream);
+  if (!e.empty()) RT_FAIL(e);
+  const std::string e2 = bvh_relocate(b, bl.node_off, bl.tri_off, r->stream);
+  if (!e2.empty()) RT_FAIL(e2);
+  return HALA_OK;
+}
+
+int build_two_level(hala_rt_renderer* r) {
+  const HostScene& hs = r->hs;
+  r->blas.clear();
+  r->prim_blas.assign(hs.prims.size(), -1);
+  // the trees: [0] the world tree over the instances that stay flattened (if any), then one per instanced primitive in order of first use
+  std::unique_ptr<hala_rt_renderer::Blas> world(new hala_rt_renderer::Blas());
+  uint32_t n_items = 0;
+  for (size_t i = 0; i < hs.instances.size(); ++i) {
+    if (!r->inst_instanced[i]) { world->insts.push_back((uint32_t)i); continue; }
+    ++n_items;
+    const uint32_t p = hs.instance_prim[i];
+    if (r->prim_blas[p] < 0) r->prim_blas[p] = -2;  // marked; numbered below
+  }
+  uint32_t tri_at = 0;
+  if (!world->insts.empty()) {
+    for (uint32_t i : world->insts) tri_at += hs.inst_first_tri[i + 1] - hs.inst_first_tri[i];
+    world->tri_off = 0; world->b.tri_count = tri_at;
+    ++n_items;
+    r->blas.push_back(std::move(world));
+  }
+  for (size_t i = 0; i < hs.instances.size(); ++i) {
+    const uint32_t p = hs.instance_prim[i];
+    if (!r->inst_instanced[i] || r->prim_blas[p] != -2) continue;
+    std::unique_ptr<hala_rt_renderer::Blas> bl(new hala_rt_renderer::Blas());
+    bl->object_space = true; bl->prim = p; bl->tri_off = tri_at;
+    bl->b.tri_count = (uint32_t)(hs.prims[p].indices.size() / 3);
+    tri_at += bl->b.tri_count;
+    r->prim_blas[p] = (int32_t)r->blas.size();
+    r->blas.push_back(std::move(bl));
+  }
+  if (tri_at >= (1u << 28)) RT_FAIL("The scene stores 2^28 triangles or more.");
+  r->stored_tris = tri_at;
+  r->tlas_capacity = std::max(1u, n_items);
+  uint32_t node_at = r->tlas_capacity;
+  for (auto& bl : r->blas) {
+    bl->node_off = node_at;
+    bl->node_cap = std::max<uint32_t>(bl->b.tri_count, 2) - 1;
+    node_at += bl->node_cap;
+  }
+  RT_HIP(r->d_tris_by_id.resize(tri_at)); RT_HIP(r->d_tris.resize(tri_at)); RT_HIP(r->d_shade_tris.resize(tri_at));
+  RT_HIP(r->d_nodes.resize(node_at));
+  RT_HIP(hipMemsetAsync(r->d_nodes.ptr, 0xff, (size_t)node_at * sizeof(BvhNode4), r->stream));  // unused slots of the reserved ranges: absent children
+  if (attach_any_triangles(r) != HALA_OK) return HALA_ERR;
+  uint32_t nodes_used = r->tlas_capacity;
+  for (auto& bl : r->blas) {
+    if (blas_build_or_refit(r, *bl, false) != HALA_OK) return HALA_ERR;
+    nodes_used = std::max(nodes_used, bl->node_off + bl->b.node_count);
+  }
+  r->bvh.tri_count = tri_at;
+  r->bvh.node_count = node_at;  // the node array as a whole (reserved ranges included: hala_rt_download_bvh)
+  r->bvh.tris_any = r->any_invisible ? r->d_tris_any.ptr : nullptr;
+  r->leaf_max_built = kLeafMax;
+  if (build_instance_levels(r) != HALA_OK) return HALA_ERR;
+  return configure_traversal(r);
+}
+
 int build_bvh(hala_rt_renderer* r) {
+  classify_instances(r, &r->inst_instanced);
+  r->two_level = false;
+  for (uint8_t f : r->inst_instanced) r->two_level = r->two_level || f != 0;
+  if (r->bvh.topology) { bvh_free_topology(r->bvh.topology); r->bvh.topology = nullptr; }
+  r->blas.clear();
+  r->bvh.gid_first = nullptr; r->bvh.inst_index = nullptr; r->bvh.object_space = false;
+  if (r->two_level) return build_two_level(r);
   const uint32_t n = r->hs.triangle_count;
-  RT_HIP(r->d_tris_by_id.resize(n)); RT_HIP(r->d_tris.resize(n)); RT_HIP(r->d_tri_instance.resize(n)); RT_HIP(r->d_shade_tris.resize(n));
+  r->stored_tris = n; r->tlas_nodes = 0; r->tlas_capacity = 0;
+  RT_HIP(r->d_tris_by_id.resize(n)); RT_HIP(r->d_tris.resize(n)); RT_HIP(r->d_shade_tris.resize(n));
   RT_HIP(r->d_nodes.resize(std::max<uint32_t>(n, 2) - 1));
   r->bvh.primitives = r->d_instances.ptr; r->bvh.inst_first_tri = r->d_inst_first_tri.ptr;
   r->bvh.instance_count = (uint32_t)r->hs.instances.size(); r->bvh.tri_count = n;
-  r->bvh.tris_by_id = r->d_tris_by_id.ptr; r->bvh.shade_tris = r->d_shade_tris.ptr; r->bvh.tris = r->d_tris.ptr; r->bvh.tri_instance = r->d_tri_instance.ptr; r->bvh.nodes = r->d_nodes.ptr;
+  r->bvh.tris_by_id = r->d_tris_by_id.ptr; r->bvh.shade_tris = r->d_shade_tris.ptr; r->bvh.tris = r->d_tris.ptr; r->bvh.nodes = r->d_nodes.ptr;
   if (attach_any_triangles(r) != HALA_OK) return HALA_ERR;
   // a scene this small will be staged in LDS (configure_traversal: 48 B per triangle + at most ~32 B of nodes per triangle)
   uint32_t leaf_max = (size_t)n * 80 <= kLdsStageBudget ? kLeafMaxStaged : kLeafMax;
@@ -789,8 +1031,9 @@ int hala_rt_commit(hala_rt_renderer* r) {
 int hala_rt_set_build_options(hala_rt_renderer* r, const hala_rt_build_options* o) {
   if (!r) RT_FAIL("The renderer handle is null!");
   if (!o) RT_FAIL("The build options are null!");
-  if (o->builder > 3u || o->ploc_tail > 2u) RT_FAIL("Invalid build options.");
+  if (o->builder > 3u || o->ploc_tail > 2u || o->instancing > 1u) RT_FAIL("Invalid build options.");
   for (uint32_t v : o->reserved) if (v != 0u) RT_FAIL("Invalid build options (reserved fields must be 0).");
+  r->instancing_mode = o->instancing;
   r->bvh.opt.builder = o->builder; r->bvh.opt.ploc_tail = o->ploc_tail;
   r->bvh.opt.ploc_look_every = o->ploc_look_every; r->bvh.opt.collapse_look_every = o->collapse_look_every;
   return HALA_OK;
@@ -1346,8 +1589,11 @@ int hala_rt_trace_rays_host(hala_rt_renderer* r, const hala_ray* rays, hala_hit*
 int hala_rt_get_bvh_info(hala_rt_renderer* r, hala_bvh_info* out) {
   if (!r || !out) RT_FAIL("The renderer handle is null!");
   if (!r->committed) RT_FAIL("The top level acceleration structure is none!");
-  out->node_count = r->bvh.node_count; out->triangle_count = r->bvh.tri_count; out->max_depth = r->bvh.max_depth; out->lds_node_count = r->lds_nodes;
+  out->node_count = r->bvh.node_count; out->triangle_count = r->hs.triangle_count; out->max_depth = r->bvh.max_depth; out->lds_node_count = r->lds_nodes;
   out->node_width = 4u;
+  out->stored_triangle_count = r->stored_tris; out->instance_node_count = r->two_level ? r->tlas_nodes : 0u;
+  out->instance_ref_count = r->two_level ? (uint32_t)r->inst_refs.size() : 0u;
+  out->tree_bytes = (uint64_t)r->d_nodes.bytes() + r->d_tris.bytes() + r->d_tris_any.bytes() + r->d_shade_tris.bytes() + r->d_inst_refs.bytes() + r->d_inst_info.bytes();
   memcpy(out->scene_min, r->bvh.scene_min, 12); memcpy(out->scene_max, r->bvh.scene_max, 12);
   return HALA_OK;
 }
@@ -1364,6 +1610,13 @@ int hala_rt_download_bvh(hala_rt_renderer* r, void* nodes_64B, void* triangles_4
   return HALA_OK;
 }
 
+int hala_rt_download_instance_refs(hala_rt_renderer* r, void* refs_64B, uint32_t capacity, uint32_t* count) {
+  if (!r || !count) RT_FAIL("Invalid argument.");
+  if (!r->committed) RT_FAIL("The top level acceleration structure is none!");
+  *count = r->two_level ? (uint32_t)r->inst_refs.size() : 0u;
+  if (refs_64B && r->two_level) memcpy(refs_64B, r->inst_refs.data(), std::min<size_t>(capacity, r->inst_refs.size()) * sizeof(InstRef));
+  return HALA_OK;
+}
 int hala_rt_update_node_transform(hala_rt_renderer* r, uint32_t node_index, const float local_transform[16]) {
   if (!r || !local_transform) RT_FAIL("Invalid argument.");
   if (!r->has_scene || node_index >= r->hs.nodes.size()) RT_FAIL("The node does not exist.");
@@ -1417,9 +1670,30 @@ int hala_rt_refit(hala_rt_renderer* r) {
   // (the BVH-order triangles carry their material's shading kind: rewritten by the refit pass as well)
   bool geometry_moved = r->vertices_dirty || r->materials_dirty_any || had_invisible != r->any_invisible || before.size() != r->hs.instances.size() ||
                         kinds_before != r->material_kind;
+  r->materials_dirty_any_refit = r->materials_dirty_any;
   r->materials_dirty_any = false;
   for (size_t i = 0; i < before.size() && !geometry_moved; ++i) geometry_moved = memcmp(before[i].transform, r->hs.instances[i].transform, 64) != 0;
-  if (geometry_moved) {
+  // which instances are intersected in object space may have changed (a transform that is no longer invertible, or is again): rebuild
+  std::vector<uint8_t> flags;
+  classify_instances(r, &flags);
+  if (flags != r->inst_instanced) {
+    if (build_bvh(r) != HALA_OK) return HALA_ERR;
+    r->vertices_dirty = false;
+  } else if (r->two_level) {
+    // RENDER_SPEC 4.5: a node that moves an instanced primitive only touches the instance levels (rebuilt on the host below).  The trees
+    // underneath are refitted when what THEY hold changed: vertices or materials (any tree), the transform of a flattened instance (the world tree)
+    const bool content = r->vertices_dirty || r->materials_dirty_any_refit || had_invisible != r->any_invisible || kinds_before != r->material_kind;
+    r->bvh.tris_any = r->any_invisible ? r->d_tris_any.ptr : nullptr;
+    for (auto& bl : r->blas) {
+      bool moved = content;
+      if (!bl->object_space)
+        for (uint32_t i : bl->insts) moved = moved || memcmp(before[i].transform, r->hs.instances[i].transform, 64) != 0;
+      if (moved && blas_build_or_refit(r, *bl, true) != HALA_OK) return HALA_ERR;
+    }
+    if (build_instance_levels(r) != HALA_OK) return HALA_ERR;
+    if (configure_traversal(r) != HALA_OK) return HALA_ERR;
+    r->vertices_dirty = false;
+  } else if (geometry_moved) {
     const std::string e2 = bvh_refit(r->bvh, r->stream);
     if (!e2.empty()) RT_FAIL(e2);
     if (configure_traversal(r) != HALA_OK) return HALA_ERR;

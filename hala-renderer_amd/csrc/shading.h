@@ -546,8 +546,25 @@ RT_DI float tex_lod(const SceneView& sv, uint32_t tex, float lod_base) {
   return lod_base + 0.5f * log2_approx((float)td.width * (float)td.height);
 }
 
+// two-level trees (RENDER_SPEC 4.5): the instance a global triangle id belongs to (the last one whose first triangle is <= id; the
+// table is tiny and hot) — shading records are then found by instance: shade_base + (id - first_tri)
+RT_DI uint32_t instance_of(const SceneView& sv, uint32_t gid) {
+  uint32_t lo = 0, hi = sv.instance_count;
+  while (hi - lo > 1u) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (sv.inst_info[mid].first_tri <= gid) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+// the shading record of a triangle met by the traversal of a two-level tree: inside an instance the lane carries the primitive's first
+// record (bit 31 set: "inside"), local = the triangle's number inside the primitive; in the world tree the instance is looked up
+RT_DI uint32_t hit_record_of(const SceneView& sv, uint32_t gid, uint32_t shade_base_flagged, uint32_t local) {
+  if (shade_base_flagged >> 31) return (shade_base_flagged & 0x7fffffffu) + local;
+  const InstInfo ii = sv.inst_info[instance_of(sv, gid)];
+  return ii.shade_base + (gid - ii.first_tri);
+}
 // RENDER_SPEC 7.1d: what decides whether a translucent triangle blocks an any-hit ray: the material's opacity times the alpha of its
-// base-colour map (bilinear fetch of level 0 at the hit's interpolated texture coordinates)
+// base-colour map (bilinear fetch of level 0 at the hit's interpolated texture coordinates); prim = its shading record
 RT_DI float hit_alpha(const SceneView& sv, uint32_t prim, float u, float v) {
   const float4* sp = reinterpret_cast<const float4*>(sv.shade_tris + prim);
   const uint32_t material = __float_as_uint(sp[1].w);
@@ -568,14 +585,15 @@ RT_DI float hit_alpha(const SceneView& sv, uint32_t prim, float u, float v) {
 // boundary of a medium — a ray that gets through adds +sigma t to its optical depth where it leaves the object (hit from behind:
 // det < 0), -sigma t where it enters, per channel, in 2^-16 units with wrap-around integer arithmetic: the sums do not depend on the
 // order of the crossings.  Returns true if the triangle blocks; q = what to add to the ray's optical depth.
-RT_DI bool any_hit_event(const SceneView& sv, uint32_t key, uint32_t prim, uint32_t flag, float t, float det, float u, float v, uint32_t q[3]) {
+// prim = the triangle's global id (what the hash is keyed by), rec = its shading record (== prim in one-level trees)
+RT_DI bool any_hit_event(const SceneView& sv, uint32_t key, uint32_t prim, uint32_t rec, uint32_t flag, float t, float det, float u, float v, uint32_t q[3]) {
   q[0] = q[1] = q[2] = 0u;
   if (flag & 1u) {
     const float x = (float)(pcg_hash(key + prim * 0x9E3779B1u) >> 8) * (1.0f / 16777216.0f);
-    if (x < hit_alpha(sv, prim, u, v)) return true;
+    if (x < hit_alpha(sv, rec, u, v)) return true;
   }
   if (flag & 2u) {
-    const uint32_t material = __float_as_uint(reinterpret_cast<const float4*>(sv.shade_tris + prim)[1].w);
+    const uint32_t material = __float_as_uint(reinterpret_cast<const float4*>(sv.shade_tris + rec)[1].w);
     const hala_gpu_material& m = sv.materials[material];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -613,15 +631,26 @@ RT_DI f3 transform_vector(const float* m, f3 p) {
 template <bool SIMPLE, typename LUT>
 RT_DI Surface make_surface(const SceneView& sv, LUT lut, float pixel_spread, f3 o, f3 d, float t, float u, float v, uint32_t prim) {
   Surface sf;
+  // two-level trees (RENDER_SPEC 4.5): shading records are per PRIMITIVE triangle, found through the instance of the hit's global id
+  uint32_t rec = prim, inst_tl = 0;
+  bool instanced = false;
+  if (sv.two_level) {
+    inst_tl = instance_of(sv, prim);
+    const InstInfo ii = sv.inst_info[inst_tl];
+    rec = ii.shade_base + (prim - ii.first_tri);
+    instanced = ii.instanced != 0u;
+  }
   // line 1 of the 128-B shading record: geometric normal, vertex normals, instance, material
-  const float4* sp = reinterpret_cast<const float4*>(sv.shade_tris + prim);
+  const float4* sp = reinterpret_cast<const float4*>(sv.shade_tris + rec);
   const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3];
-  const uint32_t inst = __float_as_uint(s0.w), material = __float_as_uint(s1.w);
+  const uint32_t inst = sv.two_level ? inst_tl : __float_as_uint(s0.w), material = __float_as_uint(s1.w);
   const hala_gpu_mesh_data& md = sv.primitives[inst];
   float w0 = 1.0f - u - v;
   f3 nl = madd3(mk3(s3.x, s3.y, s3.z), v, madd3(mk3(s2.x, s2.y, s2.z), u, mk3(s1.x, s1.y, s1.z) * w0));
   sf.ns = normalize3(transform_normal(md.transform, nl));
-  const f3 gcross = mk3(s0.x, s0.y, s0.z);
+  // geometric normal: cross(e1, e2) of the stored edges — world space, or (instanced primitives) object space moved to world space like a normal
+  f3 gcross = mk3(s0.x, s0.y, s0.z);
+  if (instanced) gcross = transform_normal(md.transform, gcross);
   sf.ng = normalize3(gcross);
   sf.P = madd3(d, t, o);
   const hala_gpu_material& m = sv.materials[material];

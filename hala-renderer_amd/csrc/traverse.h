@@ -128,11 +128,14 @@ struct Trav {
   int sp;
   uint32_t key;  // any-hit rays: decides which translucent triangles block this ray (RENDER_SPEC 7.1d)
   uint32_t tau[3];  // any-hit rays: optical depth of the media crossed so far, 2^-16 units, wrap-around sums (RENDER_SPEC 7.1g)
+  // two-level trees (INST variants): while the ray is inside an instance `r` is the OBJECT-space ray, the triangles' ids are local to the
+  // primitive: + gid_base = global id, + (shade_base & 0x7fffffff) = shading record (bit 31 of shade_base: inside an instance)
+  uint32_t gid_base, shade_base;
 };
 RT_DI void trav_begin(Trav& t, const RayPre& r, float tmax, uint32_t key) {
   t.r = r; t.tmax = tmax; t.key = key; t.tau[0] = t.tau[1] = t.tau[2] = 0u;
   t.best.t = tmax; t.best.u = 0.0f; t.best.v = 0.0f; t.best.prim = kAbsent;
-  t.cur = 0; t.sp = 0;
+  t.cur = 0; t.sp = 0; t.gid_base = 0u; t.shade_base = 0u;
 }
 
 typedef float v2f __attribute__((ext_vector_type(2)));  // operand pair of the packed FP32 instructions
@@ -197,7 +200,7 @@ RT_DI bool leaf_test_staged(const SceneView& sv, const TraverseLds& lds, const R
         if (tt[j] > r.tmin && tt[j] < tmax) {
           if (ALPHA && __float_as_uint(j ? b1.w : b0.w) != 0u) {  // translucent and / or the boundary of a medium (7.1d, 7.1g)
             uint32_t q[3];
-            if (!any_hit_event(sv, key, id, __float_as_uint(j ? b1.w : b0.w), tt[j], dd[j], uu[j], vv[j], q)) { tau[0] += q[0]; tau[1] += q[1]; tau[2] += q[2]; continue; }
+            if (!any_hit_event(sv, key, id, id, __float_as_uint(j ? b1.w : b0.w), tt[j], dd[j], uu[j], vv[j], q)) { tau[0] += q[0]; tau[1] += q[1]; tau[2] += q[2]; continue; }
           }
           best.t = tt[j]; best.u = uu[j]; best.v = vv[j]; best.prim = id; return true;
         }
@@ -235,8 +238,13 @@ RT_DI float lane_read(uint32_t src_lane_x4, float v) {  // v of lane src_lane_x4
 //   owner                         -> reads its slot back.
 // A per-lane leaf loop ran at 4-6 of 64 lanes on the 1 M-triangle scene (1.4-1.6 passes of <= 2 sequential triangle tests per wave
 // step, each with its own dependent fetch); dealt out, a wave step has ONE pass of one triangle test at ~4x the lanes.
-template <bool ANY, bool COUNT, bool STAGED, bool ALPHA>
+// INST: the tree has instance levels (RENDER_SPEC 4.5).  An instance leaf sorts and waits like an inner child; when its turn comes the
+// lane parks the world-space ray on its traversal stack (three entries under an exit mark), moves the ray into the instance's object
+// space (t is kept: the direction is not normalised) and goes on at the root of the primitive's tree; popping the exit mark brings the
+// world-space ray back.  No registers and no LDS beyond the stack: the large-scene kernels have neither to spare at 5 waves per SIMD.
+template <bool ANY, bool COUNT, bool STAGED, bool ALPHA, bool INST = false>
 RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, Trav& t, bool has, StepCounters& sc) {
+  static_assert(!(INST && STAGED), "LDS-staged trees have no instance levels");
   constexpr int kS = stack_lds<STAGED>();
   RT_LDS u32x2* stack = lds.stack + threadIdx.x;
   const RayPre& r = t.r;
@@ -276,7 +284,8 @@ RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, 
       const float tn = hw_maxf(hw_maxf(tx.x, ty.x), hw_maxf(tz.x, r.tmin));
       const float tf = hw_minf(hw_minf(tx.y, ty.y), hw_minf(tz.y, best.t));
       const bool hit = ref[c] != kAbsent && tn <= tf * 1.0000004f;
-      key[c] = hit ? ((__float_as_uint(tn) & ~3u) | (uint32_t)c | (~ref[c] & kInnerKey)) : kMissKey;
+      const uint32_t inner_bit = INST ? ((!(ref[c] >> 31) || (ref[c] >> 28) == 0xFu) ? kInnerKey : 0u) : (~ref[c] & kInnerKey);  // instance leaves wait like inner children
+      key[c] = hit ? ((__float_as_uint(tn) & ~3u) | (uint32_t)c | inner_bit) : kMissKey;
     }
     sort2kv(key[0], key[1], ref[0], ref[1]); sort2kv(key[2], key[3], ref[2], ref[3]); sort2kv(key[0], key[2], ref[0], ref[2]);
     sort2kv(key[1], key[3], ref[1], ref[3]); sort2kv(key[1], key[2], ref[1], ref[2]);
@@ -348,6 +357,8 @@ RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, 
         const float tmin = lane_read(src, r.tmin);
         const float tlim = ANY ? lane_read(src, t.tmax) : 0.0f;
         const uint32_t okey_any = (ANY && ALPHA) ? __float_as_uint(lane_read(src, __uint_as_float(t.key))) : 0u;
+        const uint32_t gbase = INST ? __float_as_uint(lane_read(src, __uint_as_float(t.gid_base))) : 0u;  // the owner may be inside an instance: local ids
+        const uint32_t sbase = (INST && ANY && ALPHA) ? __float_as_uint(lane_read(src, __uint_as_float(t.shade_base))) : 0u;
         if (COUNT) {
           const unsigned long long m = __ballot(valid);
           if (valid) sc.leaf_lanes++;
@@ -367,7 +378,8 @@ RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, 
                 bool blocks = true;
                 if (ALPHA && __float_as_uint(b.w) != 0u) {  // translucent and / or the boundary of a medium (7.1d, 7.1g)
                   uint32_t q[3];
-                  blocks = any_hit_event(sv, okey_any, __float_as_uint(a.w), __float_as_uint(b.w), tt, det, tu, tv, q);
+                  const uint32_t gid = __float_as_uint(a.w) + gbase;
+                  blocks = any_hit_event(sv, okey_any, gid, INST ? hit_record_of(sv, gid, sbase, __float_as_uint(a.w)) : gid, __float_as_uint(b.w), tt, det, tu, tv, q);
                   if (!blocks && (q[0] | q[1] | q[2])) {
                     RT_LDS uint32_t* ot = (RT_LDS uint32_t*)okey;
                     __hip_atomic_fetch_add(ot + 1, q[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -379,7 +391,7 @@ RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, 
               }
             }
             else {
-              mine = ((unsigned long long)__float_as_uint(tt) << 32) | (unsigned long long)hit_encode(__float_as_uint(a.w), __float_as_uint(c.w));  // id << 3 | shading kind
+              mine = ((unsigned long long)__float_as_uint(tt) << 32) | (unsigned long long)hit_encode(__float_as_uint(a.w) + gbase, __float_as_uint(c.w));  // id << 3 | shading kind
               __hip_atomic_fetch_min(okey, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             }
           }
@@ -404,12 +416,53 @@ RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, 
   if (ANY && found) { if (!STAGED) best.prim = 0u; return true; }
   // go on with the nearest inner child if it is still in reach, else with the first stack entry that is
   if (next != kAbsent && !(key_tn(next_key) <= best.t)) next = kAbsent;
-  while (next == kAbsent) {
-    if (sp == 0) return true;
-    --sp;
-    uint2 e;
-    if (sp < kS) { const u32x2 v = stack[sp * kTraverseThreads]; e = make_uint2(v.x, v.y); } else e = spill[sp - kS];
-    if (key_tn(e.x) <= best.t) next = e.y;
+  if (!INST) {
+    while (next == kAbsent) {
+      if (sp == 0) return true;
+      --sp;
+      uint2 e;
+      if (sp < kS) { const u32x2 v = stack[sp * kTraverseThreads]; e = make_uint2(v.x, v.y); } else e = spill[sp - kS];
+      if (key_tn(e.x) <= best.t) next = e.y;
+    }
+  } else {
+    auto pop = [&]() -> uint2 {
+      --sp;
+      if (sp < kS) { const u32x2 v = stack[sp * kTraverseThreads]; return make_uint2(v.x, v.y); }
+      return spill[sp - kS];
+    };
+    auto push = [&](uint32_t a, uint32_t b) {
+      if (sp < kS) stack[sp * kTraverseThreads] = u32x2{a, b}; else spill[sp - kS] = make_uint2(a, b);
+      ++sp;
+    };
+    for (;;) {
+      if (next == kAbsent) {
+        if (sp == 0) return true;
+        const uint2 e = pop();
+        if (e.y == kExitRef) {  // the instance's tree is done: back to the world-space ray parked under the mark
+          const uint2 c2 = pop(), c1 = pop(), c0 = pop();
+          t.r = make_ray(mk3(__uint_as_float(c0.x), __uint_as_float(c0.y), __uint_as_float(c1.x)),
+                         mk3(__uint_as_float(c1.y), __uint_as_float(c2.x), __uint_as_float(c2.y)), t.r.tmin);
+          t.gid_base = 0u; t.shade_base = 0u;
+          continue;
+        }
+        if (key_tn(e.x) <= best.t) next = e.y;
+        continue;
+      }
+      if (is_inst_leaf(next)) {  // enter the instance (RENDER_SPEC 4.5)
+        const float4* ip = reinterpret_cast<const float4*>(sv.inst_refs + (next & 0x0fffffffu));
+        const float4 i0 = ip[0], i1 = ip[1], i2 = ip[2], i3 = ip[3];  // r0 | r1 | r2 | tr, then root, gid_base, shade_base, inst
+        push(__float_as_uint(t.r.o.x), __float_as_uint(t.r.o.y));
+        push(__float_as_uint(t.r.o.z), __float_as_uint(t.r.d.x));
+        push(__float_as_uint(t.r.d.y), __float_as_uint(t.r.d.z));
+        push(0u, kExitRef);  // key 0: never culled
+        const f3 r0 = mk3(i0.x, i0.y, i0.z), r1 = mk3(i0.w, i1.x, i1.y), r2 = mk3(i1.z, i1.w, i2.x), tr = mk3(i2.y, i2.z, i2.w);
+        const f3 tv = t.r.o - tr, d = t.r.d;
+        t.r = make_ray(mk3(dot3(r0, tv), dot3(r1, tv), dot3(r2, tv)), mk3(dot3(r0, d), dot3(r1, d), dot3(r2, d)), t.r.tmin);
+        t.gid_base = __float_as_uint(i3.y); t.shade_base = __float_as_uint(i3.z) | 0x80000000u;  // bit 31: inside an instance
+        next = __float_as_uint(i3.x);
+      }
+      break;
+    }
   }
   t.cur = next;
   t.sp = sp;

@@ -119,10 +119,12 @@ class HalaRenderer:
 
     BUILDERS = {None: 0, "auto": 0, "sah": 1, "ploc": 2, "lbvh": 3}
 
-    def set_build_options(self, builder=None, ploc_tail=0, ploc_look_every=0, collapse_look_every=0):
+    def set_build_options(self, builder=None, ploc_tail=0, ploc_look_every=0, collapse_look_every=0, instancing=True):
         """how the next commit() builds the acceleration structure (hala_rt_set_build_options): builder = None | "sah" | "ploc" | "lbvh";
-        the other fields only change how the host drives the build rounds (same tree)"""
-        o = A.BuildOptions(builder=self.BUILDERS[builder], ploc_tail=ploc_tail, ploc_look_every=ploc_look_every, collapse_look_every=collapse_look_every)
+        instancing = False flattens every instance to world space (one tree; RENDER_SPEC 4.5); the other fields only change how the host
+        drives the build rounds (same tree)"""
+        o = A.BuildOptions(builder=self.BUILDERS[builder], ploc_tail=ploc_tail, ploc_look_every=ploc_look_every, collapse_look_every=collapse_look_every,
+                           instancing=0 if instancing else 1)
         self._check(self._lib.hala_rt_set_build_options(self._h, C.byref(o)))
 
     def update(self, delta_time=0.0, width=None, height=None, ui_fn=None):
@@ -253,9 +255,18 @@ class HalaRenderer:
     def download_bvh(self):
         i = self.bvh_info()
         nodes = np.empty(i.node_count * 16, dtype=np.uint32)
-        tris = np.empty(max(i.triangle_count, 1) * 12, dtype=np.uint32)
+        tris = np.empty(max(i.stored_triangle_count, 1) * 12, dtype=np.uint32)
         self._check(self._lib.hala_rt_download_bvh(self._h, C.c_void_p(nodes.ctypes.data), C.c_void_p(tris.ctypes.data)))
-        return nodes, tris[: i.triangle_count * 12]
+        return nodes, tris[: i.stored_triangle_count * 12]
+
+    def download_instance_refs(self):
+        """two-level trees: the 64-B records the instance leaves index ([n, 16] uint32: 12 floats world -> object, root node, global id
+        of the first triangle, first shading record, instance index); empty for one-level trees"""
+        n = C.c_uint32(0)
+        self._check(self._lib.hala_rt_download_instance_refs(self._h, None, C.c_uint32(0), C.byref(n)))
+        refs = np.empty((max(n.value, 1), 16), dtype=np.uint32)
+        self._check(self._lib.hala_rt_download_instance_refs(self._h, C.c_void_p(refs.ctypes.data), C.c_uint32(n.value), C.byref(n)))
+        return refs[: n.value]
 
     def update_node_transform(self, node_index, local_transform):
         m = np.asarray(local_transform, dtype=np.float32)

@@ -337,7 +337,11 @@ typedef struct hala_rt_build_options {
   uint32_t ploc_tail;           /* 0 / 1: the last PLOC rounds in one workgroup | 2: every round its own launch */
   uint32_t ploc_look_every;     /* PLOC rounds between two host looks at the device counters (default 6) */
   uint32_t collapse_look_every; /* levels of the 4-wide collapse between two host looks (default 8) */
-  uint32_t reserved[4];         /* must be 0 */
+  uint32_t instancing;          /* 0: two-level tree — a primitive that several instances reference gets ONE object-space tree, its instances
+                                 *    are leaves of the instance levels (RENDER_SPEC 4.5; what the reference's BLAS / TLAS split expresses,
+                                 *    gpu_uploader.rs:782-815, :843-885, :937-959); 1: every instance flattened to world space (one tree).
+                                 *    The two settings intersect instanced geometry in different spaces: images agree to rounding, not bit for bit. */
+  uint32_t reserved[3];         /* must be 0 */
 } hala_rt_build_options;
 int hala_rt_set_build_options(hala_rt_renderer* r, const hala_rt_build_options* options);
 
@@ -554,9 +558,21 @@ typedef struct hala_bvh_info {
   float scene_min[3];
   float scene_max[3];
   uint32_t node_width;
+  /* two-level trees (RENDER_SPEC 4.5; scenes in which several instances reference one primitive): the triangles the trees store (every
+   * instanced primitive once; == triangle_count otherwise), the nodes of the instance levels (the first nodes of the array; 0: one-level
+   * tree) and the instance references their leaves index */
+  uint32_t stored_triangle_count;
+  uint32_t instance_node_count;
+  uint32_t instance_ref_count;
+  uint64_t tree_bytes; /* device bytes of nodes + triangles (+ any-hit copy) + shading records + instance tables */
 } hala_bvh_info;
 int hala_rt_get_bvh_info(hala_rt_renderer* r, hala_bvh_info* out);
+/* node_count nodes and stored_triangle_count triangles.  Two-level trees: child references are absolute; a reference with bits 31..28 = 0xF
+ * is an instance leaf whose low 28 bits index the records of hala_rt_download_instance_refs (64 B each: 3 rows of world -> object and the
+ * translation as 12 floats, then root node, global id of the instance's first triangle, first shading record, instance index); the
+ * triangles of an instanced primitive are in object space and carry ids local to the primitive. */
 int hala_rt_download_bvh(hala_rt_renderer* r, void* nodes_64B, void* triangles_48B);
+int hala_rt_download_instance_refs(hala_rt_renderer* r, void* refs_64B, uint32_t capacity, uint32_t* count);
 /* Refit after vertex/transform edits (north_star "BVH build/refit"; the reference rebuilds only):
  * re-flattens instances with the given node local transforms and refits AABBs bottom-up on the GPU. */
 int hala_rt_update_node_transform(hala_rt_renderer* r, uint32_t node_index, const float local_transform[16]);

@@ -153,6 +153,15 @@ int orc_validate_bvh4(const void* nodes64, uint32_t node_count, const void* tris
 
 // Makes orc_render traverse a tree the product built (same layout as above; node_count 0 switches back to the oracle's own).
 void orc_scene_use_bvh4(orc_scene* s, const void* nodes64, uint32_t node_count, const void* tris48, uint32_t tri_count);
+/* two-level trees (RENDER_SPEC 4.5): + the 64-B instance references (include/halart.h: hala_rt_download_instance_refs) */
+void orc_scene_use_bvh4_two_level(orc_scene* s, const void* nodes64, uint32_t node_count, const void* tris48, uint32_t tri_count,
+                                  const void* refs64, uint32_t ref_count);
+void orc_trace_rays_on_bvh4_two_level(const void* nodes64, uint32_t node_count, const void* tris48, uint32_t tri_count, const void* refs64,
+                                      const orc_ray* rays, orc_hit* hits, uint32_t count, int mode, uint64_t* counters);
+int orc_validate_bvh4_two_level(const orc_scene* s, const void* nodes64, uint32_t node_count, const void* tris48, uint32_t tri_count,
+                                const void* refs64, uint32_t ref_count, uint32_t* max_depth);
+/* 1: every instance is flattened to world space in scenes created from now on (hala_rt_build_options::instancing = 1) */
+void orc_set_instancing_off(int off);
 // The oracle's own SAH tree in the product's 4-wide format (greedy surface-area collapse, conservative quantisation) and
 // its triangles in that tree's order: a CPU-built tree to pin the two functions above on, and a quality yardstick for
 // the product's builder.  Returns the node count (query with nodes64_out == NULL); 0 on failure.

@@ -114,10 +114,12 @@ static void build_bvh(orc_scene* s) {
   for (int k = 0; k < 3; ++k) amax = std::max(amax, std::max(std::fabs(s->bounds_min[k]), std::fabs(s->bounds_max[k])));
   const float pad = amax * 1.9073486328125e-06f;  // 2^-19
   for (uint32_t i = 0; i < N; ++i) {
-    const Tri& t = s->tris_by_id[i];
-    float v1[3], v2[3];
-    for (int k = 0; k < 3; ++k) { v1[k] = t.v0[k] + t.e1[k]; v2[k] = t.v0[k] + t.e2[k]; }
-    refs[i].box.reset(); refs[i].box.grow(t.v0); refs[i].box.grow(v1); refs[i].box.grow(v2);
+    // world-space vertices (the triangles of instanced instances are stored in object space: RENDER_SPEC 4.5; the oracle's own tree is
+    // one world-space tree over ALL triangles either way — only the ray/triangle test follows the rule)
+    const float* w9 = &s->tri_verts9[(size_t)i * 9];
+    refs[i].box.reset(); refs[i].box.grow(w9); refs[i].box.grow(w9 + 3); refs[i].box.grow(w9 + 6);
+    if (s->instances[s->tri_instance[i]].instanced)  // moved there by other arithmetic than the ray's way into object space: twice the pad
+      for (int k = 0; k < 3; ++k) { refs[i].box.mn[k] -= pad; refs[i].box.mx[k] += pad; }
     // The slab test works on t = plane*idir - o*idir, whose rounding error is a few ulp of the largest coordinate involved — as
     // is the triangle test's.  A hit exactly on a box face can therefore be culled (seen once in 2*10^7 rays on the 1 M-triangle
     // scene, where brute force and the product's quantised boxes kept it).  Padding every box by 2^-19 of the scene's largest
@@ -147,6 +149,24 @@ static void build_bvh(orc_scene* s) {
 // ---------------------------------------------------------------------------------------------------------
 // scene
 // ---------------------------------------------------------------------------------------------------------
+// RENDER_SPEC 4.5: world -> object of an instance — rows of the inverse of the upper 3x3 (cross products of its columns over the
+// determinant) and the translation; false: not invertible in float (the instance is flattened like one that is referenced once)
+static bool world_to_object(const float* m, float* r0, float* r1, float* r2, float* tr) {
+  const V3 c0 = v3(m[0], m[1], m[2]), c1 = v3(m[4], m[5], m[6]), c2 = v3(m[8], m[9], m[10]);
+  const V3 k0 = cross3(c1, c2), k1 = cross3(c2, c0), k2 = cross3(c0, c1);
+  const float det = dot3(c0, k0);
+  if (!(det != 0.0f) || !std::isfinite(det)) return false;
+  const float inv = 1.0f / det;
+  const V3 a = k0 * inv, b = k1 * inv, c = k2 * inv;
+  r0[0] = a.x; r0[1] = a.y; r0[2] = a.z; r1[0] = b.x; r1[1] = b.y; r1[2] = b.z; r2[0] = c.x; r2[1] = c.y; r2[2] = c.z;
+  for (int k = 0; k < 3; ++k) tr[k] = m[12 + k];
+  for (int k = 0; k < 3; ++k) if (!std::isfinite(r0[k]) || !std::isfinite(r1[k]) || !std::isfinite(r2[k]) || !std::isfinite(tr[k])) return false;
+  return true;
+}
+static int g_instancing_off = 0;
+// 1: every instance is flattened to world space (what hala_rt_build_options::instancing = 1 selects in the product)
+extern "C" void orc_set_instancing_off(int off) { g_instancing_off = off; }
+
 extern "C" orc_scene* orc_scene_create(const orc_scene_desc* desc) {
   orc_scene* s = new orc_scene();
   std::vector<float> world((size_t)desc->node_count * 16);
@@ -162,6 +182,12 @@ extern "C" orc_scene* orc_scene_create(const orc_scene_desc* desc) {
       slot[m].push_back({s->owned_vertices.size() - 1, s->owned_indices.size() - 1});
     }
   }
+  // RENDER_SPEC 4.5: how many instances reference each primitive
+  std::vector<std::vector<uint32_t>> prim_refs(desc->mesh_count);
+  for (uint32_t m = 0; m < desc->mesh_count; ++m) prim_refs[m].assign(desc->meshes[m].primitive_count, 0u);
+  for (uint32_t k = 0; k < desc->node_count; ++k)
+    if (desc->nodes[k].mesh_index != ORC_NONE)
+      for (uint32_t p = 0; p < desc->meshes[desc->nodes[k].mesh_index].primitive_count; ++p) prim_refs[desc->nodes[k].mesh_index][p]++;
   // RENDER_SPEC §3 / gpu_uploader.rs:843-875: instances in node order, then primitive order
   for (int i = 0; i < 3; ++i) { s->bounds_min[i] = std::numeric_limits<float>::infinity(); s->bounds_max[i] = -s->bounds_min[i]; }
   for (uint32_t k = 0; k < desc->node_count; ++k) {
@@ -176,25 +202,40 @@ extern "C" orc_scene* orc_scene_create(const orc_scene_desc* desc) {
       inst.first_triangle = (uint32_t)s->tris_by_id.size();
       inst.vertices = s->owned_vertices[slot[node.mesh_index][p].first].data();
       inst.indices = s->owned_indices[slot[node.mesh_index][p].second].data();
+      inst.instanced = !g_instancing_off && prim_refs[node.mesh_index][p] >= 2u && pr.index_count >= 3u && world_to_object(w, inst.r0, inst.r1, inst.r2, inst.tr);
       uint32_t inst_id = (uint32_t)s->instances.size();
       s->instances.push_back(inst);
+      float omn[3] = {INFINITY, INFINITY, INFINITY}, omx[3] = {-INFINITY, -INFINITY, -INFINITY};  // instanced: exact object-space bounds of the primitive's triangles
       for (uint32_t t = 0; t < pr.index_count / 3; ++t) {  // primitive_count = index_count / 3 (gpu_uploader.rs:804)
-        V3 v[3];
+        V3 v[3], lv[3];
         for (int c = 0; c < 3; ++c) {
           const float* pp = inst.vertices[inst.indices[3 * t + c]].position;
-          v[c] = transform_point(w, v3(pp[0], pp[1], pp[2]));
+          lv[c] = v3(pp[0], pp[1], pp[2]);
+          v[c] = transform_point(w, lv[c]);
           const float a[3] = {v[c].x, v[c].y, v[c].z};
-          for (int i = 0; i < 3; ++i) { s->bounds_min[i] = std::min(s->bounds_min[i], a[i]); s->bounds_max[i] = std::max(s->bounds_max[i], a[i]); }
+          if (!inst.instanced) for (int i = 0; i < 3; ++i) { s->bounds_min[i] = std::min(s->bounds_min[i], a[i]); s->bounds_max[i] = std::max(s->bounds_max[i], a[i]); }
+          else for (int i = 0; i < 3; ++i) { omn[i] = std::min(omn[i], pp[i]); omx[i] = std::max(omx[i], pp[i]); }
         }
         Tri tr;
-        V3 e1 = v[1] - v[0], e2 = v[2] - v[0];
+        // RENDER_SPEC 4.5: an instanced instance's triangles stay in object space (local positions as they are)
+        V3 e1 = inst.instanced ? lv[1] - lv[0] : v[1] - v[0], e2 = inst.instanced ? lv[2] - lv[0] : v[2] - v[0];
+        if (inst.instanced) v[0] = lv[0];
         tr.v0[0] = v[0].x; tr.v0[1] = v[0].y; tr.v0[2] = v[0].z; tr.id = (uint32_t)s->tris_by_id.size();
         tr.e1[0] = e1.x; tr.e1[1] = e1.y; tr.e1[2] = e1.z; tr.pad1 = 0;
         tr.e2[0] = e2.x; tr.e2[1] = e2.y; tr.e2[2] = e2.z; tr.pad2 = 0;
         s->tris_by_id.push_back(tr);
         s->tri_instance.push_back(inst_id);
-        for (int c = 0; c < 3; ++c) { s->tri_verts9.push_back(v[c].x); s->tri_verts9.push_back(v[c].y); s->tri_verts9.push_back(v[c].z); }
+        for (int c = 0; c < 3; ++c) {
+          const V3 wv = inst.instanced ? transform_point(w, lv[c]) : v[c];
+          s->tri_verts9.push_back(wv.x); s->tri_verts9.push_back(wv.y); s->tri_verts9.push_back(wv.z);
+        }
       }
+      if (inst.instanced)  // RENDER_SPEC 4.5: its share of the scene bounds = the box of the eight corners of the primitive's bounds, moved to world space
+        for (int c = 0; c < 8; ++c) {
+          const V3 q = transform_point(w, v3((c & 1) ? omx[0] : omn[0], (c & 2) ? omx[1] : omn[1], (c & 4) ? omx[2] : omn[2]));
+          const float a[3] = {q.x, q.y, q.z};
+          for (int i = 0; i < 3; ++i) { s->bounds_min[i] = std::min(s->bounds_min[i], a[i]); s->bounds_max[i] = std::max(s->bounds_max[i], a[i]); }
+        }
     }
   }
   if (s->tris_by_id.empty()) for (int i = 0; i < 3; ++i) { s->bounds_min[i] = 0.0f; s->bounds_max[i] = 0.0f; }
@@ -338,6 +379,30 @@ static inline bool tri_test(const RayPre& r, const Tri& tr, float* t, float* u, 
   return true;
 }
 
+// RENDER_SPEC 4.5: the ray a triangle is tested with — the world-space ray, or, for a triangle of an instanced instance, the ray moved
+// into that instance's object space (t is kept: the direction is not normalised); cached per instance
+struct RayCtx {
+  const orc_scene* s;
+  RayPre world, obj;
+  uint32_t cur = 0xffffffffu;
+  const RayPre& for_tri(uint32_t gid) {
+    if (!s) return world;
+    const uint32_t ii = s->tri_instance[gid];
+    const Instance& in = s->instances[ii];
+    if (!in.instanced) return world;
+    if (ii != cur) {
+      obj = object_ray(world, in.r0, in.r1, in.r2, in.tr);
+      cur = ii;
+    }
+    return obj;
+  }
+  static RayPre object_ray(const RayPre& w, const float* r0, const float* r1, const float* r2, const float* tr) {
+    const V3 a = v3(r0[0], r0[1], r0[2]), b = v3(r1[0], r1[1], r1[2]), c = v3(r2[0], r2[1], r2[2]);
+    const V3 tv = w.o - v3(tr[0], tr[1], tr[2]);
+    return make_ray(v3(dot3(a, tv), dot3(b, tv), dot3(c, tv)), v3(dot3(a, w.d), dot3(b, w.d), dot3(c, w.d)), w.tmin);
+  }
+};
+
 // RENDER_SPEC 7.1d / 7.1g: what a triangle of the any-hit copy does to an any-hit ray that hits it inside (tmin, tmax).  Flags (word 7 of the
 // record): 0 blocks; 1 translucent: blocks iff hash(key, triangle) < opacity x alpha at the hit; 2 invisible boundary of a medium: never
 // blocks, adds to the optical depth; 3 translucent boundary of a medium: 1, then 2 when the ray gets through.
@@ -366,8 +431,9 @@ V3 any_transmittance(const AnyCtx& ax) {
   return v3(r[0], r[1], r[2]);
 }
 template <bool ANY>
-static inline bool traverse(const Node* nodes, const Tri* tris, const RayPre& r, float tmax, AnyCtx* ax, Hit* best, Counters* c) {
+static inline bool traverse(const orc_scene* s, const Node* nodes, const Tri* tris, const RayPre& r, float tmax, AnyCtx* ax, Hit* best, Counters* c) {
   best->t = tmax; best->prim = ORC_NONE; best->u = 0.0f; best->v = 0.0f;
+  RayCtx rc{s, r, r};
   uint32_t stack[1024]; int sp = 0;
   uint32_t cur = 0;
   for (;;) {
@@ -393,7 +459,7 @@ static inline bool traverse(const Node* nodes, const Tri* tris, const RayPre& r,
         for (uint32_t i = 0; i < count; ++i) {
           const Tri& tr = tris[child + i];
           float t, u, v, det;
-          if (!tri_test(r, tr, &t, &u, &v, &det)) continue;
+          if (!tri_test(rc.for_tri(tr.id), tr, &t, &u, &v, &det)) continue;
           if (ANY) {
             if (t > r.tmin && t < tmax && any_hit_event(ax, tr, t, det, u, v)) { best->t = t; best->prim = tr.id; best->u = u; best->v = v; return true; }
           } else {
@@ -418,9 +484,10 @@ static inline float bits_f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 static inline uint32_t f_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 
 template <bool ANY>
-static inline bool leaf_test(const Tri* tris, const RayPre& r, float tmax, AnyCtx* ax, Hit* best, uint32_t first, uint32_t count) {
+static inline bool leaf_test(const Tri* tris, const RayPre& r, float tmax, AnyCtx* ax, Hit* best, uint32_t first, uint32_t count, uint32_t gid_base = 0) {
   for (uint32_t i = 0; i < count; ++i) {
-    const Tri& tr = tris[first + i];
+    Tri tr = tris[first + i];
+    tr.id += gid_base;  // inside an instance of a two-level tree the triangles carry ids local to the primitive
     float t, u, v, det;
     if (!tri_test(r, tr, &t, &u, &v, &det)) continue;
     if (ANY) {
@@ -449,12 +516,20 @@ static inline float key_tn(uint32_t key) { return bits_f(key & ~3u); }
 
 constexpr size_t kSmallTreeBytes = 40 * 1024;  // RENDER_SPEC 4.4b: node_count * 64 + triangle_count * 48 <= this -> sequential leaf culling
 static inline bool is_small_tree(size_t node_count, size_t tri_count) { return node_count * 64 + tri_count * 48 <= kSmallTreeBytes; }
+// refs (may be null): the instance references of a two-level tree (RENDER_SPEC 4.5).  An instance leaf (reference bits 31..28 = 0xF)
+// sorts and waits like an inner child; entering it moves the ray into the instance's object space and goes on at the root of the
+// primitive's tree (whose triangles carry local ids: + gid_base); an exit mark on the stack brings the world-space ray back.
+static inline bool is_inst_leaf(uint32_t ref) { return (ref & 0xF0000000u) == 0xF0000000u && ref < 0xfffffffeu; }
 template <bool ANY>
-static inline bool traverse4(const Node4* nodes, const Tri* tris, bool small_tree, const RayPre& r, float tmax, AnyCtx* ax, Hit* best, Counters* c) {
+static inline bool traverse4(const Node4* nodes, const Tri* tris, bool small_tree, const RayPre& r_world, float tmax, AnyCtx* ax, Hit* best, Counters* c,
+                             const InstRef* refs = nullptr) {
   best->t = tmax; best->prim = ORC_NONE; best->u = 0.0f; best->v = 0.0f;
   struct Entry { uint32_t key, ref; };
+  constexpr uint32_t kExit = 0xfffffffeu;
   Entry stack[1024]; int sp = 0;
   uint32_t cur = 0;
+  RayPre r = r_world;
+  uint32_t gid_base = 0;
   for (;;) {
     const Node4& n = nodes[cur];
     if (c) c->nodes++;
@@ -465,6 +540,7 @@ static inline bool traverse4(const Node4* nodes, const Tri* tris, bool small_tre
       adj[a] = fmaf(n.pmin[a], idir[a], -ood[a]);
     }
     Entry e[4];
+    bool innerish[4];
     for (int ci = 0; ci < 4; ++ci) {
       float t0[3], t1[3];
       for (int a = 0; a < 3; ++a) {
@@ -478,10 +554,11 @@ static inline bool traverse4(const Node4* nodes, const Tri* tris, bool small_tre
       e[ci].ref = n.ref[ci];
     }
     std::sort(e, e + 4, [](const Entry& a, const Entry& b) { return a.key < b.key; });  // keys of hits are distinct (slot bits)
-    // inner children: nearest next, the others stacked farthest first with their keys
+    for (int i = 0; i < 4; ++i) innerish[i] = !(e[i].ref & 0x80000000u) || (refs && is_inst_leaf(e[i].ref));
+    // inner children (and instance leaves): nearest next, the others stacked farthest first with their keys
     uint32_t next = kAbsent, next_key = 0;
     for (int i = 3; i >= 0; --i) {
-      if (e[i].key == 0xffffffffu || (e[i].ref & 0x80000000u)) continue;
+      if (e[i].key == 0xffffffffu || !innerish[i]) continue;
       if (next != kAbsent) stack[sp++] = Entry{next_key, next};
       next = e[i].ref; next_key = e[i].key;
     }
@@ -493,40 +570,54 @@ static inline bool traverse4(const Node4* nodes, const Tri* tris, bool small_tre
     bool occluded = false;
     for (int i = 0; i < 4 && e[i].key != 0xffffffffu; ++i) {
       uint32_t rf = e[i].ref;
-      if (!(rf & 0x80000000u)) continue;
+      if (innerish[i]) continue;
       if (!(key_tn(e[i].key) <= (small_tree ? best->t : reach))) continue;
       uint32_t count = ((rf >> 28) & 7u) + 1u;
       if (c) c->tris += count;
-      if (!occluded && leaf_test<ANY>(tris, r, tmax, ax, best, rf & 0x0fffffffu, count)) occluded = true;
+      if (!occluded && leaf_test<ANY>(tris, r, tmax, ax, best, rf & 0x0fffffffu, count, gid_base)) occluded = true;
       if (occluded && small_tree) return true;
     }
     if (occluded) return true;
     if (next != kAbsent && !(key_tn(next_key) <= best->t)) next = kAbsent;
-    while (next == kAbsent) {
-      if (sp == 0) return best->prim != ORC_NONE;
-      Entry t = stack[--sp];
-      if (key_tn(t.key) <= best->t) next = t.ref;
+    for (;;) {
+      if (next == kAbsent) {
+        if (sp == 0) return best->prim != ORC_NONE;
+        Entry t = stack[--sp];
+        if (t.ref == kExit) { r = r_world; gid_base = 0; continue; }
+        if (key_tn(t.key) <= best->t) next = t.ref;
+        continue;
+      }
+      if (refs && is_inst_leaf(next)) {
+        const InstRef& ir = refs[next & 0x0fffffffu];
+        stack[sp++] = Entry{0u, kExit};
+        r = RayCtx::object_ray(r_world, ir.r0, ir.r1, ir.r2, ir.tr);
+        gid_base = ir.gid_base;
+        next = ir.root;
+      }
+      break;
     }
     cur = next;
   }
 }
 
-Hit trace_closest(const Node* nodes, const Tri* tris, V3 o, V3 d, float tmin, float tmax, Counters* c) {
+Hit trace_closest(const orc_scene* s, const Node* nodes, const Tri* tris, V3 o, V3 d, float tmin, float tmax, Counters* c) {
   RayPre r = make_ray(o, d, tmin);
   Hit h;
-  if (!traverse<false>(nodes, tris, r, tmax, nullptr, &h, c)) { h.t = -1.0f; h.u = 0.0f; h.v = 0.0f; h.prim = ORC_NONE; }
+  if (!traverse<false>(s, nodes, tris, r, tmax, nullptr, &h, c)) { h.t = -1.0f; h.u = 0.0f; h.v = 0.0f; h.prim = ORC_NONE; }
   return h;
 }
-bool trace_any(const Node* nodes, const Tri* tris, V3 o, V3 d, float tmin, float tmax, AnyCtx* ax, Counters* c) {
+bool trace_any(const orc_scene* s, const Node* nodes, const Tri* tris, V3 o, V3 d, float tmin, float tmax, AnyCtx* ax, Counters* c) {
   RayPre r = make_ray(o, d, tmin);
   Hit h;
-  return traverse<true>(nodes, tris, r, tmax, ax, &h, c);
+  return traverse<true>(s, nodes, tris, r, tmax, ax, &h, c);
 }
+// a tree handed over by the product is "small" (RENDER_SPEC 4.4b) by ITS size; two-level trees are never LDS-staged
+static inline bool ext_small(const orc_scene* s) { return s->ext_refs.empty() && is_small_tree(s->ext_nodes.size(), s->ext_tris.size()); }
 Hit scene_trace_closest(const orc_scene* s, V3 o, V3 d, float tmin, float tmax, Counters* c) {
-  if (s->ext_nodes.empty()) return trace_closest(s->nodes.data(), s->tris.data(), o, d, tmin, tmax, c);
+  if (s->ext_nodes.empty()) return trace_closest(s, s->nodes.data(), s->tris.data(), o, d, tmin, tmax, c);
   RayPre r = make_ray(o, d, tmin);
   Hit h;
-  if (!traverse4<false>(s->ext_nodes.data(), s->ext_tris.data(), is_small_tree(s->ext_nodes.size(), s->ext_tris.size()), r, tmax, nullptr, &h, c)) { h.t = -1.0f; h.u = 0.0f; h.v = 0.0f; h.prim = ORC_NONE; }
+  if (!traverse4<false>(s->ext_nodes.data(), s->ext_tris.data(), ext_small(s), r, tmax, nullptr, &h, c, s->ext_refs.empty() ? nullptr : s->ext_refs.data())) { h.t = -1.0f; h.u = 0.0f; h.v = 0.0f; h.prim = ORC_NONE; }
   return h;
 }
 // RENDER_SPEC 7.1d / 7.1g: how an any-hit ray treats the triangles of a material
@@ -555,11 +646,12 @@ void make_any_triangles(const orc_scene* s, const std::vector<Tri>& in, std::vec
 bool scene_trace_any(const orc_scene* s, V3 o, V3 d, float tmin, float tmax, uint32_t key, Counters* c, V3* trans) {
   AnyCtx ax{s, key, {0u, 0u, 0u}};
   bool occ;
-  if (s->ext_nodes.empty()) occ = trace_any(s->nodes.data(), (s->tris_any.empty() ? s->tris : s->tris_any).data(), o, d, tmin, tmax, &ax, c);
+  if (s->ext_nodes.empty()) occ = trace_any(s, s->nodes.data(), (s->tris_any.empty() ? s->tris : s->tris_any).data(), o, d, tmin, tmax, &ax, c);
   else {
     RayPre r = make_ray(o, d, tmin);
     Hit h;
-    occ = traverse4<true>(s->ext_nodes.data(), (s->ext_tris_any.empty() ? s->ext_tris : s->ext_tris_any).data(), is_small_tree(s->ext_nodes.size(), s->ext_tris.size()), r, tmax, &ax, &h, c);
+    occ = traverse4<true>(s->ext_nodes.data(), (s->ext_tris_any.empty() ? s->ext_tris : s->ext_tris_any).data(), ext_small(s), r, tmax, &ax, &h, c,
+                          s->ext_refs.empty() ? nullptr : s->ext_refs.data());
   }
   if (trans) *trans = any_transmittance(ax);
   return occ;
@@ -572,7 +664,31 @@ bool scene_trace_any(const orc_scene* s, V3 o, V3 d, float tmin, float tmax, uin
 extern "C" void orc_scene_use_bvh4(orc_scene* s, const void* nodes64, uint32_t node_count, const void* tris48, uint32_t tri_count) {
   s->ext_nodes.assign((const Node4*)nodes64, (const Node4*)nodes64 + node_count);
   s->ext_tris.assign((const Tri*)tris48, (const Tri*)tris48 + (node_count ? tri_count : 0));
+  s->ext_refs.clear();
   orc::make_any_triangles(s, s->ext_tris, &s->ext_tris_any);
+}
+// ... the two-level form (RENDER_SPEC 4.5): + the instance references its instance leaves index.  The stored triangles of an instanced
+// primitive carry local ids; their any-hit class is the primitive's (every instance of a primitive has its material)
+extern "C" void orc_scene_use_bvh4_two_level(orc_scene* s, const void* nodes64, uint32_t node_count, const void* tris48, uint32_t tri_count,
+                                             const void* refs64, uint32_t ref_count) {
+  s->ext_nodes.assign((const Node4*)nodes64, (const Node4*)nodes64 + node_count);
+  s->ext_tris.assign((const Tri*)tris48, (const Tri*)tris48 + (node_count ? tri_count : 0));
+  s->ext_refs.assign((const InstRef*)refs64, (const InstRef*)refs64 + ref_count);
+  // global id of every stored triangle (for the material lookup): world-tree triangles carry it; a primitive's triangles get the ids of
+  // the first instance that references them
+  std::vector<Tri> tmp = s->ext_tris;
+  std::vector<uint8_t> seen(tmp.size(), 0);
+  for (const InstRef& ir : s->ext_refs) {
+    const Instance& in = s->instances[ir.inst];
+    const uint32_t n = (ir.inst + 1 < s->instances.size() ? s->instances[ir.inst + 1].first_triangle : (uint32_t)s->tris_by_id.size()) - in.first_triangle;
+    // the primitive's triangles sit at [shade_base, shade_base + n) of the stored array, in the tree's order: ids are local
+    for (uint32_t k = 0; k < n && ir.shade_base + k < tmp.size(); ++k)
+      if (!seen[ir.shade_base + k]) { tmp[ir.shade_base + k].id += in.first_triangle; seen[ir.shade_base + k] = 1; }
+  }
+  std::vector<Tri> any;
+  orc::make_any_triangles(s, tmp, &any);
+  for (size_t k = 0; k < any.size(); ++k) any[k].id = s->ext_tris[k].id;  // back to the stored (local) ids
+  s->ext_tris_any = any;
 }
 
 static void trace_batch(const orc_scene* s, const Node* nodes, const Tri* tris, const orc_ray* rays, orc_hit* hits, uint32_t count, int mode, uint64_t* counters) {
@@ -583,11 +699,11 @@ static void trace_batch(const orc_scene* s, const Node* nodes, const Tri* tris, 
     Counters c;
     V3 o = v3(r.origin[0], r.origin[1], r.origin[2]), d = v3(r.direction[0], r.direction[1], r.direction[2]);
     if (mode == 0) {
-      Hit h = trace_closest(nodes, tris, o, d, r.tmin, r.tmax, &c);
+      Hit h = trace_closest(s, nodes, tris, o, d, r.tmin, r.tmax, &c);
       hits[i].t = h.t; hits[i].u = h.u; hits[i].v = h.v; hits[i].prim = h.prim;
     } else {
       AnyCtx ax{s, pcg_hash((uint32_t)i ^ kAnyKeyBatch), {0u, 0u, 0u}};  // RENDER_SPEC 7.1d: the key of ray i of a batch
-      bool occ = trace_any(nodes, tris, o, d, r.tmin, r.tmax, &ax, &c);
+      bool occ = trace_any(s, nodes, tris, o, d, r.tmin, r.tmax, &ax, &c);
       hits[i].t = occ ? 1.0f : -1.0f; hits[i].u = 0.0f; hits[i].v = 0.0f; hits[i].prim = ORC_NONE;
     }
     cn += c.nodes; ct += c.tris;
@@ -598,11 +714,21 @@ static void trace_batch(const orc_scene* s, const Node* nodes, const Tri* tris, 
 extern "C" void orc_trace_rays(const orc_scene* s, const orc_ray* rays, orc_hit* hits, uint32_t count, int mode, uint64_t* counters) {
   trace_batch(s, s->nodes.data(), (mode == 1 && !s->tris_any.empty() ? s->tris_any : s->tris).data(), rays, hits, count, mode, counters);
 }
+static void trace_rays_on_bvh4(const void* nodes64, uint32_t node_count, const void* tris48, uint32_t tri_count, const InstRef* refs, const orc_ray* rays,
+                               orc_hit* hits, uint32_t count, int mode, uint64_t* counters);
 extern "C" void orc_trace_rays_on_bvh4(const void* nodes64, uint32_t node_count, const void* tris48, uint32_t tri_count, const orc_ray* rays,
                                        orc_hit* hits, uint32_t count, int mode, uint64_t* counters) {
+  trace_rays_on_bvh4(nodes64, node_count, tris48, tri_count, nullptr, rays, hits, count, mode, counters);
+}
+extern "C" void orc_trace_rays_on_bvh4_two_level(const void* nodes64, uint32_t node_count, const void* tris48, uint32_t tri_count, const void* refs64,
+                                                 const orc_ray* rays, orc_hit* hits, uint32_t count, int mode, uint64_t* counters) {
+  trace_rays_on_bvh4(nodes64, node_count, tris48, tri_count, (const InstRef*)refs64, rays, hits, count, mode, counters);
+}
+static void trace_rays_on_bvh4(const void* nodes64, uint32_t node_count, const void* tris48, uint32_t tri_count, const InstRef* refs, const orc_ray* rays,
+                               orc_hit* hits, uint32_t count, int mode, uint64_t* counters) {
   const Node4* nodes = (const Node4*)nodes64;
   const Tri* tris = (const Tri*)tris48;
-  const bool small_tree = orc::is_small_tree(node_count, tri_count);
+  const bool small_tree = !refs && orc::is_small_tree(node_count, tri_count);
   uint64_t cn = 0, ct = 0;
 #pragma omp parallel for schedule(dynamic, 4096) reduction(+ : cn, ct)
   for (int64_t i = 0; i < (int64_t)count; ++i) {
@@ -611,10 +737,10 @@ extern "C" void orc_trace_rays_on_bvh4(const void* nodes64, uint32_t node_count,
     RayPre r = make_ray(v3(ry.origin[0], ry.origin[1], ry.origin[2]), v3(ry.direction[0], ry.direction[1], ry.direction[2]), ry.tmin);
     Hit h;
     if (mode == 0) {
-      if (traverse4<false>(nodes, tris, small_tree, r, ry.tmax, nullptr, &h, &c)) hits[i] = orc_hit{h.t, h.u, h.v, h.prim};
+      if (traverse4<false>(nodes, tris, small_tree, r, ry.tmax, nullptr, &h, &c, refs)) hits[i] = orc_hit{h.t, h.u, h.v, h.prim};
       else hits[i] = orc_hit{-1.0f, 0.0f, 0.0f, ORC_NONE};
     } else {
-      hits[i] = orc_hit{traverse4<true>(nodes, tris, small_tree, r, ry.tmax, nullptr, &h, &c) ? 1.0f : -1.0f, 0.0f, 0.0f, ORC_NONE};
+      hits[i] = orc_hit{traverse4<true>(nodes, tris, small_tree, r, ry.tmax, nullptr, &h, &c, refs) ? 1.0f : -1.0f, 0.0f, 0.0f, ORC_NONE};
     }
     cn += c.nodes; ct += c.tris;
   }
@@ -628,9 +754,10 @@ extern "C" void orc_trace_rays_brute(const orc_scene* s, const orc_ray* rays, or
     RayPre r = make_ray(v3(ry.origin[0], ry.origin[1], ry.origin[2]), v3(ry.direction[0], ry.direction[1], ry.direction[2]), ry.tmin);
     Hit best{ry.tmax, 0.0f, 0.0f, ORC_NONE};
     bool any = false;
+    RayCtx rc{s, r, r};
     for (const Tri& tr : s->tris_by_id) {
       float t, u, v;
-      if (!tri_test(r, tr, &t, &u, &v)) continue;
+      if (!tri_test(rc.for_tri(tr.id), tr, &t, &u, &v)) continue;
       if (mode == 1) {  // RENDER_SPEC 7.1d
         const int k = orc::any_class(s, s->instances[s->tri_instance[tr.id]].material_index);
         Tri flagged = tr; flagged.pad1 = k == 2 ? 1u : (k == 3 ? 2u : (k == 4 ? 3u : 0u));
@@ -722,6 +849,116 @@ extern "C" int orc_validate_bvh4(const void* nodes64, uint32_t node_count, const
     }
   }
   for (uint32_t i = 0; i < tri_count; ++i) if (!seen_tri[i]) return 10;
+  if (max_depth) *max_depth = md;
+  return 0;
+}
+
+// ... of a two-level tree (RENDER_SPEC 4.5).  World-space part (instance levels + the tree over the triangles that are not instanced):
+// every child box contains the exact world-space vertices below it — for an instance leaf: all triangles of that instance, moved to world
+// space by RENDER_SPEC 3's arithmetic; the stored triangles are the scene's, bit for bit (object space for instanced primitives, ids
+// local); every primitive's tree is valid in object space; every global triangle id is reachable exactly once.  0 = valid.
+extern "C" int orc_validate_bvh4_two_level(const orc_scene* s, const void* nodes64, uint32_t node_count, const void* tris48, uint32_t tri_count,
+                                           const void* refs64, uint32_t ref_count, uint32_t* max_depth) {
+  const Node4* nodes = (const Node4*)nodes64;
+  const Tri* tris = (const Tri*)tris48;
+  const InstRef* refs = (const InstRef*)refs64;
+  if (max_depth) *max_depth = 0;
+  if (node_count == 0) return 1;
+  auto child_box = [&](const Node4& n, int ci, double* mn, double* mx) {
+    for (int a = 0; a < 3; ++a) {
+      const int e = (int)((n.exps >> (8 * a)) & 0xffu) - 127;
+      const double q = std::ldexp(1.0, e);
+      mn[a] = (double)n.pmin[a] + (double)((n.qlo[a] >> (8 * ci)) & 0xffu) * q;
+      mx[a] = (double)n.pmin[a] + (double)((n.qhi[a] >> (8 * ci)) & 0xffu) * q;
+    }
+  };
+  const uint32_t total = (uint32_t)s->tris_by_id.size();
+  std::vector<uint8_t> seen_gid(total, 0), seen_node(node_count, 0), seen_slot(tri_count, 0), seen_ref(ref_count, 0), queued_root(node_count, 0);
+  struct Item { uint32_t node, depth; int ref; };    // ref >= 0: inside the tree of instance reference `ref` (object space)
+  std::vector<Item> st{{0, 1, -1}};
+  uint32_t md = 0;
+  auto inst_tris = [&](uint32_t inst) {
+    return (inst + 1 < s->instances.size() ? s->instances[inst + 1].first_triangle : total) - s->instances[inst].first_triangle;
+  };
+  while (!st.empty()) {
+    Item it = st.back(); st.pop_back();
+    if (it.node >= node_count) return 2;
+    if (seen_node[it.node]) return 3;
+    seen_node[it.node] = 1;
+    md = std::max(md, it.depth);
+    const Node4& n = nodes[it.node];
+    for (int ci = 0; ci < 4; ++ci) {
+      const uint32_t rf = n.ref[ci];
+      if (rf == kAbsent) continue;
+      double mn[3], mx[3];
+      child_box(n, ci, mn, mx);
+      if (orc::is_inst_leaf(rf)) {
+        if (it.ref >= 0) return 20;  // no instances inside instances
+        const uint32_t k = rf & 0x0fffffffu;
+        if (k >= ref_count || seen_ref[k]) return 21;
+        seen_ref[k] = 1;
+        const InstRef& ir = refs[k];
+        if (ir.inst >= s->instances.size() || !s->instances[ir.inst].instanced) return 22;
+        const Instance& in = s->instances[ir.inst];
+        if (ir.gid_base != in.first_triangle || ir.root >= node_count) return 23;
+        if (memcmp(ir.r0, in.r0, 12) || memcmp(ir.r1, in.r1, 12) || memcmp(ir.r2, in.r2, 12) || memcmp(ir.tr, in.tr, 12)) return 24;  // RENDER_SPEC 4.5 arithmetic
+        const uint32_t cnt = inst_tris(ir.inst);
+        for (uint32_t t = 0; t < cnt; ++t) {
+          const uint32_t gid = in.first_triangle + t;
+          if (seen_gid[gid]) return 7;
+          seen_gid[gid] = 1;
+          const float* pv = &s->tri_verts9[(size_t)gid * 9];
+          for (int cc = 0; cc < 3; ++cc)
+            for (int a = 0; a < 3; ++a) if ((double)pv[3 * cc + a] < mn[a] || (double)pv[3 * cc + a] > mx[a]) return 25;
+        }
+        if (!queued_root[ir.root]) { queued_root[ir.root] = 1; st.push_back({ir.root, it.depth + 1, (int)k}); }  // a primitive's tree is checked once
+        continue;
+      }
+      if (!(rf & 0x80000000u)) {
+        if (rf >= node_count) return 2;
+        const Node4& cn = nodes[rf];
+        for (int cj = 0; cj < 4; ++cj) {
+          if (cn.ref[cj] == kAbsent) continue;
+          double gmn[3], gmx[3];
+          child_box(cn, cj, gmn, gmx);
+          for (int a = 0; a < 3; ++a) {
+            const double q = std::ldexp(1.0, (int)((cn.exps >> (8 * a)) & 0xffu) - 127);
+            if (gmn[a] < mn[a] - q || gmx[a] > mx[a] + q) return 4;
+          }
+        }
+        st.push_back({rf, it.depth + 1, it.ref});
+        continue;
+      }
+      const uint32_t first = rf & 0x0fffffffu, count = ((rf >> 28) & 7u) + 1u;
+      if ((uint64_t)first + count > tri_count) return 5;
+      for (uint32_t i = 0; i < count; ++i) {
+        if (seen_slot[first + i]) return 6;
+        seen_slot[first + i] = 1;
+        const Tri& tr = tris[first + i];
+        uint32_t gid = tr.id;
+        const Instance* in = nullptr;
+        if (it.ref >= 0) {  // object space: ids are local to the primitive
+          const InstRef& ir = refs[it.ref];
+          in = &s->instances[ir.inst];
+          if (tr.id >= inst_tris(ir.inst)) return 7;
+          gid = ir.gid_base + tr.id;
+        } else {
+          if (gid >= total || seen_gid[gid]) return 7;
+          if (s->instances[s->tri_instance[gid]].instanced) return 26;  // an instanced triangle in the world tree
+          seen_gid[gid] = 1;
+        }
+        const Tri& want = s->tris_by_id[gid];
+        for (int k2 = 0; k2 < 3; ++k2) if (tr.v0[k2] != want.v0[k2] || tr.e1[k2] != want.e1[k2] || tr.e2[k2] != want.e2[k2]) return 8;
+        for (int cc = 0; cc < 3; ++cc) {
+          float pv[3];
+          if (in) { const float* pp = in->vertices[in->indices[3 * tr.id + cc]].position; pv[0] = pp[0]; pv[1] = pp[1]; pv[2] = pp[2]; }
+          else memcpy(pv, &s->tri_verts9[(size_t)gid * 9 + 3 * cc], 12);
+          for (int a = 0; a < 3; ++a) if ((double)pv[a] < mn[a] || (double)pv[a] > mx[a]) return 9;
+        }
+      }
+    }
+  }
+  for (uint32_t i = 0; i < total; ++i) if (!seen_gid[i]) return 10;
   if (max_depth) *max_depth = md;
   return 0;
 }

@@ -522,7 +522,10 @@ static Surface make_surface(const orc_scene* s, float pixel_spread, V3 o, V3 d, 
   float w0 = 1.0f - h.u - h.v;
   V3 nl = madd3(ld3(c.normal), h.v, madd3(ld3(b.normal), h.u, ld3(a.normal) * w0));
   sf.ns = normalize3(transform_normal(inst.transform, nl));
+  // geometric normal: cross(e1, e2) of the stored edges — world space, or (RENDER_SPEC 4.5, instanced instances) object space, moved to
+  // world space like a normal
   V3 gcross = cross3(ld3(tr.e1), ld3(tr.e2));
+  if (inst.instanced) gcross = transform_normal(inst.transform, gcross);
   sf.ng = normalize3(gcross);
   sf.P = madd3(d, h.t, o);
   sf.m = s->materials[inst.material_index];

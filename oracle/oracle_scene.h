@@ -43,7 +43,18 @@ struct Instance {
   uint32_t first_triangle;  // global id of its first triangle
   const orc_vertex* vertices;
   const uint32_t* indices;
+  // RENDER_SPEC 4.5: an instance of a primitive that several instances reference is intersected in OBJECT space — its triangles keep
+  // their local positions, the ray is moved: p' = rows * (p - tr) with rows = the inverse of the upper 3x3 of `transform`
+  bool instanced = false;
+  float r0[3], r1[3], r2[3], tr[3];
 };
+
+// a product tree's instance reference (RENDER_SPEC 4.5; include/halart.h: hala_rt_download_instance_refs), 64 B
+struct InstRef {
+  float r0[3], r1[3], r2[3], tr[3];
+  uint32_t root, gid_base, shade_base, inst;
+};
+static_assert(sizeof(InstRef) == 64, "instance reference is 64 B");
 
 // RENDER_SPEC §7.4: one image decoded to linear RGBA32F with its full 2x2-box mip chain
 struct Image {
@@ -64,7 +75,7 @@ struct EnvMap {
 struct orc_scene {
   std::vector<orc::Instance> instances;
   std::vector<uint32_t> tri_instance;  // global triangle id -> instance
-  std::vector<orc::Tri> tris_by_id;    // world-space, indexed by global id
+  std::vector<orc::Tri> tris_by_id;    // indexed by global id; world space, except the triangles of instanced instances (object space: RENDER_SPEC 4.5)
   std::vector<float> tri_verts9;       // world-space v0,v1,v2 per global id (RENDER_SPEC §3)
   std::vector<orc::Tri> tris;          // BVH order
   std::vector<orc::Tri> tris_any;      // RENDER_SPEC 7.1d: what the any-hit traversals see — the triangles of opacity-0 materials made
@@ -85,13 +96,14 @@ struct orc_scene {
   // optional: a tree handed over by the product (orc_scene_use_bvh4); the integrator then traverses IT (RENDER_SPEC §4.4b)
   std::vector<orc::Node4> ext_nodes;
   std::vector<orc::Tri> ext_tris, ext_tris_any;
+  std::vector<orc::InstRef> ext_refs;   // ... and the instance references of its two-level form
 };
 
 namespace orc {
 struct Counters { uint64_t nodes = 0, tris = 0; };
 struct Hit { float t, u, v; uint32_t prim; };
-// RENDER_SPEC §4: closest / any traversal over (nodes, tris).
-Hit trace_closest(const Node* nodes, const Tri* tris, V3 o, V3 d, float tmin, float tmax, Counters* c);
+// RENDER_SPEC §4: closest / any traversal over (nodes, tris); s (may be null: no instancing) tells which triangles are intersected in object space
+Hit trace_closest(const orc_scene* s, const Node* nodes, const Tri* tris, V3 o, V3 d, float tmin, float tmax, Counters* c);
 // RENDER_SPEC 7.1d / 7.1g, any-hit rays: 0 = every hit blocks, 1 = invisible (opacity exactly 0, no medium behind it), 2 = translucent
 // (blocks with probability opacity x base-colour-map alpha, decided per (ray key, triangle)), 3 = invisible boundary of a medium (never
 // blocks, adds to the ray's optical depth), 4 = translucent boundary of a medium (2, and 3 when it lets the ray through)
@@ -105,7 +117,7 @@ struct AnyCtx { const orc_scene* s; uint32_t key; uint32_t tau[3]; };
 float hit_alpha(const orc_scene* s, uint32_t prim, float u, float v);  // opacity x base-colour-map alpha (bilinear, level 0) at a hit
 // a triangle of the any-hit copy was hit inside (tmin, tmax) at distance t with Moeller-Trumbore determinant det: true = it blocks the ray
 bool any_hit_event(AnyCtx* ax, const Tri& tr, float t, float det, float u, float v);
-bool trace_any(const Node* nodes, const Tri* tris, V3 o, V3 d, float tmin, float tmax, AnyCtx* ax, Counters* c);
+bool trace_any(const orc_scene* s, const Node* nodes, const Tri* tris, V3 o, V3 d, float tmin, float tmax, AnyCtx* ax, Counters* c);
 V3 any_transmittance(const AnyCtx& ax);  // exp_neg(-max(tau, 0) / 65536) per channel
 // the same on the scene's tree of choice: the product's 4-wide tree if one was handed over, else the oracle's own BVH2
 Hit scene_trace_closest(const orc_scene* s, V3 o, V3 d, float tmin, float tmax, Counters* c);

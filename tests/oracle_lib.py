@@ -179,12 +179,18 @@ class OracleScene:
         lib().orc_scene_get_triangles(self._h, fptr(out))
         return out
 
-    def use_bvh(self, nodes_u32=None, tris_u32=None):
-        """render() then traverses this product-built tree (None: the oracle's own again)"""
+    def use_bvh(self, nodes_u32=None, tris_u32=None, refs_u32=None):
+        """render() then traverses this product-built tree (None: the oracle's own again); refs_u32: the instance references of a
+        two-level tree (renderer.download_instance_refs())"""
         if nodes_u32 is None:
             lib().orc_scene_use_bvh4(self._h, C.c_void_p(0), C.c_uint32(0), C.c_void_p(0), C.c_uint32(0))
             return
-        self._ext = (np.ascontiguousarray(nodes_u32), np.ascontiguousarray(tris_u32))
+        self._ext = (np.ascontiguousarray(nodes_u32), np.ascontiguousarray(tris_u32), None if refs_u32 is None else np.ascontiguousarray(refs_u32))
+        if refs_u32 is not None and len(refs_u32):
+            lib().orc_scene_use_bvh4_two_level(self._h, C.c_void_p(self._ext[0].ctypes.data), C.c_uint32(self._ext[0].size // 16),
+                                               C.c_void_p(self._ext[1].ctypes.data), C.c_uint32(self._ext[1].size // 12),
+                                               C.c_void_p(self._ext[2].ctypes.data), C.c_uint32(self._ext[2].size // 16))
+            return
         lib().orc_scene_use_bvh4(self._h, C.c_void_p(self._ext[0].ctypes.data), C.c_uint32(self._ext[0].size // 16),
                                  C.c_void_p(self._ext[1].ctypes.data), C.c_uint32(self._ext[1].size // 12))
 
@@ -251,10 +257,21 @@ class OracleScene:
         return images, st
 
 
-def trace_on_bvh(nodes_u32, tris_u32, rays, mode=0):
+def set_instancing(on=True):
+    """scenes created from now on: on = RENDER_SPEC 4.5 (instanced primitives intersected in object space), off = everything flattened"""
+    lib().orc_set_instancing_off(C.c_int(0 if on else 1))
+
+
+def trace_on_bvh(nodes_u32, tris_u32, rays, mode=0, refs_u32=None):
     rays = np.ascontiguousarray(rays, dtype=A.RAY_DTYPE)
     hits = np.empty(rays.shape[0], dtype=A.HIT_DTYPE)
     ctr = (C.c_uint64 * 2)(0, 0)
+    if refs_u32 is not None and len(refs_u32):  # two-level tree (RENDER_SPEC 4.5)
+        refs_u32 = np.ascontiguousarray(refs_u32)
+        lib().orc_trace_rays_on_bvh4_two_level(C.c_void_p(nodes_u32.ctypes.data), C.c_uint32(nodes_u32.size // 16), C.c_void_p(tris_u32.ctypes.data),
+                                               C.c_uint32(tris_u32.size // 12), C.c_void_p(refs_u32.ctypes.data), C.c_void_p(rays.ctypes.data),
+                                               C.c_void_p(hits.ctypes.data), C.c_uint32(rays.shape[0]), C.c_int(mode), ctr)
+        return hits, (ctr[0], ctr[1])
     fn = lib().orc_trace_rays_on_bvh4
     fn(C.c_void_p(nodes_u32.ctypes.data), C.c_uint32(nodes_u32.size // 16), C.c_void_p(tris_u32.ctypes.data),
        C.c_uint32(tris_u32.size // 12), C.c_void_p(rays.ctypes.data), C.c_void_p(hits.ctypes.data),
@@ -270,6 +287,17 @@ def validate_bvh(nodes_u32, tris_u32, ref_triangles9):
     fn.restype = C.c_int
     rc = fn(C.c_void_p(nodes_u32.ctypes.data), C.c_uint32(nodes_u32.size // 16), C.c_void_p(tris_u32.ctypes.data),
             C.c_uint32(tris_u32.size // 12), fptr(ref) if ref is not None else C.c_void_p(0), C.byref(md))
+    return rc, md.value
+
+
+def validate_bvh_two_level(scene, nodes_u32, tris_u32, refs_u32):
+    """structural check of a product-built two-level tree (RENDER_SPEC 4.5) against the scene `scene` (an OracleScene): (code, levels)"""
+    md = C.c_uint32()
+    fn = lib().orc_validate_bvh4_two_level
+    fn.restype = C.c_int
+    refs_u32 = np.ascontiguousarray(refs_u32)
+    rc = fn(scene._h, C.c_void_p(nodes_u32.ctypes.data), C.c_uint32(nodes_u32.size // 16), C.c_void_p(tris_u32.ctypes.data),
+            C.c_uint32(tris_u32.size // 12), C.c_void_p(refs_u32.ctypes.data), C.c_uint32(refs_u32.size // 16), C.byref(md))
     return rc, md.value
 
 

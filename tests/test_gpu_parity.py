@@ -30,6 +30,19 @@ def make_renderer(halart, scene, w, h, max_depth=5, rr_depth=3, tonemap=(False, 
     return r
 
 
+def validate_tree(oracle, osc, r):
+    """structural check of the renderer's tree against the oracle's scene: (code, levels, two_level).  One-level trees: every child box
+    contains what hangs below it, the triangles are the scene's bit for bit; two-level trees (RENDER_SPEC 4.5: scenes in which several
+    instances reference one primitive): the same per tree, in its own space, plus the instance levels and references"""
+    nodes, tris = r.download_bvh()
+    refs = r.download_instance_refs()
+    if len(refs):
+        rc, depth = oracle.validate_bvh_two_level(osc, nodes, tris, refs)
+        return rc, depth, True
+    rc, depth = oracle.validate_bvh(nodes, tris, osc.triangles())
+    return rc, depth, False
+
+
 def struct_bytes(s):
     return bytes(memoryview(s))
 
@@ -146,11 +159,15 @@ def test_bvh_structure_and_flattening(halart, oracle, name):
     assert info.triangle_count == osc.triangle_count == s.triangle_count()
     omn, omx = osc.bounds()
     assert list(info.scene_min) == list(omn) and list(info.scene_max) == list(omx)
-    nodes, tris = r.download_bvh()
     assert info.node_width == 4  # compressed 4-wide nodes are the default format (RENDER_SPEC §4.1b)
-    rc, depth = oracle.validate_bvh(nodes, tris, osc.triangles())  # also checks v0/e1/e2 bit-exact vs RENDER_SPEC §3
+    rc, depth, two_level = validate_tree(oracle, osc, r)  # also checks v0/e1/e2 bit-exact vs RENDER_SPEC §3 / 4.5
     assert rc == 0, f"validate_bvh code {rc}"
-    assert depth == info.max_depth
+    assert two_level == (name == "sponza_60k")  # the atrium's columns and arches are instanced primitives
+    if two_level:
+        assert depth <= info.max_depth and info.instance_node_count > 0 and info.instance_ref_count == 42
+        assert info.stored_triangle_count < 0.6 * info.triangle_count  # every instanced primitive is stored once
+    else:
+        assert depth == info.max_depth and info.stored_triangle_count == info.triangle_count and info.instance_node_count == 0
     r.close()
 
 
@@ -179,16 +196,24 @@ def test_traversal_step_counts_match_oracle_on_same_bvh(halart, oracle):
     """the inputs of roofline.achieved: nodes visited / triangles tested per ray must equal the oracle's count on the
     SAME (GPU-built) BVH for the same rays"""
     s = scenes.sponza_class(target_triangles=60000, disney=False)
-    r = make_renderer(halart, s, 16, 16)
-    osc = oracle.OracleScene(s)
-    rays = osc.camera_rays(320, 180, 0)
-    nodes, tris = r.download_bvh()
-    for mode in (0, 1):
-        hits, cnt = r.trace_rays_host(rays, mode, count_steps=True)
-        ohits, ocnt = oracle.trace_on_bvh(nodes, tris, rays, mode)
-        assert cnt == ocnt
-        assert np.array_equal(hits["t"], ohits["t"])
-    r.close()
+    for instancing in (True, False):  # the two-level tree (instance levels + one tree per instanced primitive) and everything flattened
+        r = make_renderer(halart, s, 16, 16, build=dict(instancing=instancing))
+        oracle.set_instancing(instancing)
+        try:
+            osc = oracle.OracleScene(s)
+        finally:
+            oracle.set_instancing(True)
+        rays = osc.camera_rays(320, 180, 0)
+        nodes, tris = r.download_bvh()
+        refs = r.download_instance_refs()
+        assert (len(refs) > 0) == instancing
+        for mode in (0, 1):
+            hits, cnt = r.trace_rays_host(rays, mode, count_steps=True)
+            ohits, ocnt = oracle.trace_on_bvh(nodes, tris, rays, mode, refs)
+            assert cnt == ocnt, (instancing, mode)
+            assert np.array_equal(hits["t"], ohits["t"])
+            assert hits.tobytes() == osc.trace(rays, mode).tobytes()  # and the oracle's own tree, same instancing rule
+        r.close()
 
 
 def test_deep_stack_spills_to_global_scratch(halart, oracle):
@@ -440,8 +465,7 @@ def test_refit_after_vertex_deformation(halart, oracle):
     r.refit()
     s.meshes[mesh].primitives[0].vertices = v
     osc = oracle.OracleScene(s)
-    nodes, tris = r.download_bvh()
-    rc, _ = oracle.validate_bvh(nodes, tris, osc.triangles())
+    rc, _, _ = validate_tree(oracle, osc, r)
     assert rc == 0
     rays = osc.camera_rays(160, 96, 0)
     assert r.trace_rays_host(rays, 0).tobytes() == osc.trace(rays, 0).tobytes()
@@ -462,13 +486,13 @@ def test_ploc_drivers_build_the_same_tree(halart, oracle):
         r = make_renderer(halart, s, 16, 16, build=dict(builder="ploc", ploc_tail=tail, ploc_look_every=look, collapse_look_every=collapse_look))
         trees.append(r.download_bvh())
         info = r.bvh_info()
+        if len(trees) == 1:
+            rc, _, two_level = validate_tree(oracle, oracle.OracleScene(s), r)  # (a two-level tree: every tree of it is built by PLOC)
+            assert rc == 0 and two_level
         r.close()
     assert info.triangle_count >= 4096
     for nodes, tris in trees[1:]:
         assert nodes.tobytes() == trees[0][0].tobytes() and tris.tobytes() == trees[0][1].tobytes()
-    osc = oracle.OracleScene(s)
-    rc, _ = oracle.validate_bvh(trees[0][0], trees[0][1], osc.triangles())
-    assert rc == 0
 
 
 def test_builders_differ_in_trees_not_in_results(halart, oracle):
@@ -476,14 +500,18 @@ def test_builders_differ_in_trees_not_in_results(halart, oracle):
     structural check, is rebuilt byte for byte, gives the oracle's hits (the oracle traverses its OWN tree) and the oracle's step counts
     on that very tree; the SAH tree is the one with the fewest node visits per ray"""
     s = scenes.sponza_class(target_triangles=60_000, disney=False)
-    osc = oracle.OracleScene(s)
+    oracle.set_instancing(False)  # one tree over all 60 k triangles (instancing off on both sides): the builders are compared on it
+    try:
+        osc = oracle.OracleScene(s)
+    finally:
+        oracle.set_instancing(True)
     mn, mx = osc.bounds()
     rays = np.concatenate([random_rays(30000, mn, mx, 23), osc.camera_rays(160, 90, 0)])
     want = osc.trace(rays, 0)
     want_any = osc.trace(rays, 1)
     visits = {}
     for builder in ("sah", "ploc", "lbvh", None):
-        r = make_renderer(halart, s, 16, 16, build=dict(builder=builder))
+        r = make_renderer(halart, s, 16, 16, build=dict(builder=builder, instancing=False))
         nodes, tris = r.download_bvh()
         rc, depth = oracle.validate_bvh(nodes, tris, osc.triangles())
         assert rc == 0 and depth == r.bvh_info().max_depth, builder
@@ -495,7 +523,7 @@ def test_builders_differ_in_trees_not_in_results(halart, oracle):
         assert np.array_equal(got_any["t"], want_any["t"]), builder
         assert cnt_any == oracle.trace_on_bvh(nodes, tris, rays, 1)[1], builder
         r.close()
-        r2 = make_renderer(halart, s, 16, 16, build=dict(builder=builder))  # deterministic: atomics only carry min / max / integer sums
+        r2 = make_renderer(halart, s, 16, 16, build=dict(builder=builder, instancing=False))  # deterministic: atomics only carry min / max / integer sums
         n2, t2 = r2.download_bvh()
         r2.close()
         assert n2.tobytes() == nodes.tobytes() and t2.tobytes() == tris.tobytes(), builder
@@ -901,9 +929,10 @@ def test_full_size_scene_bvh_and_rays(halart, oracle):
     osc = oracle.OracleScene(s)
     info = r.bvh_info()
     assert info.triangle_count == osc.triangle_count > 900_000
-    nodes, tris = r.download_bvh()
-    rc, depth = oracle.validate_bvh(nodes, tris, osc.triangles())
-    assert rc == 0 and depth == info.max_depth
+    rc, depth, two_level = validate_tree(oracle, osc, r)
+    assert rc == 0 and two_level and depth <= info.max_depth
+    # RENDER_SPEC 4.5: the 28 columns and 14 arches are instances of three primitives, stored once
+    assert info.instance_ref_count == 42 and info.stored_triangle_count < 0.45 * info.triangle_count
     rays = osc.camera_rays(640, 360, 0)
     got = r.trace_rays_host(rays, 0)
     sub = slice(0, None, len(rays) // 1500)
@@ -1216,3 +1245,129 @@ def test_random_scenes_bit_exact(halart, oracle, seed):
     bad, rays_ok, lit = render_random_scene_both(halart, oracle, seed, big=seed % 6 == 5)
     assert bad == [0, 0, 0, 0] and rays_ok, (seed, bad, rays_ok)
     assert lit >= 0.0
+
+
+# ---- two-level trees (RENDER_SPEC 4.5) ---------------------------------------------------------------------------------------------
+def _instanced_cornell(extra):
+    """the Cornell box with further instances of the short block's mesh: extra = [(4x4 local transform, parent node or None)]"""
+    s = scenes.cornell_box()
+    for k, (m, parent) in enumerate(extra):
+        s.nodes.append(H.HalaNode(name=f"copy_{k}", mesh_index=1, parent=parent, local_transform=np.asarray(m, dtype=f32)))
+    return s
+
+
+def _xf(t=(0, 0, 0), scale=(1, 1, 1), ry=0.0, rx=0.0):
+    cy, sy, cx, sx = np.cos(ry), np.sin(ry), np.cos(rx), np.sin(rx)
+    R = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]]) @ np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    m = np.eye(4)
+    m[:3, :3] = R @ np.diag(scale)
+    m[:3, 3] = t
+    return m.astype(f32)
+
+
+def test_two_level_instances_with_general_transforms(halart, oracle):
+    """RENDER_SPEC 4.5 on small scenes (a two-level tree whatever the size): the short block's mesh referenced four more times —
+    rotated + non-uniformly scaled, MIRRORED (negative determinant), under a parent that shears it, and squashed flat (determinant 0:
+    that instance is flattened to world space, its siblings stay instanced).  Ray batches equal the oracle's own tree and brute force bit
+    for bit, the render equals the oracle's, the tree passes the structural check, the step counts equal the oracle's on that tree."""
+    shear = np.eye(4, dtype=f32); shear[0, 1] = 0.35; shear[:3, 3] = (60.0, 200.0, 120.0)
+    s = _instanced_cornell([(_xf((250, 330, 230), (0.6, 1.4, 0.5), ry=0.7, rx=0.2), None),
+                            (_xf((520, 60, 90), (-0.8, 0.9, 0.7), ry=-0.4), None),
+                            (shear, None),
+                            (_xf((-20, 150, 200), (0.5, 0.5, 0.5), ry=1.1), 6),     # child of the shearing node
+                            (_xf((100, 400, 300), (0.7, 0.0, 0.7)), None)])        # flat: not invertible
+    r = make_renderer(halart, s, 64, 48)
+    osc = oracle.OracleScene(s)
+    info = r.bvh_info()
+    assert info.instance_ref_count == 5 and info.instance_node_count >= 1  # the original + 4 invertible copies; the flat one is flattened
+    assert info.stored_triangle_count == info.triangle_count - 4 * 10 and info.lds_node_count == 0
+    rc, depth, two_level = validate_tree(oracle, osc, r)
+    assert rc == 0 and two_level
+    omn, omx = osc.bounds()
+    assert list(info.scene_min) == list(omn) and list(info.scene_max) == list(omx)
+    pad = (omx - omn) * 0.2
+    rays = np.concatenate([random_rays(40000, omn - pad, omx + pad, 3), osc.camera_rays(160, 120, 0)])
+    nodes, tris = r.download_bvh()
+    refs = r.download_instance_refs()
+    for mode in (0, 1):
+        got, cnt = r.trace_rays_host(rays, mode, count_steps=True)
+        assert got.tobytes() == osc.trace(rays, mode).tobytes()
+        assert cnt == oracle.trace_on_bvh(nodes, tris, rays, mode, refs)[1]
+    sub = rays[::13]
+    assert r.trace_rays_host(sub, 0).tobytes() == osc.trace(sub, 0, brute=True).tobytes()
+    r.update_batch(3); r.render()
+    imgs, st = osc.render(64, 48, frames=3)
+    assert_images_equal(r, imgs)
+    stg = r.statistics()
+    assert (stg.rays_closest_total, stg.rays_shadow_total) == (st.rays_closest, st.rays_shadow)
+    # everything flattened (hala_rt_build_options::instancing = 1; the oracle told the same): the other arithmetic, the same picture to rounding
+    r2 = make_renderer(halart, s, 64, 48, build=dict(instancing=False))
+    oracle.set_instancing(False)
+    try:
+        flat = oracle.OracleScene(s)
+    finally:
+        oracle.set_instancing(True)
+    assert r2.bvh_info().instance_ref_count == 0
+    r2.update_batch(3); r2.render()
+    fimgs, _ = flat.render(64, 48, frames=3)
+    assert_images_equal(r2, fimgs)
+    assert np.abs(fimgs[0][..., :3] - imgs[0][..., :3]).mean() < 2e-3
+    r.close(); r2.close()
+
+
+def test_two_level_refit_of_a_moved_instance_touches_only_the_instance_levels(halart, oracle):
+    """hala_rt_update_node_transform on a node of an INSTANCED primitive + refit: the primitives' trees and all triangles stay byte for
+    byte, only the instance levels (the first instance_node_count nodes) and the instance references are rebuilt; a node of a primitive
+    that is referenced once is flattened geometry: moving it refits the world tree.  Both times the frame equals the oracle's."""
+    s = scenes.sponza_class(target_triangles=60_000)
+    r = make_renderer(halart, s, 48, 27)
+    info = r.bvh_info()
+    T = info.instance_node_count
+    assert T > 0
+    n0, t0 = r.download_bvh()
+    refs0 = r.download_instance_refs()
+    col = next(k for k, n in enumerate(s.nodes) if n.name == "column_5")
+    m = np.array(s.nodes[col].local_transform, dtype=f32).copy()
+    m[:3, 3] += np.array([1.5, 0.0, -2.0], dtype=f32)
+    r.update_node_transform(col, m)
+    r.refit()
+    n1, t1 = r.download_bvh()
+    refs1 = r.download_instance_refs()
+    assert t0.tobytes() == t1.tobytes()
+    assert n0.reshape(-1, 16)[T:].tobytes() == n1.reshape(-1, 16)[T:].tobytes()      # every tree below the instance levels: untouched
+    assert n0.reshape(-1, 16)[:T].tobytes() != n1.reshape(-1, 16)[:T].tobytes() and refs0.tobytes() != refs1.tobytes()
+    s.nodes[col].local_transform = m
+    osc = oracle.OracleScene(s)
+    assert validate_tree(oracle, osc, r)[0] == 0
+    r.update(); r.update(); r.render()
+    img, _ = osc.render(48, 27, frames=2)
+    assert r.read_image(0).tobytes() == img[0].tobytes()
+    # a drape is referenced once: flattened into the world tree, which a move refits
+    dr = next(k for k, n in enumerate(s.nodes) if n.name == "drape_2")
+    m2 = np.array(s.nodes[dr].local_transform, dtype=f32).copy()
+    m2[:3, 3] += np.array([0.0, 0.8, 1.0], dtype=f32)
+    r.update_node_transform(dr, m2)
+    r.refit()
+    n2, t2 = r.download_bvh()
+    assert t2.tobytes() != t1.tobytes() and n2.reshape(-1, 16)[T:].tobytes() != n1.reshape(-1, 16)[T:].tobytes()
+    s.nodes[dr].local_transform = m2
+    osc = oracle.OracleScene(s)
+    assert validate_tree(oracle, osc, r)[0] == 0
+    r.update(); r.update(); r.render()
+    img, _ = osc.render(48, 27, frames=2)
+    assert r.read_image(0).tobytes() == img[0].tobytes()
+    r.close()
+
+
+def test_two_level_tree_stores_instanced_primitives_once(halart):
+    """the 1 M-triangle atrium: 28 columns + 14 arches are instances of three primitives.  Nodes + triangles + shading records of the
+    two-level tree against everything flattened (hala_rt_build_options::instancing = 1)"""
+    s = scenes.sponza_class(target_triangles=1_000_000, disney=False)
+    sizes = {}
+    for instancing in (True, False):
+        r = make_renderer(halart, s, 16, 16, build=dict(instancing=instancing))
+        i = r.bvh_info()
+        sizes[instancing] = (i.tree_bytes, i.stored_triangle_count, i.triangle_count)
+        r.close()
+    assert sizes[False][1] == sizes[False][2] == sizes[True][2] > 900_000
+    assert sizes[True][1] < 0.45 * sizes[True][2] and sizes[True][0] < 0.45 * sizes[False][0], sizes
