@@ -317,7 +317,7 @@ __global__ void __launch_bounds__(kTraverseThreads, STAGED ? kTraverseWavesPerSi
 k_trace_batch(SceneView sv, const hala_ray* __restrict__ rays, hala_hit* __restrict__ hits, const uint32_t* __restrict__ n_ptr,
               uint32_t n_imm, WorkCounters* __restrict__ work, uint2* __restrict__ spill_base, Control* __restrict__ ctl, int account,
               uint32_t refill) {
-  const TraverseLds lds = stage_bvh<STAGED>(sv, g_smem);
+  const TraverseLds lds = stage_bvh<STAGED, INST>(sv, g_smem);
   const uint32_t n = n_ptr ? *n_ptr : n_imm;
   uint2* spill = spill_base ? spill_base + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * kStackSpill : nullptr;
   StepCounters sc;
@@ -335,7 +335,7 @@ template <bool COUNT, bool STAGED, bool INST>
 __global__ void __launch_bounds__(kTraverseThreads, STAGED ? kTraverseWavesPerSimdStaged : kTraverseWavesPerSimd)
 k_trace_primary(SceneView sv, FrameConst fc, hala_hit* __restrict__ hits, WorkCounters* __restrict__ work, uint2* __restrict__ spill_base,
                 Control* __restrict__ ctl, uint32_t n_account, uint32_t refill) {
-  const TraverseLds lds = stage_bvh<STAGED>(sv, g_smem);
+  const TraverseLds lds = stage_bvh<STAGED, INST>(sv, g_smem);
   uint2* spill = spill_base ? spill_base + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * kStackSpill : nullptr;
   StepCounters sc;
   if (blockIdx.x == 0 && threadIdx.x == 0) ctl->rays_closest += n_account;
@@ -352,7 +352,7 @@ template <bool COUNT, bool STAGED, bool ALPHA, bool INST>
 __global__ void __launch_bounds__(kTraverseThreads, STAGED ? kTraverseWavesPerSimdStaged : kTraverseWavesPerSimd)
 k_trace_shadow(SceneView sv, Queues q, PathState ps, Control* __restrict__ ctl, uint32_t depth, uint32_t kind, uint2* __restrict__ spill_base,
                uint32_t refill) {
-  const TraverseLds lds = stage_bvh<STAGED>(sv, g_smem);
+  const TraverseLds lds = stage_bvh<STAGED, INST>(sv, g_smem);
   const uint32_t n = ctl->n_shadow[kind][depth];
   uint2* spill = spill_base ? spill_base + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * kStackSpill : nullptr;
   StepCounters sc;
@@ -374,7 +374,7 @@ template <bool STAGED, bool ALPHA, bool INST>
 __global__ void __launch_bounds__(kTraverseThreads, STAGED ? kTraverseWavesPerSimdStaged : kTraverseWavesPerSimd)
 k_trace_shadow_then_batch(SceneView sv, const Tri* __restrict__ tris_any, Queues q, PathState ps, Control* __restrict__ ctl, uint32_t depth,
                           uint32_t kinds, const hala_ray* __restrict__ rays, hala_hit* __restrict__ hits, uint2* __restrict__ spill_base, uint32_t refill) {
-  const TraverseLds lds = stage_bvh<STAGED>(sv, g_smem);
+  const TraverseLds lds = stage_bvh<STAGED, INST>(sv, g_smem);
   uint2* spill = spill_base ? spill_base + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * kStackSpill : nullptr;
   StepCounters sc;
   {
@@ -789,23 +789,27 @@ __global__ void __launch_bounds__(256) k_scatter_tiles(FrameConst fc, const floa
 // ---------------------------------------------------------------------------------------------------------
 static inline uint32_t blocks_for(uint32_t n, uint32_t per) { return (n + per - 1) / per; }
 
-size_t traverse_fixed_lds_bytes(bool staged) {  // per-lane stacks (+ the waves' leaf work lists and merge slots of the large-scene variant)
-  return staged ? (size_t)kStackLdsStaged * kTraverseThreads * 8 : (size_t)kStackLdsGlobal * kTraverseThreads * 8 + (kTraverseThreads / 64) * kCoopBytesPerWave;
+// tree: 0 large one-level, 1 LDS-staged, 2 two-level (kernels.h: TreeKind)
+size_t traverse_fixed_lds_bytes(int tree) {  // per-lane stacks (+ the waves' leaf work lists and merge slots of the large-scene variants)
+  return tree == 1 ? (size_t)kStackLdsStaged * kTraverseThreads * 8
+                   : (size_t)(tree == 2 ? kStackLdsInst : kStackLdsGlobal) * kTraverseThreads * 8 + (kTraverseThreads / 64) * kCoopBytesPerWave;
 }
-uint32_t traverse_stack_lds_levels(bool staged) { return staged ? kStackLdsStaged : kStackLdsGlobal; }
+uint32_t traverse_stack_lds_levels(int tree) { return tree == 1 ? kStackLdsStaged : (tree == 2 ? kStackLdsInst : kStackLdsGlobal); }
 uint32_t traverse_stack_spill_levels() { return kStackSpill; }
 uint32_t traverse_max_leaf(bool staged) { return staged ? 8u : (uint32_t)kLeafSlots; }
-uint32_t traverse_blocks_per_cu(size_t dynamic_lds_bytes, bool staged) {
+uint32_t traverse_blocks_per_cu(size_t dynamic_lds_bytes, int tree) {
   int a = 0, b = 0;
-  const hipError_t ea = staged ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_batch<false, false, true, false, false>, kTraverseThreads, dynamic_lds_bytes)
-                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_batch<false, false, false, false, false>, kTraverseThreads, dynamic_lds_bytes);
-  const hipError_t eb = staged ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_trace_shadow<false, true, false, false>, kTraverseThreads, dynamic_lds_bytes)
-                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_trace_shadow<false, false, false, false>, kTraverseThreads, dynamic_lds_bytes);
+  const hipError_t ea = tree == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_batch<false, false, true, false, false>, kTraverseThreads, dynamic_lds_bytes)
+                      : tree == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_batch<false, false, false, false, true>, kTraverseThreads, dynamic_lds_bytes)
+                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_trace_batch<false, false, false, false, false>, kTraverseThreads, dynamic_lds_bytes);
+  const hipError_t eb = tree == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_trace_shadow<false, true, false, false>, kTraverseThreads, dynamic_lds_bytes)
+                      : tree == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_trace_shadow<false, false, false, true>, kTraverseThreads, dynamic_lds_bytes)
+                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_trace_shadow<false, false, false, false>, kTraverseThreads, dynamic_lds_bytes);
   if (ea != hipSuccess || eb != hipSuccess) return 0;
   return (uint32_t)std::max(0, std::min(a, b));
 }
 static size_t traverse_smem(const SceneView& sv) {
-  return traverse_fixed_lds_bytes(sv.staged != 0u) + (sv.staged ? (size_t)sv.lds_nodes * 64 + (size_t)sv.lds_tris * 48 : 0);
+  return traverse_fixed_lds_bytes(sv.staged ? 1 : (sv.two_level ? 2 : 0)) + (sv.staged ? (size_t)sv.lds_nodes * 64 + (size_t)sv.lds_tris * 48 : 0);
 }
 
 // the traversal kernels are compiled per (any-hit, counting, BVH staged in LDS); all three are launch-time constants

@@ -17,11 +17,12 @@ struct LaunchCfg {
 };
 
 // integrator.hip
-size_t traverse_fixed_lds_bytes(bool staged);  // LDS bytes of one workgroup besides a staged BVH: per-lane stacks (+ leaf work lists)
-uint32_t traverse_stack_lds_levels(bool staged);  // stack entries kept in LDS
+// `tree`: 0 = a large one-level tree, 1 = a tree staged whole in LDS, 2 = a two-level tree (RENDER_SPEC 4.5): each has its kernel variants
+size_t traverse_fixed_lds_bytes(int tree);  // LDS bytes of one workgroup besides a staged BVH: per-lane stacks (+ leaf work lists)
+uint32_t traverse_stack_lds_levels(int tree);  // stack entries kept in LDS
 uint32_t traverse_max_leaf(bool staged);  // largest leaf (triangles) the traversal variant accepts
 uint32_t traverse_stack_spill_levels();  // deeper entries spilled to global scratch (8 B each, per lane)
-uint32_t traverse_blocks_per_cu(size_t dynamic_lds_bytes, bool staged);  // resident workgroups per CU (occupancy query)
+uint32_t traverse_blocks_per_cu(size_t dynamic_lds_bytes, int tree);  // resident workgroups per CU (occupancy query)
 void launch_trace_batch(const LaunchCfg& lc, const SceneView& sv, const hala_ray* rays, hala_hit* hits, const uint32_t* n_ptr,
                         uint32_t n_imm, WorkCounters* work, Control* ctl, bool any, bool count, bool account, hipStream_t s);
 void launch_trace_shadow(const LaunchCfg& lc, const SceneView& sv, const Queues& q, const PathState& ps, Control* ctl, uint32_t depth,

@@ -150,7 +150,7 @@ struct hala_rt_renderer {
   };
   std::vector<std::unique_ptr<Blas>> blas;
   bool two_level = false;
-  uint32_t instancing_mode = 0;            // hala_rt_build_options::instancing: 0 by the rule of RENDER_SPEC 4.5, 1 never (everything flattened)
+  uint32_t instancing_mode = 0;            // hala_rt_build_options::instancing: 0 automatic (by size), 1 never (everything flattened), 2 by the rule of RENDER_SPEC 4.5
   std::vector<uint8_t> inst_instanced;     // per instance: intersected in object space
   std::vector<int32_t> prim_blas;          // per primitive: index into blas, -1
   uint32_t tlas_capacity = 0, tlas_nodes = 0, stored_tris = 0;
@@ -536,8 +536,9 @@ int configure_traversal(hala_rt_renderer* r) {
   r->lds_nodes = r->staged ? r->bvh.node_count : 0u;
   r->lds_tris = r->staged ? r->bvh.tri_count : 0u;
   if (r->leaf_max_built > traverse_max_leaf(r->staged)) RT_FAIL("The BVH was built with larger leaves than the traversal variant for its size accepts.");
-  const size_t smem = (size_t)r->lds_nodes * 64 + (size_t)r->lds_tris * 48 + traverse_fixed_lds_bytes(r->staged);
-  uint32_t per_cu = traverse_blocks_per_cu(smem, r->staged);
+  const int tree = r->staged ? 1 : (r->two_level ? 2 : 0);
+  const size_t smem = (size_t)r->lds_nodes * 64 + (size_t)r->lds_tris * 48 + traverse_fixed_lds_bytes(tree);
+  uint32_t per_cu = traverse_blocks_per_cu(smem, tree);
   if (per_cu == 0) RT_FAIL("The traversal kernel does not fit on a compute unit with the requested LDS staging.");
   per_cu = std::min(per_cu, 8u);
   if (const char* e = tune_env("HALART_BLOCKS_PER_CU")) per_cu = std::min(per_cu, std::max(1u, (uint32_t)atoi(e)));  // tuning knob
@@ -547,8 +548,8 @@ int configure_traversal(hala_rt_renderer* r) {
   // refilling once half the wave is idle is best when node fetches go to L2 / Infinity Cache
   r->lcfg.refill = r->staged ? 64u : kRefillThreshold;
   if (const char* e = tune_env("HALART_REFILL")) r->lcfg.refill = std::min(64u, std::max(1u, (uint32_t)strtoul(e, nullptr, 10)));  // tuning knob
-  if (r->two_level || r->bvh.stack_need > traverse_stack_lds_levels(r->staged)) {
-    if (r->two_level || r->bvh.stack_need > traverse_stack_lds_levels(r->staged) + traverse_stack_spill_levels()) {
+  if (r->two_level || r->bvh.stack_need > traverse_stack_lds_levels(tree)) {
+    if (r->two_level || r->bvh.stack_need > traverse_stack_lds_levels(tree) + traverse_stack_spill_levels()) {
       // 3 x levels is a loose bound (every node on the path deferring three siblings).  Before refusing the tree, take the exact
       // one: need(node) = (inner children - 1) + max need(inner child) — the worst order visits the child with the deepest
       // need first while all its siblings wait.  Nodes are in breadth-first order (children behind their parent): one reverse sweep.
@@ -573,7 +574,7 @@ int configure_traversal(hala_rt_renderer* r) {
       }
       r->bvh.stack_need = need.empty() ? 1u : std::max(1u, need[0]);
     }
-    if (r->bvh.stack_need > traverse_stack_lds_levels(r->staged) + traverse_stack_spill_levels())
+    if (r->bvh.stack_need > traverse_stack_lds_levels(tree) + traverse_stack_spill_levels())
       RT_FAIL("The BVH is deeper than the traversal stack supports (" + std::to_string(r->bvh.max_depth) + " levels, " + std::to_string(r->bvh.stack_need) + " stack entries).");
     RT_HIP(r->d_spill.resize((size_t)r->lcfg.persistent_blocks * 256 * traverse_stack_spill_levels()));
     r->lcfg.spill = r->d_spill.ptr;
@@ -631,7 +632,9 @@ static void h_transform_point(const float* m, const float* p, float* o) {  // RE
 static void classify_instances(hala_rt_renderer* r, std::vector<uint8_t>* flags) {
   const HostScene& hs = r->hs;
   flags->assign(hs.instances.size(), 0);
-  if (r->instancing_mode == 1u) return;
+  // automatic: the flattened tree is the faster one (no moves into object space, no instance levels to walk) while it fits comfortably
+  constexpr uint32_t kFlattenLimit = 1u << 26;  // triangles: ~15 GB of nodes, triangles and shading records
+  if (r->instancing_mode == 1u || (r->instancing_mode == 0u && hs.triangle_count <= kFlattenLimit)) return;
   std::vector<uint32_t> refs(hs.prims.size(), 0u);
   for (uint32_t p : hs.instance_prim) refs[p]++;
   for (size_t i = 0; i < hs.instances.size(); ++i) {
@@ -1031,7 +1034,7 @@ int hala_rt_commit(hala_rt_renderer* r) {
 int hala_rt_set_build_options(hala_rt_renderer* r, const hala_rt_build_options* o) {
   if (!r) RT_FAIL("The renderer handle is null!");
   if (!o) RT_FAIL("The build options are null!");
-  if (o->builder > 3u || o->ploc_tail > 2u || o->instancing > 1u) RT_FAIL("Invalid build options.");
+  if (o->builder > 3u || o->ploc_tail > 2u || o->instancing > 2u) RT_FAIL("Invalid build options.");
   for (uint32_t v : o->reserved) if (v != 0u) RT_FAIL("Invalid build options (reserved fields must be 0).");
   r->instancing_mode = o->instancing;
   r->bvh.opt.builder = o->builder; r->bvh.opt.ploc_tail = o->ploc_tail;

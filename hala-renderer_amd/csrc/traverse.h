@@ -35,7 +35,13 @@ constexpr int kStackLdsStaged = 12;  // entries kept in LDS per lane, LDS-staged
 #define RT_STACK_LDS 8  // large scenes: the LDS also holds the wave's leaf work list (below); pops drop culled entries, deep stacks are rare
 #endif
 constexpr int kStackLdsGlobal = RT_STACK_LDS;
-template <bool STAGED> RT_DI constexpr int stack_lds() { return STAGED ? kStackLdsStaged : kStackLdsGlobal; }
+// two-level trees park the world-space ray on the stack while a lane is inside an instance (4 entries).  More LDS entries per lane do
+// not pay: 10 or 12 instead of 8 cost a resident workgroup per CU (configs[3] two-level: 12.8 instead of 11.8 ms per frame)
+#ifndef RT_STACK_LDS_INST
+#define RT_STACK_LDS_INST 8
+#endif
+constexpr int kStackLdsInst = RT_STACK_LDS_INST;
+template <bool STAGED, bool INST = false> RT_DI constexpr int stack_lds() { return STAGED ? kStackLdsStaged : (INST ? kStackLdsInst : kStackLdsGlobal); }
 constexpr int kStackSpill = 56;  // deeper entries, global scratch
 // Wave-cooperative leaf pass of the large-scene kernels (trav_step, !STAGED): every wave owns a work list of up to 64 x 4 leaf items
 // (8 B: leaf reference, owner lane) and one 16-B merge slot per lane (best hit so far as a 64-bit key | u, v).
@@ -63,11 +69,11 @@ RT_DI float4 ld4(const RT_LDS f32x4* p) { const f32x4 v = *p; return make_float4
 
 // LDS layout: stack | STAGED: nodes | triangles; else: per-wave work lists | per-wave merge slots.  STAGED: cooperative copy of the
 // whole BVH (coalesced 16-B loads).
-template <bool STAGED>
+template <bool STAGED, bool INST = false>
 RT_DI TraverseLds stage_bvh(const SceneView& sv, unsigned char* smem) {
   RT_LDS unsigned char* base = (RT_LDS unsigned char*)smem;
   RT_LDS u32x2* st = (RT_LDS u32x2*)base;
-  RT_LDS unsigned char* rest = base + (size_t)stack_lds<STAGED>() * kTraverseThreads * 8;
+  RT_LDS unsigned char* rest = base + (size_t)stack_lds<STAGED, INST>() * kTraverseThreads * 8;
   if (STAGED) {
     RT_LDS f32x4* ln = (RT_LDS f32x4*)rest;
     RT_LDS f32x4* lt = ln + (size_t)sv.lds_nodes * 4;
@@ -245,7 +251,7 @@ RT_DI float lane_read(uint32_t src_lane_x4, float v) {  // v of lane src_lane_x4
 template <bool ANY, bool COUNT, bool STAGED, bool ALPHA, bool INST = false>
 RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, Trav& t, bool has, StepCounters& sc) {
   static_assert(!(INST && STAGED), "LDS-staged trees have no instance levels");
-  constexpr int kS = stack_lds<STAGED>();
+  constexpr int kS = stack_lds<STAGED, INST>();
   RT_LDS u32x2* stack = lds.stack + threadIdx.x;
   const RayPre& r = t.r;
   HitRec& best = t.best;

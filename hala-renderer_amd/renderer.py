@@ -119,12 +119,13 @@ class HalaRenderer:
 
     BUILDERS = {None: 0, "auto": 0, "sah": 1, "ploc": 2, "lbvh": 3}
 
-    def set_build_options(self, builder=None, ploc_tail=0, ploc_look_every=0, collapse_look_every=0, instancing=True):
+    def set_build_options(self, builder=None, ploc_tail=0, ploc_look_every=0, collapse_look_every=0, instancing=None):
         """how the next commit() builds the acceleration structure (hala_rt_set_build_options): builder = None | "sah" | "ploc" | "lbvh";
-        instancing = False flattens every instance to world space (one tree; RENDER_SPEC 4.5); the other fields only change how the host
-        drives the build rounds (same tree)"""
+        instancing = True: two-level tree (RENDER_SPEC 4.5: primitives referenced by several instances are stored once), False: every
+        instance flattened to world space (one tree), None: automatic (flattened up to 2^26 triangles); the other fields only change how the
+        host drives the build rounds (same tree)"""
         o = A.BuildOptions(builder=self.BUILDERS[builder], ploc_tail=ploc_tail, ploc_look_every=ploc_look_every, collapse_look_every=collapse_look_every,
-                           instancing=0 if instancing else 1)
+                           instancing=0 if instancing is None else (2 if instancing else 1))
         self._check(self._lib.hala_rt_set_build_options(self._h, C.byref(o)))
 
     def update(self, delta_time=0.0, width=None, height=None, ui_fn=None):

@@ -337,10 +337,15 @@ typedef struct hala_rt_build_options {
   uint32_t ploc_tail;           /* 0 / 1: the last PLOC rounds in one workgroup | 2: every round its own launch */
   uint32_t ploc_look_every;     /* PLOC rounds between two host looks at the device counters (default 6) */
   uint32_t collapse_look_every; /* levels of the 4-wide collapse between two host looks (default 8) */
-  uint32_t instancing;          /* 0: two-level tree — a primitive that several instances reference gets ONE object-space tree, its instances
-                                 *    are leaves of the instance levels (RENDER_SPEC 4.5; what the reference's BLAS / TLAS split expresses,
-                                 *    gpu_uploader.rs:782-815, :843-885, :937-959); 1: every instance flattened to world space (one tree).
-                                 *    The two settings intersect instanced geometry in different spaces: images agree to rounding, not bit for bit. */
+  uint32_t instancing;          /* what becomes of a primitive that several instances reference (RENDER_SPEC 4.5; the reference's BLAS /
+                                 * TLAS split, gpu_uploader.rs:782-815, :843-885, :937-959):
+                                 *  2: two-level tree — the primitive gets ONE object-space tree, its instances are leaves of instance
+                                 *     levels that are rebuilt on the host when a node moves; every instanced primitive is stored once;
+                                 *  1: every instance is flattened to world space, one tree over all triangles: the faster tree on this
+                                 *     hardware (configs[3]: 9.7 instead of 11.8 ms per frame), at the full triangle count in memory;
+                                 *  0: automatic — 1 unless the flattened scene holds more than 2^26 triangles (about 15 GB of tree), then 2.
+                                 * The two forms intersect instanced geometry in different spaces: images agree to rounding, not bit for bit;
+                                 * hala_bvh_info::instance_ref_count tells which one a commit chose. */
   uint32_t reserved[3];         /* must be 0 */
 } hala_rt_build_options;
 int hala_rt_set_build_options(hala_rt_renderer* r, const hala_rt_build_options* options);

@@ -160,7 +160,8 @@ void orc_trace_rays_on_bvh4_two_level(const void* nodes64, uint32_t node_count, 
                                       const orc_ray* rays, orc_hit* hits, uint32_t count, int mode, uint64_t* counters);
 int orc_validate_bvh4_two_level(const orc_scene* s, const void* nodes64, uint32_t node_count, const void* tris48, uint32_t tri_count,
                                 const void* refs64, uint32_t ref_count, uint32_t* max_depth);
-/* 1: every instance is flattened to world space in scenes created from now on (hala_rt_build_options::instancing = 1) */
+/* scenes created from now on: 0 = instanced primitives are intersected in object space (RENDER_SPEC 4.5; hala_rt_build_options::instancing
+ * = 2), 1 (the default) = every instance is flattened to world space */
 void orc_set_instancing_off(int off);
 // The oracle's own SAH tree in the product's 4-wide format (greedy surface-area collapse, conservative quantisation) and
 // its triangles in that tree's order: a CPU-built tree to pin the two functions above on, and a quality yardstick for

@@ -163,8 +163,9 @@ static bool world_to_object(const float* m, float* r0, float* r1, float* r2, flo
   for (int k = 0; k < 3; ++k) if (!std::isfinite(r0[k]) || !std::isfinite(r1[k]) || !std::isfinite(r2[k]) || !std::isfinite(tr[k])) return false;
   return true;
 }
-static int g_instancing_off = 0;
-// 1: every instance is flattened to world space (what hala_rt_build_options::instancing = 1 selects in the product)
+// RENDER_SPEC 4.5 is a per-scene choice (hala_rt_build_options::instancing; hala_bvh_info::instance_ref_count tells what the product chose).
+// Default: everything flattened — what the product's automatic mode picks for every scene of up to 2^26 triangles.
+static int g_instancing_off = 1;
 extern "C" void orc_set_instancing_off(int off) { g_instancing_off = off; }
 
 extern "C" orc_scene* orc_scene_create(const orc_scene_desc* desc) {

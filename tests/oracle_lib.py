@@ -257,8 +257,9 @@ class OracleScene:
         return images, st
 
 
-def set_instancing(on=True):
-    """scenes created from now on: on = RENDER_SPEC 4.5 (instanced primitives intersected in object space), off = everything flattened"""
+def set_instancing(on=False):
+    """scenes created from now on: on = RENDER_SPEC 4.5 (instanced primitives intersected in object space: what the product does with
+    build option instancing = True), off (the default) = everything flattened"""
     lib().orc_set_instancing_off(C.c_int(0 if on else 1))
 
 

@@ -57,8 +57,10 @@ def random_material(rs):
     return M
 
 
-def random_scene(seed, big=False):
-    """-> (scene, env or None, render kwargs)"""
+def random_scene(seed, big=False, instances=False):
+    """-> (scene, env or None, render kwargs); instances: some objects are referenced by further nodes with transforms of their own
+    (RENDER_SPEC 4.5: such primitives are intersected in object space when the tree is two-level) — drawn from a stream of their own, so
+    the scene is otherwise the one the seed gives without them"""
     rs = np.random.RandomState(seed)
     s = H.HalaScene()
     n_obj = rs.randint(2, 5)
@@ -106,6 +108,13 @@ def random_scene(seed, big=False):
         env = scenes.sky_sun_envmap(ew, eh, sun_gain=float(rs.choice([1.0, 30.0, 1e3])))
         if rs.rand() < 0.3:
             env[..., :3] *= rs.uniform(0.0, 2.0, (eh, ew, 3)).astype(f32)
+    if instances:
+        ri = np.random.RandomState(seed + 7919)
+        n_meshes = len(s.meshes) - 1  # not the ground
+        for k in range(int(ri.randint(2, 5))):
+            parent = 0 if ri.rand() < 0.6 else int(ri.randint(1, 1 + n_meshes))  # under the root or under one of the objects
+            s.nodes.append(H.HalaNode(name=f"inst{k}", parent=parent, mesh_index=int(ri.randint(0, n_meshes)),
+                                      local_transform=_xform(ri, ri.uniform(-1.8, 1.8, 3) * np.array([1.0, 0.5, 1.0]))))
     kw = dict(width=w, height=h, frames=int(rs.randint(1, 4)), max_depth=int(rs.randint(1, 9)), rr_depth=int(rs.randint(1, 5)),
               tonemap=[(False, False, False), (True, False, False), (True, True, False), (True, True, True)][rs.randint(4)],
               env_rotation=float(rs.choice([0.0, rs.uniform(0.0, 360.0)])), env_intensity=float(rs.choice([1.0, rs.uniform(0.2, 3.0)])),

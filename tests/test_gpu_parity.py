@@ -6,6 +6,8 @@ light records (the reference calls f32::cos there, gpu_uploader.rs:189,206).
 import ctypes as C
 import os
 
+import contextlib
+
 import numpy as np
 import pytest
 
@@ -28,6 +30,17 @@ def make_renderer(halart, scene, w, h, max_depth=5, rr_depth=3, tonemap=(False, 
     r.set_scene(scene)
     r.commit()
     return r
+
+
+@contextlib.contextmanager
+def two_level_trees(oracle):
+    """RENDER_SPEC 4.5 on both sides: oracle scenes created inside intersect instanced primitives in object space; pass the yielded build
+    options to make_renderer (hala_rt_build_options::instancing = 2).  The default everywhere else: every instance flattened."""
+    oracle.set_instancing(True)
+    try:
+        yield dict(instancing=True)
+    finally:
+        oracle.set_instancing(False)
 
 
 def validate_tree(oracle, osc, r):
@@ -150,11 +163,14 @@ SCENES = {
 }
 
 
-@pytest.mark.parametrize("name", list(SCENES.keys()))
+@pytest.mark.parametrize("name", list(SCENES.keys()) + ["sponza_60k:two_level"])
 def test_bvh_structure_and_flattening(halart, oracle, name):
+    want_two_level = name.endswith(":two_level")
+    name = name.split(":")[0]
     s = SCENES[name]()
-    r = make_renderer(halart, s, 16, 16)
-    osc = oracle.OracleScene(s)
+    with (two_level_trees(oracle) if want_two_level else contextlib.nullcontext()) as build:
+        r = make_renderer(halart, s, 16, 16, build=build)
+        osc = oracle.OracleScene(s)
     info = r.bvh_info()
     assert info.triangle_count == osc.triangle_count == s.triangle_count()
     omn, omx = osc.bounds()
@@ -162,7 +178,7 @@ def test_bvh_structure_and_flattening(halart, oracle, name):
     assert info.node_width == 4  # compressed 4-wide nodes are the default format (RENDER_SPEC §4.1b)
     rc, depth, two_level = validate_tree(oracle, osc, r)  # also checks v0/e1/e2 bit-exact vs RENDER_SPEC §3 / 4.5
     assert rc == 0, f"validate_bvh code {rc}"
-    assert two_level == (name == "sponza_60k")  # the atrium's columns and arches are instanced primitives
+    assert two_level == want_two_level  # (the atrium's columns and arches are instanced primitives)
     if two_level:
         assert depth <= info.max_depth and info.instance_node_count > 0 and info.instance_ref_count == 42
         assert info.stored_triangle_count < 0.6 * info.triangle_count  # every instanced primitive is stored once
@@ -202,7 +218,7 @@ def test_traversal_step_counts_match_oracle_on_same_bvh(halart, oracle):
         try:
             osc = oracle.OracleScene(s)
         finally:
-            oracle.set_instancing(True)
+            oracle.set_instancing(False)
         rays = osc.camera_rays(320, 180, 0)
         nodes, tris = r.download_bvh()
         refs = r.download_instance_refs()
@@ -447,12 +463,16 @@ def test_refit_after_material_edit(halart, oracle):
     r.close()
 
 
-def test_refit_after_vertex_deformation(halart, oracle):
-    """hala_rt_update_vertices + refit: a sheet of the atrium is rippled in place; the refitted tree must
-    bound the new triangles, and rays / a small render must match the oracle built from the deformed scene"""
+@pytest.mark.parametrize("mesh,instancing", [(3, None), (3, True), (0, True)])
+def test_refit_after_vertex_deformation(halart, oracle, request, mesh, instancing):
+    """hala_rt_update_vertices + refit: a mesh of the atrium is rippled in place — the first drape (mesh 3: referenced
+    once) or the first column mesh (mesh 0: 14 instances; in a two-level tree its ONE object-space tree is refitted and all instances
+    follow); the refitted tree must bound the new triangles, and rays / a small render must match the oracle built from the deformed scene"""
     s = scenes.sponza_class(target_triangles=20_000)
-    r = make_renderer(halart, s, 24, 16)
-    mesh = 3  # the first drape (scenes.sponza_class: columns 0-1, arch 2, drapes 3..)
+    oracle.set_instancing(bool(instancing))
+    request.addfinalizer(lambda: oracle.set_instancing(False))
+    r = make_renderer(halart, s, 24, 16, build=dict(instancing=instancing))
+    assert (r.bvh_info().instance_ref_count > 0) == bool(instancing)
     v = s.meshes[mesh].primitives[0].vertices.copy()
     pos = v["position"]
     pos[:, 2] += (0.35 * np.sin(3.0 * pos[:, 0] + 1.7 * pos[:, 1])).astype(f32)
@@ -483,11 +503,12 @@ def test_ploc_drivers_build_the_same_tree(halart, oracle):
     trees = []
     # builder "ploc": the fast large-scene build (the default at this size is the SAH one)
     for tail, look, collapse_look in ((1, 6, 4), (2, 1, 1), (1, 1, 3), (2, 7, 9)):
-        r = make_renderer(halart, s, 16, 16, build=dict(builder="ploc", ploc_tail=tail, ploc_look_every=look, collapse_look_every=collapse_look))
+        r = make_renderer(halart, s, 16, 16, build=dict(builder="ploc", ploc_tail=tail, ploc_look_every=look, collapse_look_every=collapse_look, instancing=True))
         trees.append(r.download_bvh())
         info = r.bvh_info()
         if len(trees) == 1:
-            rc, _, two_level = validate_tree(oracle, oracle.OracleScene(s), r)  # (a two-level tree: every tree of it is built by PLOC)
+            with two_level_trees(oracle):
+                rc, _, two_level = validate_tree(oracle, oracle.OracleScene(s), r)  # (a two-level tree: every tree of it is built by PLOC)
             assert rc == 0 and two_level
         r.close()
     assert info.triangle_count >= 4096
@@ -500,11 +521,7 @@ def test_builders_differ_in_trees_not_in_results(halart, oracle):
     structural check, is rebuilt byte for byte, gives the oracle's hits (the oracle traverses its OWN tree) and the oracle's step counts
     on that very tree; the SAH tree is the one with the fewest node visits per ray"""
     s = scenes.sponza_class(target_triangles=60_000, disney=False)
-    oracle.set_instancing(False)  # one tree over all 60 k triangles (instancing off on both sides): the builders are compared on it
-    try:
-        osc = oracle.OracleScene(s)
-    finally:
-        oracle.set_instancing(True)
+    osc = oracle.OracleScene(s)  # one tree over all 60 k triangles (every instance flattened): the builders are compared on it
     mn, mx = osc.bounds()
     rays = np.concatenate([random_rays(30000, mn, mx, 23), osc.camera_rays(160, 90, 0)])
     want = osc.trace(rays, 0)
@@ -930,9 +947,7 @@ def test_full_size_scene_bvh_and_rays(halart, oracle):
     info = r.bvh_info()
     assert info.triangle_count == osc.triangle_count > 900_000
     rc, depth, two_level = validate_tree(oracle, osc, r)
-    assert rc == 0 and two_level and depth <= info.max_depth
-    # RENDER_SPEC 4.5: the 28 columns and 14 arches are instances of three primitives, stored once
-    assert info.instance_ref_count == 42 and info.stored_triangle_count < 0.45 * info.triangle_count
+    assert rc == 0 and not two_level and depth == info.max_depth  # automatic: a scene of 1 M triangles is flattened
     rays = osc.camera_rays(640, 360, 0)
     got = r.trace_rays_host(rays, 0)
     sub = slice(0, None, len(rays) // 1500)
@@ -1156,8 +1171,8 @@ def test_render_scattering_medium_bit_exact(halart, oracle, boundary):
     r.close()
 
 
-@pytest.mark.parametrize("config,fusion", [(3, 1), (4, 1), (4, 0)])
-def test_large_configs_full_resolution_bit_exact(halart, oracle, config, fusion):
+@pytest.mark.parametrize("config,fusion,instancing", [(3, 1, None), (4, 1, None), (4, 0, None), (4, 1, True)])
+def test_large_configs_full_resolution_bit_exact(halart, oracle, config, fusion, instancing):
     """BASELINE configs[2] (82 k-triangle Disney blob under a 2048x1024 sun/sky map, MIS; 16 spp) and configs[3] (1 M-triangle atrium:
     24 materials incl. glass and clearcoat, 18 mip-mapped textures, quad lights + env; 4 spp) at 1920x1080 and their own sample
     counts, pixel for pixel against the oracle ON ITS OWN TREE (binned-SAH BVH2: nothing of the product's builder is shared), plus
@@ -1170,11 +1185,15 @@ def test_large_configs_full_resolution_bit_exact(halart, oracle, config, fusion)
         s = scenes.sponza_class(target_triangles=1_000_000)
         scenes.attach_textures(s, sets=6, size=1024)
         env, spp = scenes.sky_sun_envmap(1024, 512, sun_gain=50.0), 4
-    r = make_renderer(halart, s, 1920, 1080, env=env)
+    # instancing True: the atrium as a two-level tree (RENDER_SPEC 4.5: its 28 columns and 14 arches are instances of three primitives),
+    # the oracle told the same; None: the automatic choice (flattened at this size)
+    with (two_level_trees(oracle) if instancing else contextlib.nullcontext()) as build:
+        r = make_renderer(halart, s, 1920, 1080, env=env, build=build)
+        osc = oracle.OracleScene(s, envmap=env)  # its own tree (RENDER_SPEC 4.1b pads the boxes: results do not depend on the tree)
+    assert (r.bvh_info().instance_ref_count > 0) == bool(instancing)
     r.set_pass_fusion(fusion)
     r.update_batch(spp)
     r.render()
-    osc = oracle.OracleScene(s, envmap=env)  # its own tree (RENDER_SPEC 4.1b pads the boxes: results do not depend on the tree)
     imgs, st = osc.render(1920, 1080, frames=spp)
     assert_images_equal(r, imgs)
     stg = r.statistics()
@@ -1183,11 +1202,15 @@ def test_large_configs_full_resolution_bit_exact(halart, oracle, config, fusion)
     r.close()
 
 
-def render_random_scene_both(halart, oracle, seed, big=False):
-    """one random scene (tests/random_scenes.py) on the GPU and in the oracle -> number of differing pixels per image"""
+def render_random_scene_both(halart, oracle, seed, big=False, instances=False):
+    """one random scene (tests/random_scenes.py) on the GPU and in the oracle -> number of differing pixels per image.  instances: with
+    instanced objects and a two-level tree (RENDER_SPEC 4.5) on both sides"""
     from random_scenes import random_scene
-    s, env, kw = random_scene(seed, big)
+    s, env, kw = random_scene(seed, big, instances)
     r = halart.HalaRenderer("random", kw["width"], kw["height"], kw["max_depth"], kw["rr_depth"], *kw["tonemap"], 0)
+    if instances:
+        r.set_build_options(instancing=True)
+        oracle.set_instancing(True)
     if env is not None:
         r.set_envmap(env, kw["env_rotation"])
         r.set_env_intensity(kw["env_intensity"])
@@ -1235,6 +1258,7 @@ def render_random_scene_both(halart, oracle, seed, big=False):
                                  exposure=kw["exposure"])
         bad = [b + int(np.any(r.read_image(k) != imgs2[k], axis=-1).sum()) for k, b in enumerate(bad)]
     r.close()
+    oracle.set_instancing(False)
     return bad, rays_ok, lit
 
 
@@ -1245,6 +1269,18 @@ def test_random_scenes_bit_exact(halart, oracle, seed):
     bad, rays_ok, lit = render_random_scene_both(halart, oracle, seed, big=seed % 6 == 5)
     assert bad == [0, 0, 0, 0] and rays_ok, (seed, bad, rays_ok)
     assert lit >= 0.0
+
+
+@pytest.mark.parametrize("seed", [100, 101, 102, 103, 104, 105, 106, 107])
+def test_random_scenes_with_instances_two_level_bit_exact(halart, oracle, seed):
+    """the same with objects referenced by several nodes and a two-level tree on both sides (RENDER_SPEC 4.5): translucent / invisible /
+    medium-bounding / textured / emissive materials on instanced primitives, mirrored and nested transforms, and (every third seed) a
+    refit after a moved node, a replaced material and a deformed mesh"""
+    try:
+        bad, rays_ok, lit = render_random_scene_both(halart, oracle, seed, big=seed % 4 == 1, instances=True)
+    finally:
+        oracle.set_instancing(False)
+    assert bad == [0, 0, 0, 0] and rays_ok, (seed, bad, rays_ok)
 
 
 # ---- two-level trees (RENDER_SPEC 4.5) ---------------------------------------------------------------------------------------------
@@ -1276,8 +1312,9 @@ def test_two_level_instances_with_general_transforms(halart, oracle):
                             (shear, None),
                             (_xf((-20, 150, 200), (0.5, 0.5, 0.5), ry=1.1), 6),     # child of the shearing node
                             (_xf((100, 400, 300), (0.7, 0.0, 0.7)), None)])        # flat: not invertible
-    r = make_renderer(halart, s, 64, 48)
-    osc = oracle.OracleScene(s)
+    with two_level_trees(oracle) as build:
+        r = make_renderer(halart, s, 64, 48, build=build)
+        osc = oracle.OracleScene(s)
     info = r.bvh_info()
     assert info.instance_ref_count == 5 and info.instance_node_count >= 1  # the original + 4 invertible copies; the flat one is flattened
     assert info.stored_triangle_count == info.triangle_count - 4 * 10 and info.lds_node_count == 0
@@ -1300,13 +1337,9 @@ def test_two_level_instances_with_general_transforms(halart, oracle):
     assert_images_equal(r, imgs)
     stg = r.statistics()
     assert (stg.rays_closest_total, stg.rays_shadow_total) == (st.rays_closest, st.rays_shadow)
-    # everything flattened (hala_rt_build_options::instancing = 1; the oracle told the same): the other arithmetic, the same picture to rounding
-    r2 = make_renderer(halart, s, 64, 48, build=dict(instancing=False))
-    oracle.set_instancing(False)
-    try:
-        flat = oracle.OracleScene(s)
-    finally:
-        oracle.set_instancing(True)
+    # everything flattened (the default at this size): the other arithmetic, the same picture to rounding
+    r2 = make_renderer(halart, s, 64, 48)
+    flat = oracle.OracleScene(s)
     assert r2.bvh_info().instance_ref_count == 0
     r2.update_batch(3); r2.render()
     fimgs, _ = flat.render(64, 48, frames=3)
@@ -1315,12 +1348,14 @@ def test_two_level_instances_with_general_transforms(halart, oracle):
     r.close(); r2.close()
 
 
-def test_two_level_refit_of_a_moved_instance_touches_only_the_instance_levels(halart, oracle):
+def test_two_level_refit_of_a_moved_instance_touches_only_the_instance_levels(halart, oracle, request):
     """hala_rt_update_node_transform on a node of an INSTANCED primitive + refit: the primitives' trees and all triangles stay byte for
     byte, only the instance levels (the first instance_node_count nodes) and the instance references are rebuilt; a node of a primitive
     that is referenced once is flattened geometry: moving it refits the world tree.  Both times the frame equals the oracle's."""
     s = scenes.sponza_class(target_triangles=60_000)
-    r = make_renderer(halart, s, 48, 27)
+    oracle.set_instancing(True)
+    request.addfinalizer(lambda: oracle.set_instancing(False))
+    r = make_renderer(halart, s, 48, 27, build=dict(instancing=True))
     info = r.bvh_info()
     T = info.instance_node_count
     assert T > 0
