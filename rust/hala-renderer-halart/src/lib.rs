@@ -55,6 +55,9 @@ pub mod sys {
   #[repr(C)] #[derive(Clone, Copy)] pub struct hala_hit { pub t: f32, pub u: f32, pub v: f32, pub prim: u32 }
   #[repr(C)] #[derive(Default)] pub struct hala_rt_info { pub width: u32, pub height: u32 }
 
+  /// hala_rt_build_options (include/halart.h): every field 0 = the default
+  #[repr(C)] #[derive(Default, Clone, Copy)]
+  pub struct hala_rt_build_options { pub builder: u32, pub ploc_tail: u32, pub ploc_look_every: u32, pub collapse_look_every: u32, pub instancing: u32, pub reserved: [u32; 3] }
   #[repr(C)] pub struct hala_scene { _private: [u8; 0] }
   #[repr(C)] pub struct hala_rtprog { _private: [u8; 0] }
   extern "C" {
@@ -111,6 +114,11 @@ pub mod sys {
     pub fn hala_rt_scatter_gathered_tiles_on_stream(r: *mut hala_rt_renderer, which: c_int, d_gathered: *const c_void, bytes: usize, hip_stream: *mut c_void) -> c_int;
     pub fn hala_rt_get_stream(r: *mut hala_rt_renderer, hip_stream: *mut *mut c_void) -> c_int;
     pub fn hala_rt_set_launch_timing_period(r: *mut hala_rt_renderer, period: u32) -> c_int;
+    pub fn hala_rt_set_pass_fusion(r: *mut hala_rt_renderer, mode: u32) -> c_int;
+    pub fn hala_rt_set_build_options(r: *mut hala_rt_renderer, options: *const hala_rt_build_options) -> c_int;
+    pub fn hala_rt_tile_allgather_begin_external(r: *mut hala_rt_renderer, aov_mask: u32) -> c_int;
+    pub fn hala_rt_get_exchange_buffers(r: *mut hala_rt_renderer, which: c_int, d_staged: *mut *mut c_void, staged_bytes: *mut usize,
+                                        d_receive: *mut *mut c_void, receive_bytes: *mut usize, hip_stream: *mut *mut c_void) -> c_int;
     // cpu::HalaScene::new inside the library (for hosts without the Rust `src/scene` module)
     pub fn hala_scene_load_gltf(path: *const c_char, out: *mut *mut hala_scene) -> c_int;
     pub fn hala_scene_get_desc(scene: *const hala_scene) -> *const hala_scene_desc;
@@ -231,6 +239,14 @@ impl HalaRenderer {
   }
   /// per-launch timing events on every `period`-th update (1: all, 0: none)
   pub fn set_launch_timing_period(&mut self, period: u32) -> Result<(), HalaRendererError> { check(unsafe { sys::hala_rt_set_launch_timing_period(self.h, period) }) }
+  /// 0: one launch per pass, 1 (default): fused launches except in timed updates, 2: always
+  pub fn set_pass_fusion(&mut self, mode: u32) -> Result<(), HalaRendererError> { check(unsafe { sys::hala_rt_set_pass_fusion(self.h, mode) }) }
+  /// How the next commit() builds the acceleration structure: builder 0 auto | 1 SAH | 2 PLOC | 3 LBVH; instancing 0 auto | 1 flattened |
+  /// 2 two-level (the BLAS / TLAS split of gpu_uploader.rs:782-815, :937-959)
+  pub fn set_build_options(&mut self, builder: u32, instancing: u32) -> Result<(), HalaRendererError> {
+    let o = sys::hala_rt_build_options { builder, instancing, ..Default::default() };
+    check(unsafe { sys::hala_rt_set_build_options(self.h, &o) })
+  }
   pub fn set_tile_shard(&mut self, rank: u32, world: u32, tile_size: u32) -> Result<(), HalaRendererError> { check(unsafe { sys::hala_rt_set_tile_shard(self.h, rank, world, tile_size) }) }
 }
 impl Drop for HalaRenderer { fn drop(&mut self) { unsafe { sys::hala_rt_destroy(self.h) } } }

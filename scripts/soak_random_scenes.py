@@ -14,10 +14,11 @@ from test_gpu_parity import render_random_scene_both  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--seeds", type=int, default=200)
 ap.add_argument("--first", type=int, default=100)
+ap.add_argument("--instances", action="store_true", help="objects referenced by several nodes + two-level trees on both sides (RENDER_SPEC 4.5)")
 a = ap.parse_args()
 failed, dark = [], 0
 for seed in range(a.first, a.first + a.seeds):
-    bad, rays_ok, lit = render_random_scene_both(H, O, seed, big=seed % 6 == 5)
+    bad, rays_ok, lit = render_random_scene_both(H, O, seed, big=seed % 6 == 5, instances=a.instances)
     dark += lit < 1e-4
     if bad != [0, 0, 0, 0] or not rays_ok:
         failed.append(seed)
