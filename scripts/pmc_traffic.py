@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""profiles/r02_traffic_config3.json from a scripts/pmc_collect.sh summary: HBM-side bytes per launch of the kernel bench.py's
-`roofline` prices (k_trace_batch<false, false, false> on configs[3]), with the guide's gfx950 correction, stamped with the hash
+"""profiles/r03_traffic_config3.json from a scripts/pmc_collect.sh summary: HBM-side bytes per launch of the kernel bench.py's
+`roofline` prices (the fused launch k_trace_shadow_then_batch<false, false, false> on configs[3]), with the guide's gfx950 correction, stamped with the hash
 of the sources it was collected from (bench.py quotes it only while that hash matches) and the commit label.
 usage: pmc_traffic.py <gpurun_out/pmc_dir> <out.json> <source label> [kernel prefix]"""
 import json
@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bench import source_hash  # noqa: E402
 
-prefix = sys.argv[4] if len(sys.argv) > 4 else "k_trace_batch<false, false, false, false>"
+prefix = sys.argv[4] if len(sys.argv) > 4 else "k_trace_shadow_then_batch<false, false, false>"
 d = json.load(open(sys.argv[1] + "/summary.json"))
 key = next(k for k in d if k.startswith(prefix))
 v = d[key]
@@ -19,7 +19,7 @@ m = lambda c: v[c]["mean_per_launch"]  # noqa: E731
 fetch_kb, write_kb = m("FETCH_SIZE"), m("WRITE_SIZE")
 out = {
     "kernel": "rt::" + key,
-    "workload": "scripts/pmc_run.py 4 (bench.py's configs[3]: 1 M-triangle atrium, 1920x1080, update_batch(4)); bounce-ray launches only (depth >= 1)",
+    "workload": "scripts/pmc_run.py 4 (bench.py's configs[3]: 1 M-triangle atrium, 1920x1080, update_batch(4)); the fused launches (both shadow passes of bounce d + the closest-hit pass of bounce d + 1), averaged over the five of a frame",
     "launches_averaged": v["FETCH_SIZE"]["launches"],
     "FETCH_SIZE_KB_per_launch": fetch_kb,
     "WRITE_SIZE_KB_per_launch": write_kb,

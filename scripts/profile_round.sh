@@ -3,7 +3,7 @@
 # (bench.py's headline) and configs[1], per-config timings.
 # usage (on the GPU box): HALART_COMMIT=<label> bash scripts/profile_round.sh <tag> [quick]
 set -u
-TAG=${1:-r02_x}
+TAG=${1:-r03_x}
 QUICK=${2:-}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/$TAG
