@@ -120,35 +120,27 @@ struct Doc {
 
 // ---- accessors ------------------------------------------------------------------------------------------------------
 struct Accessor { std::vector<double> v; int ncomp = 0; size_t count = 0; };
-Accessor read_accessor(const Doc& d, uint32_t idx) {
-  const auto& accs = arr(d.j, "accessors");
-  if (idx >= accs.size()) fail("Accessor index out of range.");
-  const JsonValue& a = accs[idx];
+int component_size(int ct) {
+  switch (ct) { case 5120: case 5121: return 1; case 5122: case 5123: return 2; case 5125: case 5126: return 4; default: fail("Unknown component type."); }
+  return 0;
+}
+// `count` elements of `ncomp` components of type `ct` from a buffer view (tightly packed unless the view has a stride and `strided`)
+void read_elements(const Doc& d, uint32_t bvi, size_t byte_offset, int ct, int ncomp, size_t count, bool normalized, bool strided, std::vector<double>* out) {
   const auto& views = arr(d.j, "bufferViews");
-  const uint32_t bvi = index_or_invalid(a, "bufferView");
-  if (bvi >= views.size()) fail("Accessor without a buffer view (sparse accessors are not supported).");
+  if (bvi >= views.size()) fail("Buffer view index out of range.");
   const JsonValue& bv = views[bvi];
   const uint32_t bi = index_or_invalid(bv, "buffer");
   if (bi >= d.buffers.size()) fail("Buffer index out of range.");
-  const int ct = (int)usize(a, "componentType", 0);
-  const JsonValue* ty = get(a, "type");
-  static const std::map<std::string, int> ncomp = {{"SCALAR", 1}, {"VEC2", 2}, {"VEC3", 3}, {"VEC4", 4}, {"MAT2", 4}, {"MAT3", 9}, {"MAT4", 16}};
-  if (!ty || !ncomp.count(ty->str)) fail("Unknown accessor type.");
-  int size = 0;
-  switch (ct) { case 5120: case 5121: size = 1; break; case 5122: case 5123: size = 2; break; case 5125: case 5126: size = 4; break; default: fail("Unknown component type."); }
-  Accessor out;
-  out.ncomp = ncomp.at(ty->str);
-  out.count = usize(a, "count", 0);
-  const size_t off = usize(bv, "byteOffset", 0) + usize(a, "byteOffset", 0);
-  size_t stride = usize(bv, "byteStride", 0);
-  if (stride == 0) stride = (size_t)size * out.ncomp;
+  const int size = component_size(ct);
+  const size_t off = usize(bv, "byteOffset", 0) + byte_offset;
+  size_t stride = strided ? usize(bv, "byteStride", 0) : 0;
+  if (stride == 0) stride = (size_t)size * ncomp;
   const std::vector<uint8_t>& buf = d.buffers[bi];
-  if (out.count && off + (out.count - 1) * stride + (size_t)size * out.ncomp > buf.size()) fail("Accessor reads past the end of its buffer.");
-  const JsonValue* nrm = get(a, "normalized");
-  const bool normalized = nrm && nrm->kind == JsonValue::Bool && nrm->b && ct != 5126;
-  out.v.resize(out.count * out.ncomp);
-  for (size_t i = 0; i < out.count; ++i)
-    for (int c = 0; c < out.ncomp; ++c) {
+  if (count && (off > buf.size() || (count - 1) > (buf.size() - off) / stride || off + (count - 1) * stride + (size_t)size * ncomp > buf.size()))
+    fail("Accessor reads past the end of its buffer.");
+  out->resize(count * ncomp);
+  for (size_t i = 0; i < count; ++i)
+    for (int c = 0; c < ncomp; ++c) {
       const uint8_t* p = buf.data() + off + i * stride + (size_t)c * size;
       double x = 0.0, mx = 1.0;
       switch (ct) {
@@ -159,8 +151,46 @@ Accessor read_accessor(const Doc& d, uint32_t idx) {
         case 5125: { uint32_t t; memcpy(&t, p, 4); x = t; mx = 4294967295.0; break; }
         default: { float t; memcpy(&t, p, 4); x = t; break; }
       }
-      out.v[i * out.ncomp + c] = normalized ? (double)((float)x / (float)mx) : x;
+      (*out)[i * ncomp + c] = normalized ? (double)((float)x / (float)mx) : x;
     }
+}
+Accessor read_accessor(const Doc& d, uint32_t idx) {
+  const auto& accs = arr(d.j, "accessors");
+  if (idx >= accs.size()) fail("Accessor index out of range.");
+  const JsonValue& a = accs[idx];
+  const int ct = (int)usize(a, "componentType", 0);
+  const JsonValue* ty = get(a, "type");
+  static const std::map<std::string, int> ncomp = {{"SCALAR", 1}, {"VEC2", 2}, {"VEC3", 3}, {"VEC4", 4}, {"MAT2", 4}, {"MAT3", 9}, {"MAT4", 16}};
+  if (!ty || !ncomp.count(ty->str)) fail("Unknown accessor type.");
+  (void)component_size(ct);
+  Accessor out;
+  out.ncomp = ncomp.at(ty->str);
+  out.count = usize(a, "count", 0);
+  if (out.count > (size_t)1 << 31) fail("Accessor count is out of range.");
+  const JsonValue* nrm = get(a, "normalized");
+  const bool normalized = nrm && nrm->kind == JsonValue::Bool && nrm->b && ct != 5126;
+  const JsonValue* sparse = get(a, "sparse");
+  const uint32_t bvi = index_or_invalid(a, "bufferView");
+  if (bvi != HALA_INVALID_INDEX) read_elements(d, bvi, usize(a, "byteOffset", 0), ct, out.ncomp, out.count, normalized, true, &out.v);
+  else if (sparse) out.v.assign(out.count * out.ncomp, 0.0);  // glTF 2.0 3.6.2.3: no buffer view -> zeros, then the sparse substitution
+  else fail("Accessor without a buffer view.");
+  if (sparse) {  // `count` elements replaced: their indices (strictly increasing) and their values, both tightly packed
+    const size_t n = usize(*sparse, "count", 0);
+    const JsonValue* si = get(*sparse, "indices");
+    const JsonValue* sv = get(*sparse, "values");
+    if (!si || !sv || n == 0 || n > out.count) fail("Malformed sparse accessor.");
+    const int ict = (int)usize(*si, "componentType", 0);
+    if (ict != 5121 && ict != 5123 && ict != 5125) fail("Sparse accessor indices must be unsigned.");
+    std::vector<double> ind, val;
+    read_elements(d, index_or_invalid(*si, "bufferView"), usize(*si, "byteOffset", 0), ict, 1, n, false, false, &ind);
+    read_elements(d, index_or_invalid(*sv, "bufferView"), usize(*sv, "byteOffset", 0), ct, out.ncomp, n, normalized, false, &val);
+    double prev = -1.0;
+    for (size_t k = 0; k < n; ++k) {
+      if (!(ind[k] > prev) || ind[k] >= (double)out.count) fail("Sparse accessor indices must increase and stay inside the accessor.");
+      prev = ind[k];
+      for (int c = 0; c < out.ncomp; ++c) out.v[(size_t)ind[k] * out.ncomp + c] = val[k * out.ncomp + c];
+    }
+  }
   return out;
 }
 

@@ -49,19 +49,32 @@ class _Doc:
         with open(os.path.join(self.dir, uri), "rb") as f:
             return f.read()
 
+    def _elements(self, view, byte_offset, dt, nc, count, strided):
+        bv = self.j["bufferViews"][view]
+        off = bv.get("byteOffset", 0) + byte_offset
+        stride = (bv.get("byteStride", 0) if strided else 0) or dt.itemsize * nc
+        buf = self.buffers[bv["buffer"]]
+        if stride == dt.itemsize * nc:
+            return np.frombuffer(buf, dtype=dt, count=count * nc, offset=off).reshape(count, nc)
+        return np.stack([np.frombuffer(buf, dtype=dt, count=nc, offset=off + i * stride) for i in range(count)])
+
     def accessor(self, idx):
         acc = self.j["accessors"][idx]
-        bv = self.j["bufferViews"][acc["bufferView"]]
         dt = np.dtype(_COMPONENT[acc["componentType"]])
         nc = _NCOMP[acc["type"]]
-        off = bv.get("byteOffset", 0) + acc.get("byteOffset", 0)
-        stride = bv.get("byteStride", 0) or dt.itemsize * nc
-        buf = self.buffers[bv["buffer"]]
         count = acc["count"]
-        if stride == dt.itemsize * nc:
-            arr = np.frombuffer(buf, dtype=dt, count=count * nc, offset=off).reshape(count, nc)
+        if "bufferView" in acc:
+            arr = self._elements(acc["bufferView"], acc.get("byteOffset", 0), dt, nc, count, True)
+        elif "sparse" in acc:
+            arr = np.zeros((count, nc), dtype=dt)  # glTF 2.0 3.6.2.3: no buffer view -> zeros, then the sparse substitution
         else:
-            arr = np.stack([np.frombuffer(buf, dtype=dt, count=nc, offset=off + i * stride) for i in range(count)])
+            raise ValueError("Accessor without a buffer view.")
+        if "sparse" in acc:
+            sp = acc["sparse"]
+            ind = self._elements(sp["indices"]["bufferView"], sp["indices"].get("byteOffset", 0), np.dtype(_COMPONENT[sp["indices"]["componentType"]]), 1, sp["count"], False)[:, 0]
+            val = self._elements(sp["values"]["bufferView"], sp["values"].get("byteOffset", 0), dt, nc, sp["count"], False)
+            arr = np.array(arr)
+            arr[ind.astype(np.int64)] = val
         if acc.get("normalized") and dt != np.float32:
             arr = arr.astype(np.float32) / float(np.iinfo(dt).max)
         return arr

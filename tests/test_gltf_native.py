@@ -286,3 +286,54 @@ def test_malformed_inputs_are_refused_not_read_out_of_bounds(tmp_path):
             load_with(lambda d: d["accessors"][0].__setitem__(key, val), f"acc_{key}_{abs(hash(str(val))) % 997}.gltf")
     with pytest.raises(H.HalaRendererError, match="not a non-negative integer"):
         load_with(lambda d: d["nodes"][0].__setitem__("children", [-1]), "child_neg.gltf")
+
+
+def test_sparse_accessors(tmp_path):
+    """glTF 2.0 3.6.2.3: an accessor's `sparse` block replaces some elements of its buffer view — or of zeros when it has no view.  The
+    Cornell box is rewritten so that the POSITION accessor of its first primitive is zeros + a sparse substitution of EVERY vertex, and the
+    NORMAL accessor keeps its view with three elements overridden: both loaders must give the same scene, equal to the dense one but for the
+    three edited normals"""
+    import base64
+    import struct
+    dense = tmp_path / "dense.gltf"
+    write_gltf(scenes.cornell_box(), str(dense))
+    j = json.load(open(dense))
+    prim = j["meshes"][0]["primitives"][0]
+    pos_acc, nrm_acc = j["accessors"][prim["attributes"]["POSITION"]], j["accessors"][prim["attributes"]["NORMAL"]]
+    doc = H.gltf_loader._Doc(str(dense)) if hasattr(H.gltf_loader, "_Doc") else None
+    positions = np.array(doc.accessor(prim["attributes"]["POSITION"]), dtype=np.float32)
+    n = positions.shape[0]
+    idx16 = np.arange(n, dtype=np.uint16)
+    new_normals = np.array([[0, 1, 0], [1, 0, 0], [0, 0, -1]], dtype=np.float32)
+    nrm_idx = np.array([0, 2, n - 1], dtype=np.uint8)
+    blob = idx16.tobytes()
+    blob += b"\0" * (-len(blob) % 4)
+    off_pos = len(blob); blob += positions.tobytes()
+    off_ni = len(blob); blob += nrm_idx.tobytes(); blob += b"\0" * (-len(blob) % 4)
+    off_nv = len(blob); blob += new_normals.tobytes()
+    j["buffers"].append({"byteLength": len(blob), "uri": "data:application/octet-stream;base64," + base64.b64encode(blob).decode()})
+    b = len(j["buffers"]) - 1
+    v0 = len(j["bufferViews"])
+    j["bufferViews"] += [{"buffer": b, "byteOffset": 0, "byteLength": n * 2}, {"buffer": b, "byteOffset": off_pos, "byteLength": n * 12},
+                         {"buffer": b, "byteOffset": off_ni, "byteLength": 3}, {"buffer": b, "byteOffset": off_nv, "byteLength": 36}]
+    del pos_acc["bufferView"]
+    pos_acc.pop("byteOffset", None)
+    pos_acc["sparse"] = {"count": n, "indices": {"bufferView": v0, "componentType": 5123}, "values": {"bufferView": v0 + 1}}
+    nrm_acc["sparse"] = {"count": 3, "indices": {"bufferView": v0 + 2, "componentType": 5121}, "values": {"bufferView": v0 + 3}}
+    sparse = tmp_path / "sparse.gltf"
+    json.dump(j, open(sparse, "w"))
+    py = H.HalaScene.new(str(sparse))
+    nat = NativeScene(str(sparse))
+    assert_same_desc(nat.desc, py.to_desc().desc)
+    ref = H.HalaScene.new(str(dense))
+    got, want = py.meshes[0].primitives[0].vertices, ref.meshes[0].primitives[0].vertices
+    assert got["position"].tobytes() == want["position"].tobytes()
+    assert np.array_equal(got["normal"][[0, 2, n - 1]], new_normals)
+    keep = np.ones(n, dtype=bool); keep[[0, 2, n - 1]] = False
+    assert got["normal"][keep].tobytes() == want["normal"][keep].tobytes()
+    nat.close()
+    # a sparse block that points outside the accessor is refused by the library, not read
+    j["accessors"][prim["attributes"]["NORMAL"]]["sparse"]["count"] = n + 5
+    json.dump(j, open(tmp_path / "bad.gltf", "w"))
+    with pytest.raises(Exception):
+        NativeScene(str(tmp_path / "bad.gltf"))
