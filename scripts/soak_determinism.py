@@ -18,12 +18,15 @@ from hala_renderer_amd import workloads  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--frames", type=int, default=40)
 ap.add_argument("--config", type=int, default=3)
+ap.add_argument("--two-level", action="store_true", help="hala_rt_build_options::instancing = 2 (RENDER_SPEC 4.5)")
 args = ap.parse_args()
 cfg = workloads.baseline_config(args.config)
 r = H.HalaRenderer("soak", cfg["width"], cfg["height"], cfg["max_depth"], cfg["rr_depth"], False, False, False, 0)
 if cfg["env"] is not None:
     r.set_envmap(cfg["env"], 0.0)
 r.set_scene(cfg["scene"])
+if args.two_level:
+    r.set_build_options(instancing=True)
 r.commit()
 r.set_launch_timing_period(3)
 hashes = {}
