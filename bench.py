@@ -70,11 +70,13 @@ def cpu_baseline(cfg):
 class Run:
     """one renderer on one workload; measure() times K frames bracketed by barrier + synchronize on both sides"""
 
-    def __init__(self, H, cfg, local_rank, rank, world, dist, torch):
+    def __init__(self, H, cfg, local_rank, rank, world, dist, torch, instancing=None):
         self.cfg, self.dist, self.torch, self.world = cfg, dist, torch, world
         self.r = H.HalaRenderer("bench", cfg["width"], cfg["height"], cfg["max_depth"], cfg["rr_depth"], False, False, False, 0,
                                 device_ordinal=local_rank)
         r = self.r
+        if instancing is not None:  # None: the library's automatic choice (one tree over all triangles, flattened, at this size)
+            r.set_build_options(instancing=instancing)
         if world > 1:
             r.set_tile_shard(rank, world, TILE)
         if cfg["env"] is not None:
@@ -307,6 +309,7 @@ def main():
     _, u0, u1 = run.measure(2, 0, timing_period=1, fusion=0)
     counts = run.count()
     info = run.r.bvh_info()
+    tree_bytes_flat = info.tree_bytes
     staged = info.lds_node_count > 0
     kr = kernel_report((s0, s1), (u0, u1), counts, staged, args.steps)
 
@@ -382,6 +385,20 @@ def main():
             secondary["configs4_on_1_gpu"] = {"workload": c4["name"] + " on ONE GPU (no shard, no collective)", "steps": 3,
                                               "value": round((a1.rays_total - a0.rays_total) / d4 / 1e6, 2), "unit": "Mrays/s", "ms_per_frame": round(d4 / 3 * 1e3, 3)}
             r4.close()
+            # configs[3] as a two-level tree (hala_rt_build_options::instancing = 2: the reference's BLAS / TLAS split, RENDER_SPEC 4.5)
+            info_flat = None
+            try:
+                rt2 = Run(H, cfg, local_rank, 0, 1, None, torch, instancing=True)
+                d2, t0_, t1_ = rt2.measure(6, 2, timing_period=0)
+                i2 = rt2.r.bvh_info()
+                secondary["configs3_two_level"] = {"workload": cfg["name"] + " — two-level tree: every instanced primitive stored once, instance levels on top",
+                                                   "steps": 6, "value": round((t1_.rays_total - t0_.rays_total) / d2 / 1e6, 2), "unit": "Mrays/s", "ms_per_frame": round(d2 / 6 * 1e3, 3),
+                                                   "stored_triangles": int(i2.stored_triangle_count), "instance_refs": int(i2.instance_ref_count),
+                                                   "tree_bytes": int(i2.tree_bytes), "tree_bytes_flattened": int(tree_bytes_flat),
+                                                   "note": "images of the two forms agree to rounding, each is held bit for bit to the oracle following the same rule (tests/test_gpu_parity.py)"}
+                rt2.close()
+            except Exception as e:  # noqa: BLE001
+                secondary["configs3_two_level"] = {"error": str(e)}
             # configs[1]: the 32-triangle Cornell box whose BVH lives in LDS (round 1's headline)
             c1 = workloads.baseline_config(1)
             r1 = Run(H, c1, local_rank, 0, 1, None, torch)
