@@ -50,7 +50,7 @@ constexpr uint32_t kLeafRef = 0x80000000u;
 // InstRef table; the traversal moves the ray into the instance's object space and goes on at the root of its primitive's own tree,
 // whose triangles are stored ONCE however many instances reference the primitive.
 constexpr uint32_t kInstLeafTag = 0xF0000000u;
-constexpr uint32_t kExitRef = 0xfffffffeu;  // stack sentinel: "leaving the instance" (it and the four entries below it hold the world-space ray and 1 / d)
+constexpr uint32_t kExitRef = 0xfffffffeu;  // stack sentinel: "leaving the instance" (the three entries below it hold the world-space ray)
 #if defined(__HIPCC__)
 __host__ __device__
 #endif

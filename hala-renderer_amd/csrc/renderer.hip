@@ -560,10 +560,10 @@ int configure_traversal(hala_rt_renderer* r) {
         uint32_t inner = 0, deepest = 0;
         for (uint32_t ref : nodes[i].ref) {
           if (ref == kAbsent) continue;
-          if (is_inst_leaf(ref)) {  // RENDER_SPEC 4.5: the parked world-space ray and the exit mark (5 entries) wait below the instance's own entries
+          if (is_inst_leaf(ref)) {  // RENDER_SPEC 4.5: the world-space ray (3 entries) and the exit mark wait below the instance's own entries
             const uint32_t k = ref & 0x0fffffffu;
             ++inner;
-            if (k < r->inst_refs.size() && r->inst_refs[k].root < need.size()) deepest = std::max(deepest, 5u + need[r->inst_refs[k].root]);
+            if (k < r->inst_refs.size() && r->inst_refs[k].root < need.size()) deepest = std::max(deepest, 4u + need[r->inst_refs[k].root]);
             continue;
           }
           if (ref & kLeafRef) continue;
@@ -694,7 +694,7 @@ int build_instance_levels(hala_rt_renderer* r) {
     const float pad = (amax + ext) * 1.9073486328125e-06f * 2.0f;
     for (int k = 0; k < 3; ++k) { it.mn[k] = wmn[k] - pad; it.mx[k] = wmx[k] + pad; smin[k] = std::min(smin[k], wmn[k]); smax[k] = std::max(smax[k], wmx[k]); }
     it.ref = kInstLeafTag | (uint32_t)r->inst_refs.size();
-    it.need = 5u + bl.b.stack_need;  // the world-space ray, its reciprocal direction and the exit mark (5 entries) wait below the instance's own entries
+    it.need = 4u + bl.b.stack_need;  // the world-space ray (3 entries) and the exit mark wait below the instance's own entries
     deepest = std::max(deepest, bl.b.max_depth);
     if (r->inst_refs.size() >= 0x0ffffff0u) RT_FAIL("Too many instances.");
     r->inst_refs.push_back(ref);
