@@ -67,6 +67,29 @@ for k in range(600):
         for key in p[:-1]: o = o[key]
         o[p[-1]] = hostile[rs.randint(len(hostile))]
     json.dump(d, open(os.path.join(out, "gltf", f"s{k:04d}.gltf"), "w"))
+# sparse accessors (glTF 2.0 3.6.2.3): the POSITION accessor of the first primitive as zeros + a substitution of 5 vertices, the NORMAL accessor with two
+# elements overridden; then hostile values in every numeric leaf (counts, offsets, component types of the sparse blocks among them)
+sd = copy.deepcopy(doc)
+prim0 = sd["meshes"][0]["primitives"][0]
+pa, na = sd["accessors"][prim0["attributes"]["POSITION"]], sd["accessors"][prim0["attributes"]["NORMAL"]]
+blob = np.array([0, 1, 2, 3, 5], dtype=np.uint16).tobytes() + b"\0\0" + rs.rand(5, 3).astype(np.float32).tobytes() + bytes([0, 2, 0, 0]) + rs.rand(2, 3).astype(np.float32).tobytes()
+sd["buffers"].append({"byteLength": len(blob), "uri": "data:application/octet-stream;base64," + base64.b64encode(blob).decode()})
+bi, v0 = len(sd["buffers"]) - 1, len(sd["bufferViews"])
+sd["bufferViews"] += [{"buffer": bi, "byteOffset": 0, "byteLength": 10}, {"buffer": bi, "byteOffset": 12, "byteLength": 60},
+                      {"buffer": bi, "byteOffset": 72, "byteLength": 2}, {"buffer": bi, "byteOffset": 76, "byteLength": 24}]
+pa.pop("bufferView", None); pa.pop("byteOffset", None)
+pa["sparse"] = {"count": 5, "indices": {"bufferView": v0, "componentType": 5123}, "values": {"bufferView": v0 + 1}}
+na["sparse"] = {"count": 2, "indices": {"bufferView": v0 + 2, "componentType": 5121}, "values": {"bufferView": v0 + 3}}
+json.dump(sd, open(os.path.join(out, "gltf", "sparse_base.gltf"), "w"))
+snum = [p for p, v in leaves(sd) if isinstance(v, (int, float)) and not isinstance(v, bool)]
+sparse_first = [p for p in snum if "sparse" in p] * 6 + snum  # the sparse blocks' own numbers six times as often
+for k in range(400):
+    d = copy.deepcopy(sd)
+    for _ in range(rs.randint(1, 3)):
+        p = sparse_first[rs.randint(len(sparse_first))]; o = d
+        for key in p[:-1]: o = o[key]
+        o[p[-1]] = hostile[rs.randint(len(hostile))]
+    json.dump(d, open(os.path.join(out, "gltf", f"p{k:04d}.gltf"), "w"))
 n = 0
 for mode, size, ch in (("RGB", (17, 9), 3), ("RGBA", (16, 16), 4), ("L", (5, 7), 1), ("LA", (8, 3), 2), ("P", (12, 12), 1), ("I;16", (6, 6), 1)):
     arr = rs.randint(0, 256, (size[1], size[0], ch)).astype(np.uint8)

@@ -8,7 +8,7 @@ W=${1:-/tmp/halart_fuzz}
 mkdir -p $W
 C=$ROOT/hala-renderer_amd/csrc
 g++ -O1 -g -std=c++17 -fsanitize=address,undefined -fno-sanitize-recover=undefined -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -I$C \
-    $ROOT/scripts/fuzz/harness.cpp $C/gltf_loader.cpp $C/jpeg_decode.cpp $C/host_util.cpp -L/opt/rocm/lib -lamdhip64 -lrocprofiler-sdk-roctx -lz \
+    $ROOT/scripts/fuzz/harness.cpp $C/gltf_loader.cpp $C/jpeg_decode.cpp $C/host_util.cpp -L/opt/rocm/lib -lamdhip64 -lz -ldl \
     -Wl,-rpath,/opt/rocm/lib -o $W/harness
 python3 $ROOT/scripts/fuzz/make_corpus.py $W/corpus 2>/dev/null
 $W/harness jpeg $W/corpus/jpeg/*.jpg
