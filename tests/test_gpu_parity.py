@@ -1406,3 +1406,54 @@ def test_two_level_tree_stores_instanced_primitives_once(halart):
         r.close()
     assert sizes[False][1] == sizes[False][2] == sizes[True][2] > 900_000
     assert sizes[True][1] < 0.45 * sizes[True][2] and sizes[True][0] < 0.45 * sizes[False][0], sizes
+
+
+def test_two_level_sharded_and_reclassified_on_refit(halart, oracle, request):
+    """two-level trees under a tile shard (three emulated ranks; the gathered frame ≡ the oracle's) and through a refit that changes WHICH
+    instances are instanced: a node's transform is squashed flat (determinant 0 → that instance is flattened: the trees are rebuilt), then
+    made invertible again"""
+    import torch
+    oracle.set_instancing(True)
+    request.addfinalizer(lambda: oracle.set_instancing(False))
+    s = _instanced_cornell([(_xf((250, 330, 230), (0.6, 1.4, 0.5), ry=0.7), None), (_xf((520, 60, 90), (-0.8, 0.9, 0.7), ry=-0.4), None)])
+    w, h, world, ts = 96, 64, 3, 16
+    want, _ = oracle.OracleScene(s).render(w, h, frames=2)
+    parts, last = [], None
+    for rank in range(world):
+        r = halart.HalaRenderer("shard2", w, h, 5, 3, False, False, False, 0)
+        r.set_build_options(instancing=True)
+        r.set_tile_shard(rank, world, ts)
+        r.set_scene(s); r.commit()
+        assert r.bvh_info().instance_ref_count == 3
+        r.update_batch(2); r.render(); r.wait_idle()
+        ptr, nbytes = r.tile_buffer(0)
+        parts.append(torch.as_tensor(halart.dist._DeviceView(ptr, nbytes // 4), device="cuda:0").clone())
+        if last is not None:
+            last.close()
+        last = r
+    gathered = torch.cat(parts).contiguous()
+    last.scatter_gathered_tiles(0, gathered.data_ptr(), gathered.numel() * 4)
+    assert last.read_image(0).tobytes() == want[0].tobytes()
+    last.close()
+    # reclassification through refit
+    r = make_renderer(halart, s, 64, 48, build=dict(instancing=True))
+    node = len(s.nodes) - 1
+    flat = _xf((520, 60, 90), (0.8, 0.0, 0.7))
+    r.update_node_transform(node, flat)
+    r.refit()
+    s.nodes[node].local_transform = flat
+    osc = oracle.OracleScene(s)
+    assert r.bvh_info().instance_ref_count == 2 and validate_tree(oracle, osc, r)[0] == 0
+    r.update_batch(2); r.render()
+    img, _ = osc.render(64, 48, frames=2)
+    assert r.read_image(0).tobytes() == img[0].tobytes()
+    back = _xf((500, 80, 120), (0.5, 1.1, 0.9), ry=0.9)
+    r.update_node_transform(node, back)
+    r.refit()
+    s.nodes[node].local_transform = back
+    osc = oracle.OracleScene(s)
+    assert r.bvh_info().instance_ref_count == 3 and validate_tree(oracle, osc, r)[0] == 0
+    r.update_batch(2); r.render()
+    img, _ = osc.render(64, 48, frames=2)
+    assert r.read_image(0).tobytes() == img[0].tobytes()
+    r.close()
