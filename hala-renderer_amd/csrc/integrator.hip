@@ -150,6 +150,14 @@ RT_DI void persistent_trace(const SceneView& sv, const TraverseLds& lds, uint2* 
   // between leave in ONE store instruction — whole 1-KB runs for the whole-wave batches of the LDS-staged kernels (64 consecutive
   // queue entries: full lines for the nontemporal stores) — instead of one divergent store per lane and step.
   bool fin = false;
+  // Occluder cache (-DRT_OCCLUDER_CACHE; connection launches of large one-level trees): the triangle that blocked the lane's previous
+  // connection is tested first against its next one — consecutive rays of a lane are queue neighbours, i.e. connections of nearby surface
+  // points towards the same light or the same part of the sky; 23 % of the light and 58 % of the environment connections of configs[3] are
+  // blocked, often by the same large triangles (walls).  A hit inside (0, tmax) on a fully blocking triangle IS an any-hit result: the
+  // connection is dropped without a traversal; otherwise the ray is traced as before.  Images cannot depend on it (the suite passes with
+  // it).  It does not pay: the extra 48-B gather and triangle test of EVERY connection cost more than the traversals the hits save.
+  constexpr bool kCache = ANY && !STAGED && !INST && Source::kOccluderCache;
+  uint32_t last_occ = kAbsent;
   for (;;) {
     const unsigned long long idle = __ballot(!has);
     if (more && idle) {
@@ -175,8 +183,19 @@ RT_DI void persistent_trace(const SceneView& sv, const TraverseLds& lds, uint2* 
             idx = base + rank;
             f3 o, d; float tmin, tmax; uint32_t key = 0u;
             if (src.load(idx, &o, &d, &tmin, &tmax, &key, &pay)) {  // false: the source had no ray for this entry and has dealt with it
-              trav_begin(t, make_ray(o, d, tmin), tmax, key);
-              has = true;
+              bool blocked = false;
+              if (kCache && last_occ != kAbsent) {
+                const float4* tp = reinterpret_cast<const float4*>(sv.tris) + (size_t)last_occ * 3;
+                const float4 a = tp[0], b = tp[1], c = tp[2];
+                float tt, tu, tv, det;
+                if (COUNT) sc.tris++;
+                // flag 0: blocks every ray (a translucent triangle or a medium boundary decides per ray: RENDER_SPEC 7.1d / 7.1g — not cached)
+                blocked = tri_test_od(o, d, a, b, c, &tt, &tu, &tv, &det) && tt > maxf(tmin, 0.0f) && tt < tmax && __float_as_uint(b.w) == 0u;
+              }
+              if (!blocked) {
+                trav_begin(t, make_ray(o, d, tmin), tmax, key);
+                has = true;
+              }  // else: occluded — a connection that is blocked leaves nothing behind (ShadowSource::done does nothing for it)
             }
           }
         }
@@ -189,7 +208,10 @@ RT_DI void persistent_trace(const SceneView& sv, const TraverseLds& lds, uint2* 
 #ifdef RT_NO_DEFER
       if (trav_step<ANY, COUNT, STAGED, ALPHA, INST>(sv, lds, spill, t, has, sc)) { src.done(idx, t, pay); has = false; }
 #else
-      if (trav_step<ANY, COUNT, STAGED, ALPHA, INST>(sv, lds, spill, t, has, sc)) { fin = true; has = false; }
+      if (trav_step<ANY, COUNT, STAGED, ALPHA, INST>(sv, lds, spill, t, has, sc)) {
+        fin = true; has = false;
+        if (kCache && t.best.prim != kAbsent) last_occ = t.best.prim;
+      }
 #endif
       const uint32_t nidle = (uint32_t)__popcll(__ballot(!has));
       if (nidle == 64u || (more && nidle >= refill)) break;
@@ -199,6 +221,7 @@ RT_DI void persistent_trace(const SceneView& sv, const TraverseLds& lds, uint2* 
 }
 
 struct BatchSource {
+  static constexpr bool kOccluderCache = false;  // a caller's batch: traced ray by ray as the spec says (step counts are pinned to the oracle's)
   struct Payload {};
   const hala_ray* rays;
   hala_hit* hits;
@@ -238,6 +261,7 @@ RT_DI bool primary_ray(const FrameConst& fc, const SceneView& sv, uint32_t slot,
   return true;
 }
 struct CameraSource {
+  static constexpr bool kOccluderCache = false;
   struct Payload {};
   const FrameConst& fc;
   const SceneView& sv;
@@ -262,6 +286,11 @@ struct CameraSource {
 #endif
 template <bool PREFETCH, bool ALPHA>
 struct ShadowSource {
+#ifdef RT_OCCLUDER_CACHE  // measured: configs[3] shadow 3.95 -> 4.05 ms per frame with it (profiles/r03_experiments.txt): off
+  static constexpr bool kOccluderCache = true;
+#else
+  static constexpr bool kOccluderCache = false;
+#endif
   // contribution.xyz | pixel slot, fetched with the ray (one coalesced 48-B record), and the path's radiance as it stands
   struct Payload { float4 cs; float lx, ly, lz; };
   const ShadowEntry* entries;

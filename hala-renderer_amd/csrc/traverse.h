@@ -393,7 +393,9 @@ RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, 
                     __hip_atomic_fetch_add(ot + 3, q[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                   }
                 }
-                if (blocks) *(RT_LDS uint32_t*)okey = 0u;
+                // the owner's prim word leaves kAbsent: it becomes the BVH-order index of a blocker (which one of several does not matter) —
+                // the occluder cache of the connection launches tests that triangle first for the lane's next ray (integrator.hip)
+                if (blocks) *(RT_LDS uint32_t*)okey = (leaf & 0x0fffffffu) + j;
               }
             }
             else {
@@ -413,13 +415,14 @@ RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, 
         const u32x4 w4 = slots[lane];
         if (ANY) {
           found = w4.x != kAbsent;
+          if (found) best.prim = w4.x;  // the blocker's BVH-order index
           if (ALPHA) { t.tau[0] += w4.y; t.tau[1] += w4.z; t.tau[2] += w4.w; }
         } else { best.prim = w4.x; best.t = __uint_as_float(w4.y); best.u = __uint_as_float(w4.z); best.v = __uint_as_float(w4.w); }
       }
     }
     if (!has) return false;
   }
-  if (ANY && found) { if (!STAGED) best.prim = 0u; return true; }
+  if (ANY && found) return true;  // (best.prim != kAbsent: the blocker)
   // go on with the nearest inner child if it is still in reach, else with the first stack entry that is
   if (next != kAbsent && !(key_tn(next_key) <= best.t)) next = kAbsent;
   if (!INST) {
