@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 
 #include "hala_types.h"
 #include "host_image.h"
@@ -272,8 +273,9 @@ static std::string load_hdr(FILE* f, HostImage* img) {
   return "";
 }
 
-// ---- OpenEXR, scanline images (the `image` crate's "exr" feature, Cargo.toml:21): compression NONE / RLE / ZIPS / ZIP,
-// HALF / FLOAT / UINT samples, channels R G B [A] or Y; tiled, deep, multi-part and PIZ/PXR24/B44/DWA files are refused ----
+// ---- OpenEXR, scanline and single-level tiled images (the `image` crate's "exr" feature, Cargo.toml:21): compression NONE / RLE /
+// ZIPS / ZIP, HALF / FLOAT / UINT samples, channels R G B [A] or Y; mip / rip-mapped tiles, deep, multi-part and PIZ/PXR24/B44/DWA
+// files are refused ----
 static float half_to_float(uint16_t h) {
   const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, exp = (h >> 10) & 0x1fu, man = h & 0x3ffu;
   uint32_t bits;
@@ -297,7 +299,9 @@ static std::string load_exr(FILE* f, HostImage* img) {
   auto rd32 = [&](size_t at) { uint32_t v; memcpy(&v, &d[at], 4); return v; };
   if (!need(8) || rd32(0) != 20000630u) return "not an OpenEXR file";
   const uint32_t version = rd32(4);
-  if ((version & 0xffu) != 2u || (version & 0x1a00u)) return "tiled, deep and multi-part OpenEXR files are not supported";
+  if ((version & 0xffu) != 2u || (version & 0x1800u)) return "deep and multi-part OpenEXR files are not supported";
+  const bool tiled = (version & 0x200u) != 0u;
+  uint32_t tile_w = 0, tile_h = 0, tile_mode = 0;
   p = 8;
   struct Chan { std::string name; int type; };
   std::vector<Chan> chans;
@@ -329,12 +333,15 @@ static std::string load_exr(FILE* f, HostImage* img) {
     } else if (name == "compression" && size >= 1) compression = d[p];
     else if (name == "dataWindow" && size >= 16) memcpy(win, &d[p], 16);
     else if (name == "lineOrder" && size >= 1) line_order = d[p];
+    else if (name == "tiles" && size >= 9) { tile_w = rd32(p); tile_h = rd32(p + 4); tile_mode = d[p + 8]; }
     p += size;
   }
   if (chans.empty() || win[2] < win[0] || win[3] < win[1]) return "missing channels or data window";
   if (compression < 0 || compression > 3) return "only NONE / RLE / ZIPS / ZIP compressed OpenEXR files are supported";
   (void)line_order;  // chunks carry their own y; the offset table is not needed
+  if ((int64_t)win[2] - win[0] >= (1 << 20) || (int64_t)win[3] - win[1] >= (1 << 20)) return "data window too large";
   const uint32_t W = (uint32_t)(win[2] - win[0] + 1), H = (uint32_t)(win[3] - win[1] + 1);
+  if ((uint64_t)W * H > (1ull << 30)) return "data window too large";
   int ci[4] = {-1, -1, -1, -1};  // R G B A
   size_t line_bytes = 0;
   std::vector<size_t> chan_off(chans.size());
@@ -347,19 +354,43 @@ static std::string load_exr(FILE* f, HostImage* img) {
     else if (chans[k].name == "Y" && ci[0] < 0) ci[0] = ci[1] = ci[2] = (int)k;
   }
   if (ci[0] < 0 || ci[1] < 0 || ci[2] < 0) return "no R, G, B (or Y) channels";
-  const uint32_t block = compression == 3 ? 16u : 1u, chunks = (H + block - 1) / block;
-  p += (size_t)chunks * 8;  // offset table
+  if (tiled && (tile_w == 0 || tile_h == 0 || tile_w > (1u << 16) || tile_h > (1u << 16))) return "bad tile description";
+  if (tiled && (tile_mode & 0x0fu) != 0u) return "mip-mapped and rip-mapped tiled OpenEXR files are not supported";
+  const uint32_t block = compression == 3 ? 16u : 1u;
+  const uint32_t tiles_x = tiled ? (W + tile_w - 1) / tile_w : 1u, tiles_y = tiled ? (H + tile_h - 1) / tile_h : 0u;
+  const uint32_t chunks = tiled ? tiles_x * tiles_y : (H + block - 1) / block;
+  if ((size_t)chunks * 8 > d.size()) return "truncated offset table";
+  p += (size_t)chunks * 8;  // offset table (chunks carry their own coordinates)
   img->width = W; img->height = H; img->channels = ci[3] >= 0 ? 4 : 3;
   img->pixels.assign((size_t)W * H * img->channels, 0.0f);
   std::vector<unsigned char> raw, tmp;
   for (uint32_t c = 0; c < chunks; ++c) {
-    if (!need(8)) return "truncated pixel data";
-    int32_t y0; memcpy(&y0, &d[p], 4);
-    const uint32_t size = rd32(p + 4);
-    p += 8;
-    if (!need(size) || y0 < win[1] || y0 > win[3]) return "bad chunk";
-    const uint32_t lines = std::min<uint32_t>(block, (uint32_t)(win[3] - y0 + 1));
-    const size_t want = line_bytes * lines;
+    // a scanline chunk: y, size, data of `block` lines; a tile chunk: tile x, tile y, level x, level y, size, data of the tile's lines
+    if (!need(tiled ? 20 : 8)) return "truncated pixel data";
+    int32_t y0; uint32_t x_first = 0, cols = W;
+    uint32_t lines;
+    if (tiled) {
+      int32_t tx, ty, lx, ly;
+      memcpy(&tx, &d[p], 4); memcpy(&ty, &d[p + 4], 4); memcpy(&lx, &d[p + 8], 4); memcpy(&ly, &d[p + 12], 4);
+      p += 16;
+      if (tx < 0 || ty < 0 || (uint32_t)tx >= tiles_x || (uint32_t)ty >= tiles_y || lx != 0 || ly != 0) return "bad tile coordinates";
+      x_first = (uint32_t)tx * tile_w; cols = std::min(tile_w, W - x_first);
+      y0 = win[1] + (int32_t)((uint32_t)ty * tile_h);
+      lines = std::min(tile_h, H - (uint32_t)ty * tile_h);
+    } else {
+      memcpy(&y0, &d[p], 4);
+      p += 4;
+      if (y0 < win[1] || y0 > win[3]) return "bad chunk";
+      lines = std::min<uint32_t>(block, (uint32_t)(win[3] - y0 + 1));
+    }
+    const uint32_t size = rd32(p);
+    p += 4;
+    if (!need(size)) return "bad chunk";
+    // bytes of one line of this chunk: every channel's samples of the chunk's columns, channel after channel
+    size_t chunk_line = 0;
+    std::vector<size_t> coff(chans.size());
+    for (size_t k = 0; k < chans.size(); ++k) { coff[k] = chunk_line; chunk_line += (size_t)cols * (chans[k].type == 1 ? 2 : 4); }
+    const size_t want = chunk_line * lines;
     if (compression == 0 || size == want) raw.assign(d.begin() + p, d.begin() + p + size);
     else {
       tmp.resize(want);
@@ -386,13 +417,13 @@ static std::string load_exr(FILE* f, HostImage* img) {
       const uint32_t row = (uint32_t)(y0 - win[1]) + l;
       for (uint32_t ch = 0; ch < img->channels; ++ch) {
         const int k = ci[ch];
-        const unsigned char* src = &raw[line_bytes * l + chan_off[k]];
-        for (uint32_t x = 0; x < W; ++x) {
+        const unsigned char* src = &raw[chunk_line * l + coff[k]];
+        for (uint32_t x = 0; x < cols; ++x) {
           float v;
           if (chans[k].type == 1) { uint16_t h; memcpy(&h, src + 2 * (size_t)x, 2); v = half_to_float(h); }
           else if (chans[k].type == 2) memcpy(&v, src + 4 * (size_t)x, 4);
           else { uint32_t u; memcpy(&u, src + 4 * (size_t)x, 4); v = (float)u; }
-          img->pixels[((size_t)row * W + x) * img->channels + ch] = v;
+          img->pixels[((size_t)row * W + x_first + x) * img->channels + ch] = v;
         }
       }
     }
@@ -407,10 +438,12 @@ std::string load_float_image(const char* path, HostImage* img) {
   const size_t got = fread(magic, 1, 4, f);
   rewind(f);
   std::string e;
-  if (got >= 2 && magic[0] == 'P' && (magic[1] == 'F' || magic[1] == 'f')) e = load_pfm(f, img);
-  else if (got >= 2 && magic[0] == '#' && magic[1] == '?') e = load_hdr(f, img);
-  else if (got == 4 && magic[0] == 0x76 && magic[1] == 0x2f && magic[2] == 0x31 && magic[3] == 0x01) e = load_exr(f, img);
-  else e = "unrecognised format";
+  try {  // nothing is thrown across the C ABI: a header that asks for an absurd image ends as a decode error, not as std::bad_alloc
+    if (got >= 2 && magic[0] == 'P' && (magic[1] == 'F' || magic[1] == 'f')) e = load_pfm(f, img);
+    else if (got >= 2 && magic[0] == '#' && magic[1] == '?') e = load_hdr(f, img);
+    else if (got == 4 && magic[0] == 0x76 && magic[1] == 0x2f && magic[2] == 0x31 && magic[3] == 0x01) e = load_exr(f, img);
+    else e = "unrecognised format";
+  } catch (const std::exception& ex) { e = std::string("out of memory or malformed: ") + ex.what(); }
   fclose(f);
   if (!e.empty()) return std::string("Failed to decode image \"") + path + "\". (" + e + ")";  // src/envmap.rs:53
   return "";
