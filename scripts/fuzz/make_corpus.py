@@ -10,7 +10,7 @@ from hala_renderer_amd import scenes  # noqa: E402
 from gltf_writer import write_gltf  # noqa: E402
 
 out = sys.argv[1]
-for d in ("jpeg", "gltf", "png"):
+for d in ("jpeg", "gltf", "png", "image"):
     os.makedirs(os.path.join(out, d), exist_ok=True)
 rs = np.random.RandomState(1)
 
@@ -102,3 +102,21 @@ for mode, size, ch in (("RGB", (17, 9), 3), ("RGBA", (16, 16), 4), ("L", (5, 7),
         b = bio.getvalue() if k == 0 else mutate(bio.getvalue(), 8)
         d = json.loads(json.dumps(doc)); d["images"][0] = {"uri": "data:image/png;base64," + base64.b64encode(b).decode()}
         json.dump(d, open(os.path.join(out, "png", f"p{n:04d}.gltf"), "w")); n += 1
+
+# float images (set_envmap(path)): OpenEXR scanline + tiled in every compression, .hdr, .pfm, each with byte-level mutations
+from test_image_decoders import write_exr  # noqa: E402
+n = 0
+img = (rs.rand(21, 34, 4) * 3).astype(np.float32)
+variants = [dict(compression=c, half=hf, tile=t) for c in ("none", "zips", "zip") for hf in (False, True) for t in (None, (8, 8), (16, 5))]
+for v in variants:
+    p0 = os.path.join(out, "image", "base.exr")
+    write_exr(p0, img, v["compression"], v["half"], channels="RGBA", tile=v["tile"])
+    raw = open(p0, "rb").read()
+    for k in range(40):
+        open(os.path.join(out, "image", f"e{n:05d}.exr"), "wb").write(raw if k == 0 else mutate(raw, 8)); n += 1
+os.remove(os.path.join(out, "image", "base.exr"))
+hdr = b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 6 +X 9\n" + rs.randint(0, 256, 6 * 9 * 4).astype(np.uint8).tobytes()
+pfm = b"PF\n7 5\n-1.0\n" + rs.rand(5 * 7 * 3).astype(np.float32).tobytes()
+for base, ext in ((hdr, "hdr"), (pfm, "pfm")):
+    for k in range(150):
+        open(os.path.join(out, "image", f"x{n:05d}.{ext}"), "wb").write(base if k == 0 else mutate(base, 2)); n += 1

@@ -1,5 +1,5 @@
 #!/bin/bash
-# CPU-only robustness run of the untrusted-input paths of libhalart.so: the glTF / PNG / JPEG loaders compiled with g++
+# CPU-only robustness run of the untrusted-input paths of libhalart.so: the glTF / PNG / JPEG / OpenEXR / .hdr / .pfm loaders compiled with g++
 # -fsanitize=address,undefined (GPU sanitizers are not available on this pool) and fed ~3700 mutated files.  Any sanitizer report aborts.
 # usage: bash scripts/fuzz/run.sh [workdir]        (result line per corpus; profiles/r02_fuzz.txt holds the last run)
 set -eu
@@ -14,4 +14,5 @@ python3 $ROOT/scripts/fuzz/make_corpus.py $W/corpus 2>/dev/null
 $W/harness jpeg $W/corpus/jpeg/*.jpg
 $W/harness gltf $W/corpus/gltf/*.gltf
 $W/harness gltf $W/corpus/png/*.gltf
+$W/harness image $W/corpus/image/*
 echo "no sanitizer report"
