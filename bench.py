@@ -32,12 +32,12 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 
 
 def source_hash():
-    """hash of everything that is compiled into libhalart.so: a committed PMC traffic figure is only quoted for the
-    code it was collected from"""
+    """hash of the device code of libhalart.so and of the host code that launches it (every .hip and .h of csrc/, the Makefile, the C
+    ABI header; not the file loaders): a committed PMC traffic figure is only quoted for the code it was collected from"""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "hala-renderer_amd", "csrc")
     for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".h", ".cpp")) or name == "Makefile":
+        if name.endswith((".hip", ".h")) or name == "Makefile":
             h.update(name.encode())
             h.update(open(os.path.join(d, name), "rb").read())
     h.update(open(os.path.join(ROOT, "include", "halart.h"), "rb").read())
