@@ -52,7 +52,12 @@ def test_c99_host_saves_the_same_images_as_the_python_mirror(halart, tmp_path):
     w, h, spp = 96, 54, 3
     p = subprocess.run([exe, gltf, str(tmp_path / "c_host"), str(w), str(h), str(spp), env_path, "30"], capture_output=True, text=True)
     assert p.returncode == 0, p.stderr
-    assert p.stdout.startswith("frames 3 rays ")
+    assert p.stdout.startswith("triangles ") and "instance references 0" in p.stdout and "\nframes 3 rays " in p.stdout
+    # the reference's BLAS / TLAS split through the C ABI (hala_rt_set_build_options from C99): fewer stored triangles, the same picture to rounding
+    p2 = subprocess.run([exe, gltf, str(tmp_path / "c_host2"), str(w), str(h), str(spp), env_path, "30", "two-level"], capture_output=True, text=True)
+    assert p2.returncode == 0, p2.stderr
+    first = p2.stdout.splitlines()[0].split()
+    assert int(first[1]) > int(first[3]) and int(first[6]) == 42, p2.stdout  # triangles > stored; 28 columns + 14 arches are instance references
     r = halart.HalaRenderer("py", w, h, 8, 3, False, False, False, 0)
     r.set_envmap(env_path, 30.0)
     r.set_scene(NativeScene(gltf))
@@ -65,3 +70,7 @@ def test_c99_host_saves_the_same_images_as_the_python_mirror(halart, tmp_path):
         a = open(tmp_path / f"c_host_{aov}.pfm", "rb").read()
         b = open(tmp_path / f"py_host_{aov}.pfm", "rb").read()
         assert len(a) > w * h * 12 and a == b, aov
+    hdr = len(b"PF\n96 54\n-1.0\n")
+    flat = np.frombuffer(open(tmp_path / "c_host_albedo.pfm", "rb").read()[hdr:], dtype="<f4")
+    two = np.frombuffer(open(tmp_path / "c_host2_albedo.pfm", "rb").read()[hdr:], dtype="<f4")
+    assert flat.shape == two.shape and np.abs(flat - two).mean() < 2e-3
