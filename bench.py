@@ -229,8 +229,9 @@ def valu_note(counters):
         return None
     util, lanes = counters["valu_issue_utilisation"], counters["active_lanes_per_valu_instruction"]
     return {"issue_utilisation": util, "active_lanes_of_64": lanes, "lane_issue_frac": round(util * lanes / 64.0, 4),
-            "note": "SQ_ACTIVE_INST_VALU / (4 x SQ_BUSY_CU_CYCLES) x SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU / 64: the share of the chip's vector "
-                    "lane-issue capacity doing work — the limit that binds these kernels (the tree is cache-resident)"}
+            "note": "issue_utilisation = SQ_INSTS_VALU / (1024 SIMDs x kernel cycles / 4) with kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs (a SIMD issues one "
+                    "wave64 VALU instruction per 4 cycles); active_lanes = SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU; their product / 64 = the share of the chip's "
+                    "vector lane-issue capacity doing work — the limit that binds these kernels (the tree is cache-resident)"}
 
 
 def main():
