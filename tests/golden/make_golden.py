@@ -51,6 +51,40 @@ def media(write=True):
     return imgs, st
 
 
+def instanced_scene():
+    """RENDER_SPEC 4.5: the Cornell box with the short block's mesh referenced three more times — rotated + non-uniformly scaled, mirrored,
+    sheared by its parent — so that its ten triangles are intersected in object space when instancing is on"""
+    import hala_renderer_amd as H
+    s = scenes.cornell_box(aspect=64 / 48)
+
+    def xf(t, scale, cs):
+        c, sn = cs  # exact rationals (3-4-5 and 5-12-13 triangles): no libm in the fixture's scene
+        m = np.eye(4)
+        m[:3, :3] = np.array([[c, 0, sn], [0, 1, 0], [-sn, 0, c]]) @ np.diag(scale)
+        m[:3, 3] = t
+        return m.astype(np.float32)
+
+    shear = np.eye(4, dtype=np.float32); shear[0, 1] = 0.35; shear[:3, 3] = (60.0, 200.0, 120.0)
+    s.nodes.append(H.HalaNode(name="copy0", mesh_index=1, local_transform=xf((250, 330, 230), (0.6, 1.4, 0.5), (0.8, 0.6))))
+    s.nodes.append(H.HalaNode(name="copy1", mesh_index=1, local_transform=xf((520, 60, 90), (-0.8, 0.9, 0.7), (12.0 / 13.0, -5.0 / 13.0))))
+    s.nodes.append(H.HalaNode(name="shear", local_transform=shear))
+    s.nodes.append(H.HalaNode(name="copy2", mesh_index=1, parent=len(s.nodes) - 1, local_transform=xf((-20, 150, 200), (0.5, 0.5, 0.5), (0.6, 0.8))))
+    return s
+
+
+def instanced(write=True):
+    O.set_instancing(True)
+    try:
+        sc = O.OracleScene(instanced_scene())
+        imgs, st = sc.render(64, 48, frames=2, max_depth=5, rr_depth=3)
+    finally:
+        O.set_instancing(False)
+    if write:
+        np.savez_compressed(os.path.join(HERE, "instanced_cornell_64x48_2spp.npz"), accum=imgs[0], albedo=imgs[1], normal=imgs[2],
+                            rays=np.array([st.rays_closest, st.rays_shadow], dtype=np.uint64))
+    return imgs, st
+
+
 def config0(write=True):
     """BASELINE configs[0] (Cornell 512x512, 1 spp): hash of the colour PFM the reference's save_images would write"""
     import hashlib
@@ -69,6 +103,10 @@ def config0(write=True):
 def main():
     if "--only-config0" in sys.argv:
         print(config0())
+        return
+    if "--only-instanced" in sys.argv:  # round 3 (RENDER_SPEC 4.5): written alone so that the older files keep their bytes
+        instanced()
+        print("instanced fixture written to", HERE)
         return
     if "--only-media" in sys.argv:  # added later than the others: written alone so that their files keep their bytes
         media()
