@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""GPU builder (PLOC or LBVH, see HALART_BUILDER) vs binned-SAH (oracle's CPU builder), both as compressed 4-wide trees: traversal steps per ray on
+"""GPU builder (argv[1]: sah | ploc | lbvh; default: the library's choice) vs binned-SAH (oracle's CPU builder), both as compressed 4-wide trees: traversal steps per ray on
 the same rays, and an instruction-weighted cost (a node visit ~ 170 VALU, a triangle test ~ 60)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,6 +10,8 @@ from hala_renderer_amd import scenes
 import oracle_lib as O
 for name, s in [("blob82k", scenes.bunny_class(subdivisions=6)), ("atrium250k", scenes.sponza_class(target_triangles=250000, disney=False))]:
     r = H.HalaRenderer("q", 64, 64, 5, 3, False, False, False, 0)
+    if len(sys.argv) > 1:
+        r.set_build_options(builder=sys.argv[1])
     r.set_scene(s); r.commit()
     nodes, tris = r.download_bvh()
     osc = O.OracleScene(s)
