@@ -2,9 +2,9 @@
 // `hala_scene_load_gltf` is cpu::HalaScene::new (src/scene/cpu/scene.rs:40-55); the scene it returns is the borrowed
 // `hala_scene_desc` that `hala_rt_set_scene` consumes.  Rule by rule like the reference (each rule cites its lines); the
 // reference delegates parsing to the `gltf` and `image` crates — here: the library's own JSON reader, base64, accessor
-// decoding, a PNG decoder over zlib (8/16-bit, grey / RGB / palette / alpha, non-interlaced) and a baseline JPEG decoder
-// (jpeg_decode.cpp).  Progressive JPEG and interlaced PNG images are reported as "Unsupported image format." (the Python
-// mirror hala-renderer_amd/gltf_loader.py decodes those with PIL).
+// decoding, a PNG decoder over zlib (1..16-bit, grey / RGB / palette / alpha, plain or Adam7-interlaced), a Huffman JPEG decoder
+// (jpeg_decode.cpp: sequential and progressive), PGM / PPM and TGA.  Anything else (arithmetic-coded or lossless JPEG, other
+// containers) is reported as "Unsupported image format." (the Python mirror hala-renderer_amd/gltf_loader.py decodes with PIL).
 #include <zlib.h>
 
 #include <cmath>
@@ -241,59 +241,207 @@ bool decode_png(const std::vector<uint8_t>& raw, uint32_t* w, uint32_t* h, std::
     else if (!memcmp(type, "IEND", 4)) break;
     pos += 12 + (size_t)len;
   }
-  if (!width || !height || width > kMaxImageDim || height > kMaxImageDim || interlace != 0) return false;
+  if (!width || !height || width > kMaxImageDim || height > kMaxImageDim || interlace > 1) return false;
   int channels = 0;
   switch (ctype) { case 0: channels = 1; break; case 2: channels = 3; break; case 3: channels = 1; break; case 4: channels = 2; break; case 6: channels = 4; break; default: return false; }
   if (!(depth == 8 || depth == 16 || (depth < 8 && (ctype == 0 || ctype == 3)))) return false;
-  const size_t bpp_bits = (size_t)channels * depth, row_bytes = (width * bpp_bits + 7) / 8, bpp = std::max<size_t>(1, bpp_bits / 8);
-  std::vector<uint8_t> data((row_bytes + 1) * height);
+  const size_t bpp_bits = (size_t)channels * depth, bpp = std::max<size_t>(1, bpp_bits / 8);
+  // the image is one pass, or the seven Adam7 passes (PNG 8.2): pass p holds the pixels (x0 + i dx, y0 + j dy), filtered as an image of its own
+  struct Pass { uint32_t x0, y0, dx, dy; };
+  static const Pass adam7[7] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}};
+  static const Pass whole[1] = {{0, 0, 1, 1}};
+  const Pass* passes = interlace ? adam7 : whole;
+  const int pass_count = interlace ? 7 : 1;
+  size_t total = 0;
+  for (int p = 0; p < pass_count; ++p) {
+    const size_t pw = passes[p].x0 < width ? (width - passes[p].x0 + passes[p].dx - 1) / passes[p].dx : 0;
+    const size_t ph = passes[p].y0 < height ? (height - passes[p].y0 + passes[p].dy - 1) / passes[p].dy : 0;
+    if (pw && ph) total += ((pw * bpp_bits + 7) / 8 + 1) * ph;
+  }
+  std::vector<uint8_t> data(total);
   uLongf out_len = (uLongf)data.size();
   if (uncompress(data.data(), &out_len, idat.data(), (uLong)idat.size()) != Z_OK || out_len != data.size()) return false;
-  std::vector<uint8_t> prev(row_bytes, 0), cur(row_bytes);
   rgba->assign((size_t)width * height * 4, 255);
-  for (uint32_t y = 0; y < height; ++y) {
-    const uint8_t* in = &data[(row_bytes + 1) * y];
-    const int filter = in[0];
-    for (size_t i = 0; i < row_bytes; ++i) {
-      const int a = i >= bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
-      int x = in[1 + i];
-      switch (filter) {
-        case 0: break;
-        case 1: x += a; break;
-        case 2: x += b; break;
-        case 3: x += (a + b) / 2; break;
-        case 4: { const int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c); x += (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); break; }
-        default: return false;
+  size_t at = 0;
+  for (int p = 0; p < pass_count; ++p) {
+    const Pass ps = passes[p];
+    const uint32_t pw = ps.x0 < width ? (width - ps.x0 + ps.dx - 1) / ps.dx : 0, ph = ps.y0 < height ? (height - ps.y0 + ps.dy - 1) / ps.dy : 0;
+    if (!pw || !ph) continue;
+    const size_t row_bytes = ((size_t)pw * bpp_bits + 7) / 8;
+    std::vector<uint8_t> prev(row_bytes, 0), cur(row_bytes);
+    for (uint32_t y = 0; y < ph; ++y) {
+      const uint8_t* in = &data[at];
+      at += row_bytes + 1;
+      const int filter = in[0];
+      for (size_t i = 0; i < row_bytes; ++i) {
+        const int a = i >= bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
+        int x = in[1 + i];
+        switch (filter) {
+          case 0: break;
+          case 1: x += a; break;
+          case 2: x += b; break;
+          case 3: x += (a + b) / 2; break;
+          case 4: { const int q = a + b - c, pa = abs(q - a), pb = abs(q - b), pc = abs(q - c); x += (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); break; }
+          default: return false;
+        }
+        cur[i] = (uint8_t)x;
       }
-      cur[i] = (uint8_t)x;
-    }
-    for (uint32_t xx = 0; xx < width; ++xx) {
-      uint8_t* px = &(*rgba)[((size_t)y * width + xx) * 4];
-      auto sample = [&](int ch) -> uint32_t {  // 8-bit value of channel ch of pixel xx
-        if (depth == 8) return cur[(size_t)xx * channels + ch];
-        if (depth == 16) return cur[((size_t)xx * channels + ch) * 2];
-        const size_t bit = (size_t)xx * depth;
-        const uint32_t v = (cur[bit / 8] >> (8 - depth - (bit % 8))) & ((1u << depth) - 1u);
-        return ctype == 3 ? v : v * 255u / ((1u << depth) - 1u);
-      };
-      if (ctype == 3) {
-        const uint32_t idx = sample(0);
-        if ((size_t)idx * 3 + 2 >= plte.size()) return false;
-        px[0] = plte[idx * 3]; px[1] = plte[idx * 3 + 1]; px[2] = plte[idx * 3 + 2];
-        px[3] = idx < trns.size() ? trns[idx] : 255;
-      } else if (ctype == 0 || ctype == 4) {
-        px[0] = px[1] = px[2] = (uint8_t)sample(0);
-        px[3] = ctype == 4 ? (uint8_t)sample(1) : 255;
-      } else {
-        px[0] = (uint8_t)sample(0); px[1] = (uint8_t)sample(1); px[2] = (uint8_t)sample(2);
-        px[3] = ctype == 6 ? (uint8_t)sample(3) : 255;
+      for (uint32_t xx = 0; xx < pw; ++xx) {
+        uint8_t* px = &(*rgba)[((size_t)(ps.y0 + y * ps.dy) * width + ps.x0 + xx * ps.dx) * 4];
+        auto sample = [&](int ch) -> uint32_t {  // 8-bit value of channel ch of pixel xx of this pass row
+          if (depth == 8) return cur[(size_t)xx * channels + ch];
+          if (depth == 16) return cur[((size_t)xx * channels + ch) * 2];
+          const size_t bit = (size_t)xx * depth;
+          const uint32_t v = (cur[bit / 8] >> (8 - depth - (bit % 8))) & ((1u << depth) - 1u);
+          return ctype == 3 ? v : v * 255u / ((1u << depth) - 1u);
+        };
+        if (ctype == 3) {
+          const uint32_t idx = sample(0);
+          if ((size_t)idx * 3 + 2 >= plte.size()) return false;
+          px[0] = plte[idx * 3]; px[1] = plte[idx * 3 + 1]; px[2] = plte[idx * 3 + 2];
+          px[3] = idx < trns.size() ? trns[idx] : 255;
+        } else if (ctype == 0 || ctype == 4) {
+          px[0] = px[1] = px[2] = (uint8_t)sample(0);
+          px[3] = ctype == 4 ? (uint8_t)sample(1) : 255;
+        } else {
+          px[0] = (uint8_t)sample(0); px[1] = (uint8_t)sample(1); px[2] = (uint8_t)sample(2);
+          px[3] = ctype == 6 ? (uint8_t)sample(3) : 255;
+        }
       }
+      prev.swap(cur);
     }
-    prev.swap(cur);
   }
   *w = width; *h = height;
   return true;
 }
+
+// ---- PNM and TGA: the other 8-bit formats the reference's `image` dependency is built with (Cargo.toml features pnm, tga) ------------
+// binary or plain PGM / PPM, maxval 255: "P5"/"P6"/"P2"/"P3", whitespace- and '#'-comment separated header fields
+bool decode_pnm(const std::vector<uint8_t>& raw, uint32_t* w, uint32_t* h, std::vector<uint8_t>* rgba) {
+  if (raw.size() < 7 || raw[0] != 'P' || (raw[1] != '5' && raw[1] != '6' && raw[1] != '2' && raw[1] != '3')) return false;
+  const bool plain = raw[1] == '2' || raw[1] == '3';
+  const uint32_t channels = raw[1] == '6' || raw[1] == '3' ? 3u : 1u;
+  size_t pos = 2;
+  auto skip = [&]() {  // whitespace and comments up to the end of their line
+    while (pos < raw.size()) {
+      if (raw[pos] == '#') { while (pos < raw.size() && raw[pos] != '\n') ++pos; }
+      else if (raw[pos] == ' ' || raw[pos] == '\t' || raw[pos] == '\r' || raw[pos] == '\n' || raw[pos] == '\v' || raw[pos] == '\f') ++pos;
+      else break;
+    }
+  };
+  auto number = [&](uint32_t* out) {
+    skip();
+    uint64_t v = 0;
+    size_t digits = 0;
+    while (pos < raw.size() && raw[pos] >= '0' && raw[pos] <= '9' && digits < 10) { v = v * 10 + (raw[pos] - '0'); ++pos; ++digits; }
+    if (digits == 0 || v > 0xffffffffull) return false;
+    *out = (uint32_t)v;
+    return true;
+  };
+  uint32_t width = 0, height = 0, maxval = 0;
+  if (!number(&width) || !number(&height) || !number(&maxval)) return false;
+  if (width == 0 || height == 0 || width > kMaxImageDim || height > kMaxImageDim || maxval != 255u) return false;
+  const size_t n = (size_t)width * height;
+  std::vector<uint8_t> px(n * 4);
+  if (!plain) {
+    if (pos >= raw.size()) return false;
+    ++pos;  // the single whitespace byte after maxval
+    if (raw.size() - pos < n * channels) return false;
+    const uint8_t* s = raw.data() + pos;
+    for (size_t i = 0; i < n; ++i) {
+      px[4 * i] = s[channels * i];
+      px[4 * i + 1] = s[channels * i + (channels == 3 ? 1 : 0)];
+      px[4 * i + 2] = s[channels * i + (channels == 3 ? 2 : 0)];
+      px[4 * i + 3] = 255;
+    }
+  } else {
+    if (raw.size() - pos < n * channels * 2) return false;  // a sample and its separator take two bytes at least
+    for (size_t i = 0; i < n; ++i) {
+      uint32_t v[3] = {0, 0, 0};
+      for (uint32_t c = 0; c < channels; ++c) if (!number(&v[c]) || v[c] > 255u) return false;
+      px[4 * i] = (uint8_t)v[0];
+      px[4 * i + 1] = (uint8_t)v[channels == 3 ? 1 : 0];
+      px[4 * i + 2] = (uint8_t)v[channels == 3 ? 2 : 0];
+      px[4 * i + 3] = 255;
+    }
+  }
+  *w = width; *h = height; *rgba = std::move(px);
+  return true;
+}
+
+// TGA has no magic number: the 18-byte header must be self-consistent.  Image types 1/9 (colour-mapped), 2/10 (true colour), 3/11 (grey),
+// the upper ones run-length encoded; 8-bit indices or grey, 24/32-bit BGR(A) pixels and colour-map entries; both row orders and both
+// column orders (descriptor bits 5 and 4).
+bool decode_tga(const std::vector<uint8_t>& raw, uint32_t* w, uint32_t* h, std::vector<uint8_t>* rgba) {
+  if (raw.size() < 18) return false;
+  const uint8_t* hd = raw.data();
+  const uint32_t id_len = hd[0], cmap_type = hd[1], type = hd[2];
+  const uint32_t cmap_first = hd[3] | (hd[4] << 8), cmap_len = hd[5] | (hd[6] << 8), cmap_bits = hd[7];
+  const uint32_t width = hd[12] | (hd[13] << 8), height = hd[14] | (hd[15] << 8), bpp = hd[16], desc = hd[17];
+  const bool rle = type >= 9;
+  const uint32_t kind = rle ? type - 8 : type;  // 1 mapped, 2 true colour, 3 grey
+  if (kind < 1 || kind > 3 || type > 11 || cmap_type > 1 || width == 0 || height == 0 || (desc & 0xc0)) return false;
+  if (kind == 1 && (cmap_type != 1 || bpp != 8 || (cmap_bits != 24 && cmap_bits != 32) || cmap_len == 0)) return false;
+  if (kind == 2 && bpp != 24 && bpp != 32) return false;
+  if (kind == 3 && bpp != 8) return false;
+  if (cmap_type == 1 && cmap_bits != 15 && cmap_bits != 16 && cmap_bits != 24 && cmap_bits != 32) return false;
+  size_t pos = 18 + (size_t)id_len;
+  const size_t cmap_bytes = cmap_type ? (size_t)cmap_len * ((cmap_bits + 7) / 8) : 0;
+  if (pos + cmap_bytes > raw.size()) return false;
+  const uint8_t* cmap = raw.data() + pos;
+  pos += cmap_bytes;
+  const uint32_t bytes = bpp / 8;
+  const size_t n = (size_t)width * height;
+  std::vector<uint8_t> src(n * bytes);
+  if (!rle) {
+    if (raw.size() - pos < n * bytes) return false;
+    memcpy(src.data(), raw.data() + pos, n * bytes);
+  } else {
+    size_t done = 0;
+    while (done < n) {
+      if (pos >= raw.size()) return false;
+      const uint32_t head = raw[pos++], count = (head & 0x7f) + 1;
+      if (done + count > n) return false;
+      if (head & 0x80) {
+        if (raw.size() - pos < bytes) return false;
+        for (uint32_t k = 0; k < count; ++k) memcpy(&src[(done + k) * bytes], &raw[pos], bytes);
+        pos += bytes;
+      } else {
+        if (raw.size() - pos < (size_t)count * bytes) return false;
+        memcpy(&src[done * bytes], &raw[pos], (size_t)count * bytes);
+        pos += (size_t)count * bytes;
+      }
+      done += count;
+    }
+  }
+  std::vector<uint8_t> px(n * 4);
+  const bool top_down = (desc & 0x20) != 0, right_left = (desc & 0x10) != 0;
+  const uint32_t cmap_entry = cmap_bits / 8;
+  for (uint32_t y = 0; y < height; ++y) {
+    const uint32_t oy = top_down ? y : height - 1 - y;
+    for (uint32_t x = 0; x < width; ++x) {
+      const uint32_t ox = right_left ? width - 1 - x : x;
+      const uint8_t* s = &src[((size_t)y * width + x) * bytes];
+      uint8_t* o = &px[((size_t)oy * width + ox) * 4];
+      if (kind == 3) { o[0] = o[1] = o[2] = s[0]; o[3] = 255; }
+      else if (kind == 2) { o[0] = s[2]; o[1] = s[1]; o[2] = s[0]; o[3] = bytes == 4 ? s[3] : 255; }
+      else {
+        const uint32_t index = s[0];
+        if (index < cmap_first || index - cmap_first >= cmap_len) return false;
+        const uint8_t* e = cmap + (size_t)(index - cmap_first) * cmap_entry;
+        o[0] = e[2]; o[1] = e[1]; o[2] = e[0]; o[3] = cmap_entry == 4 ? e[3] : 255;
+      }
+    }
+  }
+  *w = width; *h = height; *rgba = std::move(px);
+  return true;
+}
+
+// the sniffing order: signatures first, the header-only format last
+bool decode_image_rgba8(const std::vector<uint8_t>& raw, uint32_t* w, uint32_t* h, std::vector<uint8_t>* rgba) {
+  return decode_png(raw, w, h, rgba) || rt::decode_jpeg(raw, w, h, rgba) || decode_pnm(raw, w, h, rgba) || decode_tga(raw, w, h, rgba);
+}
+
 
 // ---- the loader (gltf_loader.rs:121-227) ----------------------------------------------------------------------------
 void load_mesh(const Doc& d, const JsonValue& mesh, hala_scene* s) {  // :232-313
@@ -507,7 +655,7 @@ void load(const std::string& path, hala_scene* s) {
     }
     uint32_t w = 0, h = 0;
     std::vector<uint8_t> px;
-    if (!decode_png(raw, &w, &h, &px) && !rt::decode_jpeg(raw, &w, &h, &px)) fail("Unsupported image format.");
+    if (!decode_image_rgba8(raw, &w, &h, &px)) fail("Unsupported image format.");
     s->pixels.push_back(std::move(px));
     s->images.push_back(hala_image_desc{HALA_FORMAT_R8G8B8A8_SRGB, w, h, s->pixels.back().data(), s->pixels.back().size()});
   }
@@ -527,8 +675,8 @@ void load(const std::string& path, hala_scene* s) {
 
 }  // namespace
 
-// 8-bit image file -> RGBA8 for callers outside the glTF loader (cpu::HalaImageData::new_with_file, src/scene/cpu/image_data.rs:26-29: PNG
-// and baseline JPEG here); the error text is the reference's.
+// 8-bit image file -> RGBA8 for callers outside the glTF loader (cpu::HalaImageData::new_with_file, src/scene/cpu/image_data.rs:26-29: PNG,
+// baseline JPEG, PGM / PPM and TGA here); the error text is the reference's.
 namespace rt {
 std::string decode_image_file_rgba8(const char* path, uint32_t* w, uint32_t* h, std::vector<uint8_t>* rgba) {
   const std::string msg = std::string("Failed to open image \"") + (path ? path : "") + "\".";
@@ -540,7 +688,7 @@ std::string decode_image_file_rgba8(const char* path, uint32_t* w, uint32_t* h, 
   size_t got;
   while ((got = fread(buf, 1, sizeof(buf), f)) > 0) raw.insert(raw.end(), buf, buf + got);
   fclose(f);
-  if (!decode_png(raw, w, h, rgba) && !decode_jpeg(raw, w, h, rgba)) return msg;
+  if (!decode_image_rgba8(raw, w, h, rgba)) return msg;
   return "";
 }
 }  // namespace rt

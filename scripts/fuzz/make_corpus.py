@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Mutation corpus for scripts/fuzz/run.sh: sequential + progressive JPEGs, glTF documents (byte-level and structural mutations),
-PNGs of every colour type embedded in a glTF.  usage: make_corpus.py <outdir>"""
+PNGs of every colour type, PGM / PPM and TGA files embedded in a glTF.  usage: make_corpus.py <outdir>"""
 import base64, copy, io, json, os, sys
 import numpy as np
 from PIL import Image
@@ -101,6 +101,26 @@ for mode, size, ch in (("RGB", (17, 9), 3), ("RGBA", (16, 16), 4), ("L", (5, 7),
     for k in range(120):
         b = bio.getvalue() if k == 0 else mutate(bio.getvalue(), 8)
         d = json.loads(json.dumps(doc)); d["images"][0] = {"uri": "data:image/png;base64," + base64.b64encode(b).decode()}
+        json.dump(d, open(os.path.join(out, "png", f"p{n:04d}.gltf"), "w")); n += 1
+
+# PGM / PPM (binary + plain) and TGA (raw, run-length, colour-mapped, 32-bit) embedded the same way
+seeds = []
+g = rs.randint(0, 256, (7, 11, 3)).astype(np.uint8); g[:, 2:8] = g[:, 2:3]
+seeds.append(b"P6\n11 7\n255\n" + g.tobytes())
+seeds.append(b"P5\n# c\n11 7\n255\n" + g[..., 0].tobytes())
+seeds.append(b"P3\n11 7\n255\n" + b" ".join(str(int(v)).encode() for v in g.reshape(-1)) + b"\n")
+seeds.append(b"P2\n11 7\n255\n" + b" ".join(str(int(v)).encode() for v in g[..., 0].reshape(-1)) + b"\n")
+for im, kw in ((Image.fromarray(g, "RGB"), {}), (Image.fromarray(g, "RGB"), dict(compression="tga_rle")), (Image.fromarray(g[..., 0], "L"), dict(compression="tga_rle")),
+               (Image.fromarray(g, "RGB").quantize(16), {}), (Image.fromarray(g, "RGB").quantize(16), dict(compression="tga_rle")),
+               (Image.fromarray(np.dstack([g, g[..., :1]]), "RGBA"), dict(orientation=1))):
+    bio = io.BytesIO(); im.save(bio, format="TGA", **kw); seeds.append(bio.getvalue())
+from test_gltf_native import _png_bytes  # noqa: E402  (Adam7 writer)
+for ctype, depth, ch in ((2, 8, 3), (0, 2, 1), (3, 4, 1), (6, 16, 4)):
+    seeds.append(_png_bytes(rs.randint(0, 1 << depth, (9, 13, ch)), ctype, depth, True, rs.randint(0, 256, (1 << depth, 3)) if ctype == 3 else None))
+for b0 in seeds:
+    for k in range(120):
+        b = b0 if k == 0 else mutate(b0, 0 if k % 3 else 18)  # two thirds of the mutations may hit the header
+        d = json.loads(json.dumps(doc)); d["images"][0] = {"uri": "data:application/octet-stream;base64," + base64.b64encode(b).decode()}
         json.dump(d, open(os.path.join(out, "png", f"p{n:04d}.gltf"), "w")); n += 1
 
 # float images (set_envmap(path)): OpenEXR scanline + tiled in every compression, .hdr, .pfm, each with byte-level mutations

@@ -1,6 +1,6 @@
 #!/bin/bash
-# CPU-only robustness run of the untrusted-input paths of libhalart.so: the glTF / PNG / JPEG / OpenEXR / .hdr / .pfm loaders compiled with g++
-# -fsanitize=address,undefined (GPU sanitizers are not available on this pool) and fed ~3700 mutated files.  Any sanitizer report aborts.
+# CPU-only robustness run of the untrusted-input paths of libhalart.so: the glTF / PNG / JPEG / PNM / TGA / OpenEXR / .hdr / .pfm loaders compiled with g++
+# -fsanitize=address,undefined (GPU sanitizers are not available on this pool) and fed ~6300 mutated files.  Any sanitizer report aborts.
 # usage: bash scripts/fuzz/run.sh [workdir]        (result line per corpus; profiles/r02_fuzz.txt holds the last run)
 set -eu
 ROOT=$(cd "$(dirname "$0")/../.." && pwd)

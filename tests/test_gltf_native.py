@@ -337,3 +337,144 @@ def test_sparse_accessors(tmp_path):
     json.dump(j, open(tmp_path / "bad.gltf", "w"))
     with pytest.raises(Exception):
         NativeScene(str(tmp_path / "bad.gltf"))
+
+
+def _pnm_bytes(img, plain, comment):
+    h, w = img.shape[:2]
+    grey = img.ndim == 2
+    magic = {(True, False): b"P5", (True, True): b"P2", (False, False): b"P6", (False, True): b"P3"}[(grey, plain)]
+    head = magic + b"\n" + (b"# made by hand\n" if comment else b"") + f"{w} {h}".encode() + (b" # size\n" if comment else b"\n") + b"255\n"
+    if not plain:
+        return head + img.tobytes()
+    return head + b"\n".join(b" ".join(str(int(v)).encode() for v in row.reshape(-1)) for row in img) + b"\n"
+
+
+@pytest.mark.parametrize("variant", ["pgm", "ppm", "pgm-plain", "ppm-plain", "ppm-comment", "tga-rgb", "tga-rgba", "tga-grey", "tga-rle", "tga-rle-rgba",
+                                     "tga-palette", "tga-bottom-up", "tga-right-left"])
+def test_pnm_and_tga_textures_decode_like_pil(tmp_path, variant):
+    """the other 8-bit formats of the reference's `image` dependency (Cargo.toml features: pnm, tga): byte-exact against PIL's decode — these
+    formats store samples verbatim"""
+    import io
+    from PIL import Image
+    rng = np.random.default_rng(len(variant))
+    w, h = 29, 17
+    rgb = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    rgb[:, 5:20] = rgb[:, 5:6]  # runs, so the run-length packets have both kinds
+    grey = rgb[..., 0].copy()
+    rgba = np.concatenate([rgb, rng.integers(0, 256, (h, w, 1), dtype=np.uint8)], -1)
+    if variant.startswith("p"):
+        data = _pnm_bytes(grey if variant.startswith("pgm") else rgb, "plain" in variant, "comment" in variant)
+    else:
+        bio = io.BytesIO()
+        if variant == "tga-palette":
+            pil = Image.fromarray(rgb, "RGB").quantize(64)
+        else:
+            pil = {"tga-grey": Image.fromarray(grey, "L"), "tga-rgba": Image.fromarray(rgba, "RGBA"), "tga-rle-rgba": Image.fromarray(rgba, "RGBA")}.get(
+                variant, Image.fromarray(rgb, "RGB"))
+        pil.save(bio, format="TGA", compression="tga_rle" if "rle" in variant else None, orientation=1 if variant == "tga-bottom-up" else -1)
+        data = bytearray(bio.getvalue())
+        if variant == "tga-right-left":
+            data[17] |= 0x10  # columns stored right to left
+        data = bytes(data)
+    want = np.array(Image.open(io.BytesIO(data)).convert("RGBA"), dtype=np.uint8)
+    if variant == "tga-right-left":
+        assert np.array_equal(want[..., :3], rgb[:, ::-1])
+    got = _native_decode_jpeg(tmp_path, data, variant.replace("-", "_"))
+    assert got.shape == want.shape and np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("case", ["pnm-maxval", "pnm-short", "pnm-plain-range", "tga-short", "tga-rle-overrun", "tga-index", "tga-bits"])
+def test_malformed_pnm_and_tga_are_refused(tmp_path, case):
+    """truncated or inconsistent files must come back as the loader's error, never as a crash or an over-read"""
+    import io
+    from PIL import Image
+    rgb = np.arange(12 * 9 * 3, dtype=np.uint8).reshape(9, 12, 3)
+    bio = io.BytesIO()
+    if case == "pnm-maxval":
+        data = b"P6\n12 9\n1023\n" + rgb.tobytes() * 2
+    elif case == "pnm-short":
+        data = _pnm_bytes(rgb, False, False)[:-5]
+    elif case == "pnm-plain-range":
+        data = _pnm_bytes(rgb, True, False).replace(b" 7 ", b" 700 ", 1)
+    elif case == "tga-short":
+        Image.fromarray(rgb, "RGB").save(bio, format="TGA")
+        data = bio.getvalue()[:18 + 12 * 9 * 3 - 4]
+    elif case == "tga-rle-overrun":
+        Image.fromarray(np.zeros((9, 12, 3), np.uint8), "RGB").save(bio, format="TGA", compression="tga_rle")
+        data = bytearray(bio.getvalue()); data[18] = 0xff; data = bytes(data)  # a run past the first row is fine, past the image is not: make every packet 128 long
+        data = data[:18] + bytes([0xff, 0, 0, 0]) * 2  # 256 pixels into a 108-pixel image
+    elif case == "tga-index":
+        Image.fromarray(rgb, "RGB").quantize(8).save(bio, format="TGA")
+        data = bytearray(bio.getvalue()); data[5] = 2; data[6] = 0  # colour map declared 2 entries long: indices above fall outside
+        data = bytes(data[:18]) + bytes(data[18:18 + 2 * 3]) + bytes(data[18 + (len(data) - 18 - 12 * 9) :])
+    else:
+        Image.fromarray(rgb, "RGB").save(bio, format="TGA")
+        data = bytearray(bio.getvalue()); data[16] = 17; data = bytes(data)
+    with pytest.raises(H.HalaRendererError):
+        _native_decode_jpeg(tmp_path, data, case.replace("-", "_"))
+
+
+def _png_bytes(samples, ctype, depth, interlace, palette=None):
+    """a PNG writer for the tests (PIL does not write Adam7): `samples` is (h, w, channels) of integer sample values, filter type 0 on
+    every row of every pass"""
+    import struct
+    import zlib
+    h, w, ch = samples.shape
+
+    def chunk(kind, body):
+        return struct.pack(">I", len(body)) + kind + body + struct.pack(">I", zlib.crc32(kind + body))
+
+    def rows(block):
+        out = b""
+        for row in block:
+            if depth == 16:
+                body = row.astype(">u2").tobytes()
+            elif depth == 8:
+                body = row.astype(np.uint8).tobytes()
+            else:
+                bits = "".join(format(int(v), f"0{depth}b") for v in row.reshape(-1))
+                bits += "0" * (-len(bits) % 8)
+                body = bytes(int(bits[i:i + 8], 2) for i in range(0, len(bits), 8))
+            out += b"\x00" + body
+        return out
+
+    passes = [(0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)] if interlace else [(0, 0, 1, 1)]
+    raw = b"".join(rows(samples[y0::dy, x0::dx]) for x0, y0, dx, dy in passes if samples[y0::dy, x0::dx].size)
+    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 1 if interlace else 0))
+    if palette is not None:
+        out += chunk(b"PLTE", palette.astype(np.uint8).tobytes())
+    return out + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b"")
+
+
+@pytest.mark.parametrize("size", [(1, 1), (3, 2), (8, 8), (13, 11), (33, 5)])
+@pytest.mark.parametrize("kind", ["grey8", "grey1", "grey2", "grey4", "grey16", "grey-alpha", "rgb", "rgb16", "rgba", "palette8", "palette2"])
+def test_interlaced_png_decodes_like_pil(tmp_path, size, kind):
+    """Adam7 PNGs of every colour type and bit depth, at sizes with empty passes: byte-exact against the same pixels stored without
+    interlacing through the same decoder, and against PIL for the 8-bit kinds (whose RGBA conversion is the identity)"""
+    import io
+    from PIL import Image
+    w, h = size
+    rng = np.random.default_rng(w * 100 + h)
+    ctype, depth, ch = {"grey8": (0, 8, 1), "grey1": (0, 1, 1), "grey2": (0, 2, 1), "grey4": (0, 4, 1), "grey16": (0, 16, 1), "grey-alpha": (4, 8, 2), "rgb": (2, 8, 3),
+                        "rgb16": (2, 16, 3), "rgba": (6, 8, 4), "palette8": (3, 8, 1), "palette2": (3, 2, 1)}[kind]
+    palette = rng.integers(0, 256, ((1 << depth), 3)) if ctype == 3 else None
+    samples = rng.integers(0, 1 << depth, (h, w, ch))
+    plain = _native_decode_jpeg(tmp_path, _png_bytes(samples, ctype, depth, False, palette), "plain")
+    inter = _native_decode_jpeg(tmp_path, _png_bytes(samples, ctype, depth, True, palette), "adam7")
+    assert plain.shape == (h, w, 4) and np.array_equal(plain, inter)
+    if kind in ("grey8", "grey-alpha", "rgb", "rgba", "palette8", "palette2"):
+        want = np.array(Image.open(io.BytesIO(_png_bytes(samples, ctype, depth, True, palette))).convert("RGBA"), dtype=np.uint8)
+        assert np.array_equal(inter, want)
+
+
+def test_truncated_interlaced_png_is_refused(tmp_path):
+    samples = np.random.default_rng(0).integers(0, 256, (9, 10, 3))
+    good = _png_bytes(samples, 2, 8, True)
+    import struct
+    import zlib
+    # the same IDAT stream under a header that claims one more row: the inflated size no longer matches the seven passes
+    bad = bytearray(good)
+    bad[16 + 4:16 + 8] = struct.pack(">I", 10)
+    bad[29:33] = struct.pack(">I", zlib.crc32(bytes(bad[12:29])))
+    with pytest.raises(H.HalaRendererError):
+        _native_decode_jpeg(tmp_path, bytes(bad), "adam7_bad")
