@@ -140,7 +140,8 @@ struct Trav {
 };
 RT_DI void trav_begin(Trav& t, const RayPre& r, float tmax, uint32_t key) {
   t.r = r; t.tmax = tmax; t.key = key; t.tau[0] = t.tau[1] = t.tau[2] = 0u;
-  t.best.t = tmax; t.best.u = 0.0f; t.best.v = 0.0f; t.best.prim = kAbsent;
+  t.best.t = tmax == tmax ? tmax : -1.0f;  // a NaN limit admits no hit (the leaf-count compare of trav_step works on the bits of best.t)
+  t.best.u = 0.0f; t.best.v = 0.0f; t.best.prim = kAbsent;
   t.cur = 0; t.sp = 0; t.gid_base = 0u; t.shade_base = 0u;
 }
 
@@ -296,21 +297,26 @@ RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, 
     sort2kv(key[0], key[1], ref[0], ref[1]); sort2kv(key[2], key[3], ref[2], ref[3]); sort2kv(key[0], key[2], ref[0], ref[2]);
     sort2kv(key[1], key[3], ref[1], ref[3]); sort2kv(key[1], key[2], ref[1], ref[2]);
     // inner children: the nearest is visited next, the others go on the stack farthest first, each with its key so that
-    // a pop can drop entries that a hit found in the meantime has put out of reach
+    // a pop can drop entries that a hit found in the meantime has put out of reach.  The keys are sorted — leaves, inner children, misses —
+    // so "an inner child that was hit" is ONE signed compare (0x80000000 <= key < 0xffffffff), and such a child is pushed exactly when
+    // its left neighbour is an inner child as well (the leftmost one is `next`): three predicated stores, no loop-carried `next`
+    const bool in0 = (int32_t)key[0] < -1, in1 = (int32_t)key[1] < -1, in2 = (int32_t)key[2] < -1, in3 = (int32_t)key[3] < -1;
 #pragma unroll
-    for (int k = 3; k >= 0; --k) {
-      if (key[k] == kMissKey || !(key[k] & kInnerKey)) continue;
-      if (next != kAbsent) {
-        if (sp < kS) stack[sp * kTraverseThreads] = u32x2{next_key, next}; else spill[sp - kS] = make_uint2(next_key, next);
+    for (int k = 3; k >= 1; --k) {
+      const bool left = k == 3 ? in2 : (k == 2 ? in1 : in0), self = k == 3 ? in3 : (k == 2 ? in2 : in1);
+      if (self && left) {
+        if (sp < kS) stack[sp * kTraverseThreads] = u32x2{key[k], ref[k]}; else spill[sp - kS] = make_uint2(key[k], ref[k]);
         ++sp;
       }
-      next = ref[k]; next_key = key[k];
     }
+    next = in0 ? ref[0] : (in1 ? ref[1] : (in2 ? ref[2] : (in3 ? ref[3] : kAbsent)));
+    next_key = in0 ? key[0] : (in1 ? key[1] : (in2 ? key[2] : key[3]));
     // the leaves in reach as the node is entered (§4.4b): a sorted prefix.  Large trees: ALL of them are tested, none is culled by a
-    // sibling's hit; small (LDS-staged) trees: the lane tests them one after the other, nearest first, while they stay in reach
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (!(key[k] & kInnerKey) && key_tn(key[k]) <= best.t) nl = (uint32_t)k + 1u;
+    // sibling's hit; small (LDS-staged) trees: the lane tests them one after the other, nearest first, while they stay in reach.
+    // key_tn(key) <= best.t for a leaf key (sign bit clear, best.t > 0) is the unsigned compare key <= bits(best.t) | 3; inner children
+    // and misses have the sign bit and fail it: the prefix length is a sum of four compares
+    const uint32_t reach = __float_as_uint(best.t) | 3u;
+    nl = (uint32_t)(key[0] <= reach) + (uint32_t)(key[1] <= reach) + (uint32_t)(key[2] <= reach) + (uint32_t)(key[3] <= reach);
     if (COUNT && !STAGED) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) if ((uint32_t)k < nl) sc.tris += ((ref[k] >> 28) & 7u) + 1u;
