@@ -90,7 +90,9 @@ class Run:
             from hala_renderer_amd.dist import TileGather
             # one all-gather per finished frame: the accumulated colour image; albedo / normal are gathered the
             # same way when save_images needs them (TileGather(aovs=(0, 1, 2)))
-            self.gather = TileGather(r, local_rank, aovs=(r.ACCUM,))
+            # BENCH_EXCHANGE=torch hands the exchange to torch.distributed (same pipeline); unset: RCCL inside the library, and "torch" only
+            # if some rank cannot create the library's communicator (reported in config.exchange)
+            self.gather = TileGather(r, local_rank, aovs=(r.ACCUM,), exchange=os.environ.get("BENCH_EXCHANGE") or None)
         self.sync_gather = bool(os.environ.get("BENCH_SYNC_GATHER"))
 
     def step(self):
@@ -365,6 +367,7 @@ def main():
             "config": {"workload": cfg["name"], "resolution": [cfg["width"], cfg["height"]], "spp": cfg["spp"], "max_depth": cfg["max_depth"], "rr_depth": cfg["rr_depth"],
                        "triangles": int(info.triangle_count), "bvh_nodes": int(info.node_count), "bvh_build_ms": round(run.commit_ms, 2),
                        "parallelism": f"pixel-tile shard {TILE}x{TILE} of the one frame over {world} rank(s)" + (", one RCCL all-gather of the accumulated image per frame" if world > 1 else ""),
+                       **({"exchange": run.gather.exchange + (f" (fallback: {run.gather.fallback_reason})" if run.gather.fallback_reason else "")} if run.gather is not None else {}),
                        "rays_per_frame": int(rays_all / args.steps), "ms_per_frame": round(dt_all / args.steps * 1e3, 4),
                        "scaling_note": "N = 1 renders configs[3] (1920x1080); N > 1 renders configs[4] (3840x2160) strong-scaled; the single-GPU time of the 4K frame is under secondary.configs4_on_1_gpu"},
             "roofline": roof,

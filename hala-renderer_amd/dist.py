@@ -101,7 +101,7 @@ class TileGather:
     torch.distributed.all_gather on the host into the library's receive buffer, on the library's exchange stream.
     """
 
-    def __init__(self, renderer, device_index, aovs=(0, 1, 2), group=None):
+    def __init__(self, renderer, device_index, aovs=(0, 1, 2), group=None, exchange=None):
         import torch
         import torch.distributed as dist
         self.r, self.dist, self.group, self.torch, self.aovs = renderer, dist, group, torch, tuple(aovs)
@@ -110,26 +110,45 @@ class TileGather:
         self.rank = dist.get_rank(group)
         self._gloo = dist.get_backend(group) == "gloo"
         self._pending = False
-        if not self._gloo:
-            ident = [renderer.comm_unique_id() if self.rank == 0 else None]
+        # exchange: "library" = RCCL inside libhalart.so (the design); "torch" = the same pipeline with the exchange handed to
+        # torch.distributed.all_gather_into_tensor on the library's exchange stream (device to device, no host copy); "host" = gloo.
+        # "torch" is what every rank falls back to when ANY rank could not create the library's communicator: a frame must not be lost
+        # to a loader or version problem of the RCCL the process happens to find.
+        self.exchange = "host" if self._gloo else (exchange or "library")
+        self.fallback_reason = None
+        if self.exchange == "library":
+            import hala_renderer_amd as H
+            failed = None
+            try:
+                ident = [renderer.comm_unique_id() if self.rank == 0 else None]
+            except H.HalaRendererError as e:  # RCCL cannot be loaded: the same on every rank
+                ident, failed = [None], str(e)
             dist.broadcast_object_list(ident, src=0, group=group)
-            renderer.comm_init_rank(ident[0], self.rank, self.world)
+            if ident[0] is None:
+                failed = failed or "rank 0 could not create the ncclUniqueId"
+            else:
+                try:
+                    renderer.comm_init_rank(ident[0], self.rank, self.world)
+                except H.HalaRendererError as e:
+                    failed = str(e)
+            flag = torch.tensor([1 if failed else 0], dtype=torch.int32, device=self.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+            if int(flag.item()):
+                if not failed:
+                    renderer.comm_destroy()
+                self.exchange, self.fallback_reason = "torch", failed or "another rank could not create the library's communicator"
 
     def begin(self):
-        if not self._gloo:
+        if self.exchange == "library":
             self.r.tile_allgather_begin(self.aovs)
             return
         self.finish()
         self.r.tile_allgather_begin_external(self.aovs)  # stream-ordered snapshot of the tile buffers: the next frame may overwrite them
         self._pending = True
+        if self.exchange == "torch":  # enqueued right away, like the library's own collective: it runs beside the next frame
+            self._exchange_external()
 
-    def finish(self):
-        if not self._gloo:
-            self.r.tile_allgather_finish()
-            return
-        if not self._pending:
-            return
-        self._pending = False
+    def _exchange_external(self):
         torch = self.torch
         for which in self.aovs:
             sp, sn, rp, rn, stream = self.r.exchange_buffers(which)
@@ -141,11 +160,25 @@ class TileGather:
                 recv = torch.as_tensor(_DeviceView(rp, rn // 4), device=self.device)
                 if staged.data_ptr() != sp or recv.data_ptr() != rp:
                     raise RuntimeError("TileGather: torch copied an exchange buffer instead of aliasing it")
+                if self.exchange == "torch":
+                    self.dist.all_gather_into_tensor(recv, staged, group=self.group)  # stream-ordered on `ext`; nothing blocks the host
+                    continue
                 mine = staged.to("cpu")  # waits for the staging copy on this stream
                 parts = [torch.empty_like(mine) for _ in range(self.world)]
                 self.dist.all_gather(parts, mine, group=self.group)
                 recv.copy_(torch.cat(parts).to(self.device, non_blocking=False))
-            ext.synchronize()
+            if self.exchange == "host":
+                ext.synchronize()
+
+    def finish(self):
+        if self.exchange == "library":
+            self.r.tile_allgather_finish()
+            return
+        if not self._pending:
+            return
+        self._pending = False
+        if self.exchange == "host":
+            self._exchange_external()
         self.r.tile_allgather_finish()
 
     def gather(self):
@@ -153,5 +186,5 @@ class TileGather:
         self.finish()
 
     def close(self):
-        if not self._gloo:
+        if self.exchange == "library":
             self.r.comm_destroy()

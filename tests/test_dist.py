@@ -140,9 +140,12 @@ def test_rccl_pipelined_gather_is_stream_ordered(halart):
 
 
 @pytest.mark.gpu
-def test_tile_gather_over_torch_distributed_rccl(halart):
-    """what bench.py --gpus N does per rank, with the ranks this box has (one): torch.distributed (backend nccl = RCCL) only carries
-    rank 0's ncclUniqueId; TileGather then drives the library's own communicator"""
+@pytest.mark.parametrize("exchange", ["library", "torch", "fallback"])
+def test_tile_gather_over_torch_distributed_rccl(halart, exchange, monkeypatch):
+    """what bench.py --gpus N does per rank, with the ranks this box has (one).  "library": torch.distributed (backend nccl = RCCL) only
+    carries rank 0's ncclUniqueId; TileGather then drives the library's own communicator.  "torch": the library's pipeline with the
+    exchange handed to torch.distributed.all_gather_into_tensor on the library's exchange stream (device to device).  "fallback": the
+    library's communicator cannot be created (forced here) -> every rank agrees on "torch" and the frame still arrives."""
     import torch
     import torch.distributed as dist
     from hala_renderer_amd.dist import TileGather
@@ -154,11 +157,19 @@ def test_tile_gather_over_torch_distributed_rccl(halart):
         r = halart.HalaRenderer("rccl", 96, 64, 4, 2, False, False, False, 0)
         r.set_scene(scenes.cornell_box(aspect=1.5))
         r.commit()
-        g = TileGather(r, 0, aovs=(r.ACCUM,))
-        r.update_batch(2)
-        g.begin(); r.render(); g.finish()
-        r.wait_idle()
-        assert np.array_equal(_gathered(r, r.ACCUM, (64, 96, 4)), r.read_image(r.ACCUM))
+        if exchange == "fallback":
+            def refuse(*a, **k):
+                raise halart.HalaRendererError("forced: no communicator")
+            monkeypatch.setattr(type(r), "comm_init_rank", refuse)
+        g = TileGather(r, 0, aovs=(r.ACCUM,), exchange=None if exchange == "fallback" else exchange)
+        assert g.exchange == ("library" if exchange == "library" else "torch")
+        assert (g.fallback_reason is not None) == (exchange == "fallback")
+        for spp in (2, 3):  # two frames through the pipelined form: a stale receive buffer would show
+            r.reset_accumulation()
+            r.update_batch(spp)
+            g.begin(); r.render(); g.finish()
+            r.wait_idle()
+            assert np.array_equal(_gathered(r, r.ACCUM, (64, 96, 4)), r.read_image(r.ACCUM))
         g.close()
         r.close()
     finally:
