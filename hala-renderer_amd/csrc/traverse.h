@@ -236,7 +236,7 @@ RT_DI float lane_read(uint32_t src_lane_x4, float v) {  // v of lane src_lane_x4
 // One node visit of every lane that holds a ray (`has`); returns true when the lane's ray is finished (ANY: also on the first hit
 // inside (tmin, tmax)).  The whole wave must call it together: the large-scene variant (!STAGED) tests the leaves the wave's lanes
 // reached in this step COOPERATIVELY — the (ray, triangle) pairs are dealt out over all 64 lanes, whoever owns the ray:
-//   lane with nl leaves in reach -> nl items {leaf reference, owner lane} in the wave's LDS work list (position by a ballot prefix sum),
+//   lane with n leaves in reach -> n items {leaf reference, owner lane} in the wave's LDS work list (position by a ballot prefix sum),
 //                                   its best hit so far as a 64-bit key (t bits | triangle id) in its merge slot;
 //   consumer lane s of a pass     -> item s / 4, triangle s % 4 of that leaf: fetches the OWNER's ray with ds_bpermute, the triangle
 //                                   from memory, runs the one scalar triangle test, and merges an accepted hit into the owner's slot
@@ -258,7 +258,8 @@ RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, 
   HitRec& best = t.best;
   int sp = t.sp;
   uint32_t ref[4] = {kAbsent, kAbsent, kAbsent, kAbsent}, key[4] = {kMissKey, kMissKey, kMissKey, kMissKey};
-  uint32_t next = kAbsent, next_key = 0, nl = 0;
+  uint32_t next = kAbsent, next_key = 0;
+  bool lf[4] = {false, false, false, false};  // lf[k]: the k-th sorted child is a leaf in reach (a prefix: lf[k] implies lf[k - 1])
   if (has) {
     float4 q0, q1, q2, q3;
     if (STAGED) { const RT_LDS f32x4* p = lds.nodes + (size_t)t.cur * 4; q0 = ld4(p); q1 = ld4(p + 1); q2 = ld4(p + 2); q3 = ld4(p + 3); }
@@ -292,7 +293,9 @@ RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, 
       const float tf = hw_minf(hw_minf(tx.y, ty.y), hw_minf(tz.y, best.t));
       const bool hit = ref[c] != kAbsent && tn <= tf * 1.0000004f;
       const uint32_t inner_bit = INST ? ((!(ref[c] >> 31) || (ref[c] >> 28) == 0xFu) ? kInnerKey : 0u) : (~ref[c] & kInnerKey);  // instance leaves wait like inner children
-      key[c] = hit ? ((__float_as_uint(tn) & ~3u) | (uint32_t)c | inner_bit) : kMissKey;
+      uint32_t kc;  // (tn & ~3) | (slot | inner bit): one v_and_or_b32 (hipcc emits v_and + v_or for the C form)
+      asm("v_and_or_b32 %0, %1, -4, %2" : "=v"(kc) : "v"(__float_as_uint(tn)), "v"((uint32_t)c | inner_bit));
+      key[c] = hit ? kc : kMissKey;
     }
     sort2kv(key[0], key[1], ref[0], ref[1]); sort2kv(key[2], key[3], ref[2], ref[3]); sort2kv(key[0], key[2], ref[0], ref[2]);
     sort2kv(key[1], key[3], ref[1], ref[3]); sort2kv(key[1], key[2], ref[1], ref[2]);
@@ -311,16 +314,20 @@ RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, 
     }
     next = in0 ? ref[0] : (in1 ? ref[1] : (in2 ? ref[2] : (in3 ? ref[3] : kAbsent)));
     next_key = in0 ? key[0] : (in1 ? key[1] : (in2 ? key[2] : key[3]));
-    // the leaves in reach as the node is entered (§4.4b): a sorted prefix.  Large trees: ALL of them are tested, none is culled by a
-    // sibling's hit; small (LDS-staged) trees: the lane tests them one after the other, nearest first, while they stay in reach.
-    // key_tn(key) <= best.t for a leaf key (sign bit clear, best.t > 0) is the unsigned compare key <= bits(best.t) | 3; inner children
-    // and misses have the sign bit and fail it: the prefix length is a sum of four compares
-    const uint32_t reach = __float_as_uint(best.t) | 3u;
-    nl = (uint32_t)(key[0] <= reach) + (uint32_t)(key[1] <= reach) + (uint32_t)(key[2] <= reach) + (uint32_t)(key[3] <= reach);
-    if (COUNT && !STAGED) {
+  }
+  // the leaves in reach as the node is entered (§4.4b): a sorted prefix.  Large trees: ALL of them are tested, none is culled by a
+  // sibling's hit; small (LDS-staged) trees: the lane tests them one after the other, nearest first, while they stay in reach.
+  // key_tn(key) <= best.t for a leaf key (sign bit clear, best.t > 0) is the unsigned compare key <= bits(best.t) | 3; inner children
+  // and misses have the sign bit and fail it: four compares whose results stay lane masks — the ballots, the item positions and the
+  // predicates of the leaf pass below are scalar work on them, the number of leaves is never formed as a vector value.  (Outside the
+  // `has` block on purpose: a bool that crosses that join would be kept as a 0 / 1 byte in a register; a lane without a ray holds four
+  // miss keys, 0xffffffff > 0.)
+  const uint32_t reach = has ? (__float_as_uint(best.t) | 3u) : 0u;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) if ((uint32_t)k < nl) sc.tris += ((ref[k] >> 28) & 7u) + 1u;
-    }
+  for (int k = 0; k < 4; ++k) lf[k] = key[k] <= reach;  // a bare compare: its ballot is the compare's own lane mask
+  if (COUNT && !STAGED) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (lf[k]) sc.tris += ((ref[k] >> 28) & 7u) + 1u;
   }
   bool found = false;  // ANY: an occluder was hit
   if (STAGED) {
@@ -329,7 +336,7 @@ RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, 
     // triangle pair costs one packed test), nearest first
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      if ((uint32_t)k >= nl) break;
+      if (!lf[k]) break;
       if (!(key_tn(key[k]) <= best.t)) break;  // small trees (§4.4b): a hit in a nearer leaf culls the leaves behind it (sorted: all of them)
       if (COUNT) {
         sc.tris += ((ref[k] >> 28) & 7u) + 1u;
@@ -341,17 +348,21 @@ RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, 
     }
   } else {
     const uint32_t lane = threadIdx.x & 63u;
-    const unsigned long long b0 = __ballot((nl & 1u) != 0u), b1 = __ballot((nl & 2u) != 0u), b2 = __ballot((nl & 4u) != 0u);
-    if ((b0 | b1 | b2) != 0ull) {  // wave-uniform: some lane reached a leaf in this step
-      const uint32_t pre = mbcnt64(b0) + 2u * mbcnt64(b1) + 4u * mbcnt64(b2);
-      const uint32_t total = (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1) + 4u * (uint32_t)__popcll(b2);  // leaf items of the wave
+    const unsigned long long m0 = __builtin_amdgcn_ballot_w64(lf[0]), m1 = __builtin_amdgcn_ballot_w64(lf[1]), m2 = __builtin_amdgcn_ballot_w64(lf[2]),
+                             m3 = __builtin_amdgcn_ballot_w64(lf[3]);  // (the builtin on a bool: HIP's __ballot compares an int with 0 in the vector unit)
+    if (m0 != 0ull) {  // wave-uniform: some lane reached a leaf in this step (m0 covers m1, m2, m3)
+      // items of the lanes below this one: one mbcnt chain over the four masks (the accumulator operand of v_mbcnt is free)
+      const uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(m3 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m3,
+                           __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2,
+                           __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, mbcnt64(m0)))))));
+      const uint32_t total = (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1) + (uint32_t)__popcll(m2) + (uint32_t)__popcll(m3);  // leaf items of the wave
       RT_LDS u32x2* items = lds.items;
       RT_LDS u32x4* slots = lds.slots;
 #pragma unroll
       for (int k = 0; k < 4; ++k)
-        if ((uint32_t)k < nl) items[pre + (uint32_t)k] = u32x2{ref[k], lane};
-      if (nl) slots[lane] = (ANY && ALPHA) ? u32x4{best.prim, 0u, 0u, 0u}  // any-hit: blocked flag | optical depth gathered in this step
-                                           : u32x4{best.prim, __float_as_uint(best.t), __float_as_uint(best.u), __float_as_uint(best.v)};
+        if (lf[k]) items[pre + (uint32_t)k] = u32x2{ref[k], lane};
+      if (lf[0]) slots[lane] = (ANY && ALPHA) ? u32x4{best.prim, 0u, 0u, 0u}  // any-hit: blocked flag | optical depth gathered in this step
+                                              : u32x4{best.prim, __float_as_uint(best.t), __float_as_uint(best.u), __float_as_uint(best.v)};
       // One wave, one instruction stream: its LDS operations execute in program order, so a lane sees what another lane of the wave
       // wrote by an earlier instruction.  The fences only keep the COMPILER from moving or forwarding LDS accesses across the phases.
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -417,7 +428,7 @@ RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, 
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
-      if (nl) {
+      if (lf[0]) {
         const u32x4 w4 = slots[lane];
         if (ANY) {
           found = w4.x != kAbsent;
