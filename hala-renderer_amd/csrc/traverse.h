@@ -387,14 +387,12 @@ RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, 
           if (valid) sc.leaf_lanes++;
           if (m && (uint32_t)__ffsll((long long)m) - 1u == lane) sc.leaf_passes++;
         }
-        unsigned long long mine = ~0ull;
-        float tu = 0.0f, tv = 0.0f;
         RT_LDS unsigned long long* okey = (RT_LDS unsigned long long*)(slots + owner);
         if (valid) {
           const float4* p = tris + (size_t)((leaf & 0x0fffffffu) + j) * 3;
           const float4 a = p[0], b = p[1], c = p[2];
           asm volatile("" ::"v"(a.w));  // the id travels with v0 (one dwordx4), not as a dependent dword load inside the hit branch
-          float tt, det;
+          float tt, tu, tv, det;
           if (tri_test_od(o, d, a, b, c, &tt, &tu, &tv, &det) && tt > tmin) {
             if (ANY) {  // any blocking triangle: the owner's prim field leaves kAbsent
               if (tt < tlim) {
@@ -416,15 +414,14 @@ RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, 
               }
             }
             else {
-              mine = ((unsigned long long)__float_as_uint(tt) << 32) | (unsigned long long)hit_encode(__float_as_uint(a.w) + gbase, __float_as_uint(c.w));  // id << 3 | shading kind
+              const unsigned long long mine = ((unsigned long long)__float_as_uint(tt) << 32) | (unsigned long long)hit_encode(__float_as_uint(a.w) + gbase, __float_as_uint(c.w));  // id << 3 | shading kind
               __hip_atomic_fetch_min(okey, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+              // the merge that stands publishes its barycentrics (keys are unique: one triangle, one item).  Still inside the branch: every
+              // lane that merged executes the ds_min_u64 in one instruction, the read-back in the next — the LDS works them off in that order
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+              if (*okey == mine) ((RT_LDS u32x2*)okey)[1] = u32x2{__float_as_uint(tu), __float_as_uint(tv)};
             }
           }
-        }
-        if (!ANY) {
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-          // the merge that stands publishes its barycentrics (keys are unique: one triangle, one item)
-          if (mine != ~0ull && *okey == mine) ((RT_LDS u32x2*)okey)[1] = u32x2{__float_as_uint(tu), __float_as_uint(tv)};
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
