@@ -386,7 +386,8 @@ RT_DI float half_area(const Box6& b) {
 __global__ void __launch_bounds__(256) k_collapse_level(const uint32_t* __restrict__ root_of, const uint32_t* __restrict__ level, uint32_t bound,
                                                          const uint32_t* __restrict__ left, const uint32_t* __restrict__ right,
                                                          const uint32_t* __restrict__ keep, const Box6* __restrict__ node_box,
-                                                         uint4* __restrict__ refs4, uint32_t* __restrict__ cnt) {
+                                                         uint4* __restrict__ refs4, uint32_t* __restrict__ cnt,
+                                                         const uint32_t* __restrict__ first, const uint32_t* __restrict__ last, int order_mode) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= bound) return;
   const uint32_t base = level[0], size = level[1];
@@ -411,6 +412,22 @@ __global__ void __launch_bounds__(256) k_collapse_level(const uint32_t* __restri
       c[pick] = left[r]; c[pick + 1] = right[r];
       ++n;
     }
+  }
+  // Slot order = the order in which an any-hit ray of a large tree takes the inner children (RENDER_SPEC 4.4c); every other ray sorts
+  // the children by distance (the slot only breaks ties)
+  if (order_mode != 0) {
+    float w[4];
+    for (int k = 0; k < n; ++k) {
+      const uint32_t r = c[k];
+      if ((r & kLeafBit) || !keep[r]) { w[k] = -1.0f; continue; }
+      const float a = half_area(node_box[r]), cntf = (float)(last[r] - first[r] + 1u);
+      w[k] = order_mode == 1 ? a : (order_mode == 2 ? 1.0f / (a + 1e-30f) : (order_mode == 3 ? cntf : (order_mode == 4 ? cntf / (a + 1e-30f) : (a + 1e-30f) / cntf)));
+    }
+    for (int a = 1; a < n; ++a)  // insertion sort, descending weight, stable
+      for (int b = a; b > 0 && w[b] > w[b - 1]; --b) {
+        const float tw = w[b]; w[b] = w[b - 1]; w[b - 1] = tw;
+        const uint32_t tc = c[b]; c[b] = c[b - 1]; c[b - 1] = tc;
+      }
   }
   refs4[base + j] = make_uint4(c[0], c[1], c[2], c[3]);
   uint32_t inner = 0;
@@ -994,6 +1011,10 @@ static std::string fit_and_emit(BvhBuffers& b, BvhTopology& t, hipStream_t s) {
     constexpr uint32_t kMaxLevels = 96;
     uint32_t look_every = 8;
     if (b.opt.collapse_look_every) look_every = b.opt.collapse_look_every;
+    // slots by descending surface area of the inner children: configs[3] 9.09 instead of 9.40 node visits per connection ray (in-order
+    // slots), 3.40 instead of 3.45 ms per frame in the shadow passes; ascending area / triangle count / density: 9.60 / 9.48 / 9.36
+    int order_mode = 1;
+    if (const char* ev = tune_env("HALART_CHILD_ORDER")) order_mode = atoi(ev);
     DevBuf level, bases;
     if (!(e = level.alloc(16)).empty()) return e;
     if (!(e = bases.alloc(kMaxLevels * 4)).empty()) return e;
@@ -1005,7 +1026,8 @@ static std::string fit_and_emit(BvhBuffers& b, BvhTopology& t, hipStream_t s) {
       for (uint32_t k = 0; k < look_every; ++k) {
         const uint32_t bd = (uint32_t)std::min<unsigned long long>(bound, ni);
         hipLaunchKernelGGL(k_collapse_level, dim3(nblk(bd)), dim3(256), 0, s, t.root_of.as<uint32_t>(), level.as<uint32_t>(), bd, t.left.as<uint32_t>(),
-                           t.right.as<uint32_t>(), t.keep.as<uint32_t>(), t.node_box.as<Box6>(), t.refs4.as<uint4>(), t.cnt.as<uint32_t>());
+                           t.right.as<uint32_t>(), t.keep.as<uint32_t>(), t.node_box.as<Box6>(), t.refs4.as<uint4>(), t.cnt.as<uint32_t>(),
+                           t.first.as<uint32_t>(), t.last.as<uint32_t>(), order_mode);
         size_t tb = tmp_bytes;
         HIP_TRY(rocprim::exclusive_scan(tmp.p, tb, t.cnt.as<uint32_t>(), t.off.as<uint32_t>(), 0u, bd, rocprim::plus<uint32_t>(), s));
         hipLaunchKernelGGL(k_scatter_level, dim3(nblk(bd)), dim3(256), 0, s, t.root_of.as<uint32_t>(), level.as<uint32_t>(), t.refs4.as<uint4>(),

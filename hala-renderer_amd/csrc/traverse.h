@@ -253,6 +253,7 @@ template <bool ANY, bool COUNT, bool STAGED, bool ALPHA, bool INST = false>
 RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, Trav& t, bool has, StepCounters& sc) {
   static_assert(!(INST && STAGED), "LDS-staged trees have no instance levels");
   constexpr int kS = stack_lds<STAGED, INST>();
+  constexpr bool kSlotOrder = ANY && !STAGED;  // RENDER_SPEC 4.4c
   RT_LDS u32x2* stack = lds.stack + threadIdx.x;
   const RayPre& r = t.r;
   HitRec& best = t.best;
@@ -297,17 +298,22 @@ RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, 
       asm("v_and_or_b32 %0, %1, -4, %2" : "=v"(kc) : "v"(__float_as_uint(tn)), "v"((uint32_t)c | inner_bit));
       key[c] = hit ? kc : kMissKey;
     }
-    sort2kv(key[0], key[1], ref[0], ref[1]); sort2kv(key[2], key[3], ref[2], ref[3]); sort2kv(key[0], key[2], ref[0], ref[2]);
-    sort2kv(key[1], key[3], ref[1], ref[3]); sort2kv(key[1], key[2], ref[1], ref[2]);
-    // inner children: the nearest is visited next, the others go on the stack farthest first, each with its key so that
-    // a pop can drop entries that a hit found in the meantime has put out of reach.  The keys are sorted — leaves, inner children, misses —
-    // so "an inner child that was hit" is ONE signed compare (0x80000000 <= key < 0xffffffff), and such a child is pushed exactly when
-    // its left neighbour is an inner child as well (the leftmost one is `next`): three predicated stores, no loop-carried `next`
+    // Any-hit rays on large trees (kSlotOrder): nothing they find moves their limit, so no order of the children saves them a visit that
+    // another order would not have cost — they take the children in slot order and skip the sort (25 of the ~290 vector instructions of
+    // a node step).  All other rays: leaves first, nearest first, then the inner children, nearest first, then the misses.
+    if (!kSlotOrder) {
+      sort2kv(key[0], key[1], ref[0], ref[1]); sort2kv(key[2], key[3], ref[2], ref[3]); sort2kv(key[0], key[2], ref[0], ref[2]);
+      sort2kv(key[1], key[3], ref[1], ref[3]); sort2kv(key[1], key[2], ref[1], ref[2]);
+    }
+    // inner children: the first of them (sorted: the nearest) is visited next, the others go on the stack last first, each with its key
+    // so that a pop can drop entries that a hit found in the meantime has put out of reach.  "An inner child that was hit" is ONE signed
+    // compare (0x80000000 <= key < 0xffffffff); such a child is pushed exactly when an inner child stands to its left (the leftmost one
+    // is `next`): three predicated stores, no loop-carried `next`
     const bool in0 = (int32_t)key[0] < -1, in1 = (int32_t)key[1] < -1, in2 = (int32_t)key[2] < -1, in3 = (int32_t)key[3] < -1;
 #pragma unroll
     for (int k = 3; k >= 1; --k) {
-      const bool left = k == 3 ? in2 : (k == 2 ? in1 : in0), self = k == 3 ? in3 : (k == 2 ? in2 : in1);
-      if (self && left) {
+      const bool left = k == 3 ? (in0 | in1 | in2) : (k == 2 ? (in0 | in1) : in0), self = k == 3 ? in3 : (k == 2 ? in2 : in1);
+      if (self & left) {
         if (sp < kS) stack[sp * kTraverseThreads] = u32x2{key[k], ref[k]}; else spill[sp - kS] = make_uint2(key[k], ref[k]);
         ++sp;
       }
@@ -350,7 +356,7 @@ RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, 
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long m0 = __builtin_amdgcn_ballot_w64(lf[0]), m1 = __builtin_amdgcn_ballot_w64(lf[1]), m2 = __builtin_amdgcn_ballot_w64(lf[2]),
                              m3 = __builtin_amdgcn_ballot_w64(lf[3]);  // (the builtin on a bool: HIP's __ballot compares an int with 0 in the vector unit)
-    if (m0 != 0ull) {  // wave-uniform: some lane reached a leaf in this step (m0 covers m1, m2, m3)
+    if ((kSlotOrder ? (m0 | m1 | m2 | m3) : m0) != 0ull) {  // wave-uniform: some lane reached a leaf in this step (sorted: m0 covers m1, m2, m3)
       // items of the lanes below this one: one mbcnt chain over the four masks (the accumulator operand of v_mbcnt is free)
       const uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(m3 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m3,
                            __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2,
@@ -358,10 +364,20 @@ RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, 
       const uint32_t total = (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1) + (uint32_t)__popcll(m2) + (uint32_t)__popcll(m3);  // leaf items of the wave
       RT_LDS u32x2* items = lds.items;
       RT_LDS u32x4* slots = lds.slots;
+      if (!kSlotOrder) {  // the leaves in reach are a prefix of the sorted children: the lane's k-th item is child k
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (lf[k]) items[pre + (uint32_t)k] = u32x2{ref[k], lane};
-      if (lf[0]) slots[lane] = (ANY && ALPHA) ? u32x4{best.prim, 0u, 0u, 0u}  // any-hit: blocked flag | optical depth gathered in this step
+        for (int k = 0; k < 4; ++k)
+          if (lf[k]) items[pre + (uint32_t)k] = u32x2{ref[k], lane};
+      } else {
+        uint32_t pos = pre;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (lf[k]) items[pos] = u32x2{ref[k], lane};
+          pos += lf[k] ? 1u : 0u;
+        }
+      }
+      const bool any_leaf = kSlotOrder ? (lf[0] | lf[1] | lf[2] | lf[3]) : lf[0];
+      if (any_leaf) slots[lane] = (ANY && ALPHA) ? u32x4{best.prim, 0u, 0u, 0u}  // any-hit: blocked flag | optical depth gathered in this step
                                               : u32x4{best.prim, __float_as_uint(best.t), __float_as_uint(best.u), __float_as_uint(best.v)};
       // One wave, one instruction stream: its LDS operations execute in program order, so a lane sees what another lane of the wave
       // wrote by an earlier instruction.  The fences only keep the COMPILER from moving or forwarding LDS accesses across the phases.
@@ -425,7 +441,7 @@ RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, 
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
-      if (lf[0]) {
+      if (any_leaf) {
         const u32x4 w4 = slots[lane];
         if (ANY) {
           found = w4.x != kAbsent;

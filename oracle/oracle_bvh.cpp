@@ -554,7 +554,9 @@ static inline bool traverse4(const Node4* nodes, const Tri* tris, bool small_tre
       e[ci].key = hit ? ((f_bits(tn) & ~3u) | (uint32_t)ci) : 0xffffffffu;
       e[ci].ref = n.ref[ci];
     }
-    std::sort(e, e + 4, [](const Entry& a, const Entry& b) { return a.key < b.key; });  // keys of hits are distinct (slot bits)
+    // RENDER_SPEC 4.4c: an any-hit ray on a large tree takes the children in slot order — nothing it finds moves its limit, so no order
+    // spares it a visit; every other ray: nearest first
+    if (!(ANY && !small_tree)) std::sort(e, e + 4, [](const Entry& a, const Entry& b) { return a.key < b.key; });  // keys of hits are distinct (slot bits)
     for (int i = 0; i < 4; ++i) innerish[i] = !(e[i].ref & 0x80000000u) || (refs && is_inst_leaf(e[i].ref));
     // inner children (and instance leaves): nearest next, the others stacked farthest first with their keys
     uint32_t next = kAbsent, next_key = 0;
@@ -569,7 +571,8 @@ static inline bool traverse4(const Node4* nodes, const Tri* tris, bool small_tre
     // ray stops at the first accepted triangle.
     const float reach = best->t;
     bool occluded = false;
-    for (int i = 0; i < 4 && e[i].key != 0xffffffffu; ++i) {
+    for (int i = 0; i < 4; ++i) {
+      if (e[i].key == 0xffffffffu) continue;
       uint32_t rf = e[i].ref;
       if (innerish[i]) continue;
       if (!(key_tn(e[i].key) <= (small_tree ? best->t : reach))) continue;

@@ -4,8 +4,6 @@
 LIB=${1:-hala-renderer_amd/lib/libhalart.so}
 PAT=${2:-.}
 TMP=$(mktemp -d)
-/opt/rocm/lib/llvm/bin/clang-offload-bundler --list --type=o --input=$LIB >/dev/null 2>&1
-/opt/rocm/lib/llvm/bin/llvm-objdump --offloading $LIB >/dev/null 2>&1
 # the fat binary holds one code object per translation unit: extract them all
 python3 - "$LIB" "$TMP" <<'PY'
 import sys, re
