@@ -293,33 +293,40 @@ RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, 
       const float tn = hw_maxf(hw_maxf(tx.x, ty.x), hw_maxf(tz.x, r.tmin));
       const float tf = hw_minf(hw_minf(tx.y, ty.y), hw_minf(tz.y, best.t));
       const bool hit = ref[c] != kAbsent && tn <= tf * 1.0000004f;
+      if (kSlotOrder) { ref[c] = hit ? ref[c] : kAbsent; continue; }  // no keys (4.4c): a child that was missed is an absent child from here on
       const uint32_t inner_bit = INST ? ((!(ref[c] >> 31) || (ref[c] >> 28) == 0xFu) ? kInnerKey : 0u) : (~ref[c] & kInnerKey);  // instance leaves wait like inner children
       uint32_t kc;  // (tn & ~3) | (slot | inner bit): one v_and_or_b32 (hipcc emits v_and + v_or for the C form)
       asm("v_and_or_b32 %0, %1, -4, %2" : "=v"(kc) : "v"(__float_as_uint(tn)), "v"((uint32_t)c | inner_bit));
       key[c] = hit ? kc : kMissKey;
     }
-    // Any-hit rays on large trees (kSlotOrder): nothing they find moves their limit, so no order of the children saves them a visit that
-    // another order would not have cost — they take the children in slot order and skip the sort (25 of the ~290 vector instructions of
-    // a node step).  All other rays: leaves first, nearest first, then the inner children, nearest first, then the misses.
+    // Any-hit rays on large trees (kSlotOrder, RENDER_SPEC 4.4c): nothing they find moves their limit, so no order of the children saves
+    // them a visit that another order would not have cost, and a child that passed the slab test never needs a second look: they take
+    // the children in slot order, without sort and without keys (45 of the ~290 vector instructions of a node step).  All other rays:
+    // leaves first, nearest first, then the inner children, nearest first, then the misses.
     if (!kSlotOrder) {
       sort2kv(key[0], key[1], ref[0], ref[1]); sort2kv(key[2], key[3], ref[2], ref[3]); sort2kv(key[0], key[2], ref[0], ref[2]);
       sort2kv(key[1], key[3], ref[1], ref[3]); sort2kv(key[1], key[2], ref[1], ref[2]);
     }
     // inner children: the first of them (sorted: the nearest) is visited next, the others go on the stack last first, each with its key
     // so that a pop can drop entries that a hit found in the meantime has put out of reach.  "An inner child that was hit" is ONE signed
-    // compare (0x80000000 <= key < 0xffffffff); such a child is pushed exactly when an inner child stands to its left (the leftmost one
-    // is `next`): three predicated stores, no loop-carried `next`
-    const bool in0 = (int32_t)key[0] < -1, in1 = (int32_t)key[1] < -1, in2 = (int32_t)key[2] < -1, in3 = (int32_t)key[3] < -1;
+    // compare (0x80000000 <= key < 0xffffffff; slot order: a reference without the leaf bit, or an instance leaf); such a child is pushed
+    // exactly when an inner child stands to its left (the leftmost one is `next`): three predicated stores, no loop-carried `next`
+    bool in[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      in[k] = !kSlotOrder ? (int32_t)key[k] < -1 : (INST ? (int32_t)ref[k] >= (int32_t)kInstLeafTag && ref[k] < kExitRef : (int32_t)ref[k] >= 0);
+    const bool in0 = in[0], in1 = in[1], in2 = in[2], in3 = in[3];
 #pragma unroll
     for (int k = 3; k >= 1; --k) {
       const bool left = k == 3 ? (in0 | in1 | in2) : (k == 2 ? (in0 | in1) : in0), self = k == 3 ? in3 : (k == 2 ? in2 : in1);
       if (self & left) {
-        if (sp < kS) stack[sp * kTraverseThreads] = u32x2{key[k], ref[k]}; else spill[sp - kS] = make_uint2(key[k], ref[k]);
+        const uint32_t ek = kSlotOrder ? 0u : key[k];
+        if (sp < kS) stack[sp * kTraverseThreads] = u32x2{ek, ref[k]}; else spill[sp - kS] = make_uint2(ek, ref[k]);
         ++sp;
       }
     }
     next = in0 ? ref[0] : (in1 ? ref[1] : (in2 ? ref[2] : (in3 ? ref[3] : kAbsent)));
-    next_key = in0 ? key[0] : (in1 ? key[1] : (in2 ? key[2] : key[3]));
+    if (!kSlotOrder) next_key = in0 ? key[0] : (in1 ? key[1] : (in2 ? key[2] : key[3]));
   }
   // the leaves in reach as the node is entered (§4.4b): a sorted prefix.  Large trees: ALL of them are tested, none is culled by a
   // sibling's hit; small (LDS-staged) trees: the lane tests them one after the other, nearest first, while they stay in reach.
@@ -327,10 +334,11 @@ RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, 
   // and misses have the sign bit and fail it: four compares whose results stay lane masks — the ballots, the item positions and the
   // predicates of the leaf pass below are scalar work on them, the number of leaves is never formed as a vector value.  (Outside the
   // `has` block on purpose: a bool that crosses that join would be kept as a 0 / 1 byte in a register; a lane without a ray holds four
-  // miss keys, 0xffffffff > 0.)
+  // miss keys, 0xffffffff > 0 — slot order: four absent references.)
   const uint32_t reach = has ? (__float_as_uint(best.t) | 3u) : 0u;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) lf[k] = key[k] <= reach;  // a bare compare: its ballot is the compare's own lane mask
+  for (int k = 0; k < 4; ++k)  // a bare compare: its ballot is the compare's own lane mask
+    lf[k] = !kSlotOrder ? key[k] <= reach : (INST ? (int32_t)ref[k] < (int32_t)kInstLeafTag : (int32_t)ref[k] < -1);
   if (COUNT && !STAGED) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) if (lf[k]) sc.tris += ((ref[k] >> 28) & 7u) + 1u;
@@ -454,14 +462,14 @@ RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, 
   }
   if (ANY && found) return true;  // (best.prim != kAbsent: the blocker)
   // go on with the nearest inner child if it is still in reach, else with the first stack entry that is
-  if (next != kAbsent && !(key_tn(next_key) <= best.t)) next = kAbsent;
+  if (!kSlotOrder && next != kAbsent && !(key_tn(next_key) <= best.t)) next = kAbsent;
   if (!INST) {
     while (next == kAbsent) {
       if (sp == 0) return true;
       --sp;
       uint2 e;
       if (sp < kS) { const u32x2 v = stack[sp * kTraverseThreads]; e = make_uint2(v.x, v.y); } else e = spill[sp - kS];
-      if (key_tn(e.x) <= best.t) next = e.y;
+      if (kSlotOrder || key_tn(e.x) <= best.t) next = e.y;
     }
   } else {
     auto pop = [&]() -> uint2 {
@@ -484,7 +492,7 @@ RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, 
           t.gid_base = 0u; t.shade_base = 0u;
           continue;
         }
-        if (key_tn(e.x) <= best.t) next = e.y;
+        if (kSlotOrder || key_tn(e.x) <= best.t) next = e.y;
         continue;
       }
       if (is_inst_leaf(next)) {  // enter the instance (RENDER_SPEC 4.5)

@@ -531,6 +531,7 @@ static inline bool traverse4(const Node4* nodes, const Tri* tris, bool small_tre
   uint32_t cur = 0;
   RayPre r = r_world;
   uint32_t gid_base = 0;
+  const bool slot_order = ANY && !small_tree;
   for (;;) {
     const Node4& n = nodes[cur];
     if (c) c->nodes++;
@@ -555,8 +556,8 @@ static inline bool traverse4(const Node4* nodes, const Tri* tris, bool small_tre
       e[ci].ref = n.ref[ci];
     }
     // RENDER_SPEC 4.4c: an any-hit ray on a large tree takes the children in slot order — nothing it finds moves its limit, so no order
-    // spares it a visit; every other ray: nearest first
-    if (!(ANY && !small_tree)) std::sort(e, e + 4, [](const Entry& a, const Entry& b) { return a.key < b.key; });  // keys of hits are distinct (slot bits)
+    // spares it a visit, and a child that passed the slab test is never looked at again; every other ray: nearest first
+    if (!slot_order) std::sort(e, e + 4, [](const Entry& a, const Entry& b) { return a.key < b.key; });  // keys of hits are distinct (slot bits)
     for (int i = 0; i < 4; ++i) innerish[i] = !(e[i].ref & 0x80000000u) || (refs && is_inst_leaf(e[i].ref));
     // inner children (and instance leaves): nearest next, the others stacked farthest first with their keys
     uint32_t next = kAbsent, next_key = 0;
@@ -575,20 +576,20 @@ static inline bool traverse4(const Node4* nodes, const Tri* tris, bool small_tre
       if (e[i].key == 0xffffffffu) continue;
       uint32_t rf = e[i].ref;
       if (innerish[i]) continue;
-      if (!(key_tn(e[i].key) <= (small_tree ? best->t : reach))) continue;
+      if (!slot_order && !(key_tn(e[i].key) <= (small_tree ? best->t : reach))) continue;  // 4.4c: a child that passed the slab test is not looked at again
       uint32_t count = ((rf >> 28) & 7u) + 1u;
       if (c) c->tris += count;
       if (!occluded && leaf_test<ANY>(tris, r, tmax, ax, best, rf & 0x0fffffffu, count, gid_base)) occluded = true;
       if (occluded && small_tree) return true;
     }
     if (occluded) return true;
-    if (next != kAbsent && !(key_tn(next_key) <= best->t)) next = kAbsent;
+    if (!slot_order && next != kAbsent && !(key_tn(next_key) <= best->t)) next = kAbsent;
     for (;;) {
       if (next == kAbsent) {
         if (sp == 0) return best->prim != ORC_NONE;
         Entry t = stack[--sp];
         if (t.ref == kExit) { r = r_world; gid_base = 0; continue; }
-        if (key_tn(t.key) <= best->t) next = t.ref;
+        if (slot_order || key_tn(t.key) <= best->t) next = t.ref;
         continue;
       }
       if (refs && is_inst_leaf(next)) {
