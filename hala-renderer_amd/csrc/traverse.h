@@ -385,8 +385,11 @@ RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, 
         }
       }
       const bool any_leaf = kSlotOrder ? (lf[0] | lf[1] | lf[2] | lf[3]) : lf[0];
-      if (any_leaf) slots[lane] = (ANY && ALPHA) ? u32x4{best.prim, 0u, 0u, 0u}  // any-hit: blocked flag | optical depth gathered in this step
-                                              : u32x4{best.prim, __float_as_uint(best.t), __float_as_uint(best.u), __float_as_uint(best.v)};
+      if (any_leaf) {
+        if (ANY && !ALPHA) *(RT_LDS uint32_t*)(slots + lane) = kAbsent;  // any-hit: only the "blocked by" word of the slot is used (a ray in flight is not blocked yet)
+        else slots[lane] = ANY ? u32x4{kAbsent, 0u, 0u, 0u}  // + the optical depth gathered in this step
+                               : u32x4{best.prim, __float_as_uint(best.t), __float_as_uint(best.u), __float_as_uint(best.v)};
+      }
       // One wave, one instruction stream: its LDS operations execute in program order, so a lane sees what another lane of the wave
       // wrote by an earlier instruction.  The fences only keep the COMPILER from moving or forwarding LDS accesses across the phases.
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -450,7 +453,8 @@ RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
       if (any_leaf) {
-        const u32x4 w4 = slots[lane];
+        u32x4 w4;
+        if (ANY && !ALPHA) w4.x = *(RT_LDS uint32_t*)(slots + lane); else w4 = slots[lane];
         if (ANY) {
           found = w4.x != kAbsent;
           if (found) best.prim = w4.x;  // the blocker's BVH-order index
