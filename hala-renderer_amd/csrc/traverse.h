@@ -253,7 +253,7 @@ template <bool ANY, bool COUNT, bool STAGED, bool ALPHA, bool INST = false>
 RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, Trav& t, bool has, StepCounters& sc) {
   static_assert(!(INST && STAGED), "LDS-staged trees have no instance levels");
   constexpr int kS = stack_lds<STAGED, INST>();
-  constexpr bool kSlotOrder = ANY && !STAGED;  // RENDER_SPEC 4.4c
+  constexpr bool kSlotOrder = ANY;  // RENDER_SPEC 4.4c
   RT_LDS u32x2* stack = lds.stack + threadIdx.x;
   const RayPre& r = t.r;
   HitRec& best = t.best;
@@ -299,7 +299,7 @@ RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, 
       asm("v_and_or_b32 %0, %1, -4, %2" : "=v"(kc) : "v"(__float_as_uint(tn)), "v"((uint32_t)c | inner_bit));
       key[c] = hit ? kc : kMissKey;
     }
-    // Any-hit rays on large trees (kSlotOrder, RENDER_SPEC 4.4c): nothing they find moves their limit, so no order of the children saves
+    // Any-hit rays (kSlotOrder, RENDER_SPEC 4.4c): nothing they find moves their limit, so no order of the children saves
     // them a visit that another order would not have cost, and a child that passed the slab test never needs a second look: they take
     // the children in slot order, without sort and without keys (45 of the ~290 vector instructions of a node step).  All other rays:
     // leaves first, nearest first, then the inner children, nearest first, then the misses.
@@ -350,8 +350,11 @@ RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, 
     // triangle pair costs one packed test), nearest first
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      if (!lf[k]) break;
-      if (!(key_tn(key[k]) <= best.t)) break;  // small trees (§4.4b): a hit in a nearer leaf culls the leaves behind it (sorted: all of them)
+      if (kSlotOrder) { if (!lf[k]) continue; }  // any-hit: the leaves that were hit, in slot order, until a triangle is accepted
+      else {
+        if (!lf[k]) break;
+        if (!(key_tn(key[k]) <= best.t)) break;  // small trees (§4.4b): a hit in a nearer leaf culls the leaves behind it (sorted: all of them)
+      }
       if (COUNT) {
         sc.tris += ((ref[k] >> 28) & 7u) + 1u;
         const unsigned long long m = __ballot(1);  // the lanes inside this copy of the leaf test

@@ -531,7 +531,7 @@ static inline bool traverse4(const Node4* nodes, const Tri* tris, bool small_tre
   uint32_t cur = 0;
   RayPre r = r_world;
   uint32_t gid_base = 0;
-  const bool slot_order = ANY && !small_tree;
+  const bool slot_order = ANY;
   for (;;) {
     const Node4& n = nodes[cur];
     if (c) c->nodes++;
@@ -555,7 +555,7 @@ static inline bool traverse4(const Node4* nodes, const Tri* tris, bool small_tre
       e[ci].key = hit ? ((f_bits(tn) & ~3u) | (uint32_t)ci) : 0xffffffffu;
       e[ci].ref = n.ref[ci];
     }
-    // RENDER_SPEC 4.4c: an any-hit ray on a large tree takes the children in slot order — nothing it finds moves its limit, so no order
+    // RENDER_SPEC 4.4c: an any-hit ray takes the children in slot order — nothing it finds moves its limit, so no order
     // spares it a visit, and a child that passed the slab test is never looked at again; every other ray: nearest first
     if (!slot_order) std::sort(e, e + 4, [](const Entry& a, const Entry& b) { return a.key < b.key; });  // keys of hits are distinct (slot bits)
     for (int i = 0; i < 4; ++i) innerish[i] = !(e[i].ref & 0x80000000u) || (refs && is_inst_leaf(e[i].ref));
