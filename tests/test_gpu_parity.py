@@ -294,6 +294,29 @@ def test_empty_and_ragged_batches(halart, oracle):
     r.close()
 
 
+@pytest.mark.parametrize("scene_name", ["cornell", "blob"])
+def test_rays_with_odd_limits(halart, oracle, scene_name):
+    """tmax = NaN / negative / +inf / 0 and negative tmin on a caller's batch, closest and any hit, on an LDS-staged tree and on a large one:
+    a NaN or negative limit admits no hit (the kernels' leaf bookkeeping compares the BITS of the limit: trav_begin turns NaN into -1), +inf
+    is an ordinary limit, a negative tmin starts at the origin (RENDER_SPEC 4.2)"""
+    s = scenes.cornell_box() if scene_name == "cornell" else scenes.bunny_class(subdivisions=4)
+    r = make_renderer(halart, s, 16, 16)
+    osc = oracle.OracleScene(s)
+    mn, mx = osc.bounds()
+    rays = random_rays(512, mn, mx, 77)
+    limits = np.array([np.nan, -1.0, np.inf, 0.0, -0.0, 1e-30, 3e38, -np.inf], dtype=np.float32)
+    rays["tmax"] = limits[np.arange(512) % len(limits)]
+    rays["tmin"] = np.where(np.arange(512) % 3 == 0, np.float32(-5.0), np.float32(0.0))
+    for mode in (0, 1):
+        got, want = r.trace_rays_host(rays, mode), osc.trace(rays, mode)
+        assert got.tobytes() == want.tobytes()
+        dead = ~(rays["tmax"] > 0)  # NaN, negatives, zeros
+        assert np.all(got["prim"][dead] == 0xFFFFFFFF) and np.all(got["t"][dead] == -1.0)
+        if mode == 0:
+            assert np.any(got["prim"][~dead] != 0xFFFFFFFF)
+    r.close()
+
+
 def test_rtprog_trace_rays_and_indirect(halart, oracle):
     """HalaRayTracingProgram mirror (src/raytracing_program.rs:330-340) over device buffers"""
     import torch
