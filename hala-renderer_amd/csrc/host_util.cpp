@@ -274,7 +274,7 @@ static std::string load_hdr(FILE* f, HostImage* img) {
 }
 
 // ---- OpenEXR, scanline and single-level tiled images (the `image` crate's "exr" feature, Cargo.toml:21): compression NONE / RLE /
-// ZIPS / ZIP, HALF / FLOAT / UINT samples, channels R G B [A] or Y; mip / rip-mapped tiles, deep, multi-part and PIZ/PXR24/B44/DWA
+// ZIPS / ZIP / PIZ, HALF / FLOAT / UINT samples, channels R G B [A] or Y; mip / rip-mapped tiles, deep, multi-part and PXR24 / B44 / DWA
 // files are refused ----
 static float half_to_float(uint16_t h) {
   const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, exp = (h >> 10) & 0x1fu, man = h & 0x3ffu;
@@ -291,6 +291,186 @@ static float half_to_float(uint16_t h) {
   float f; memcpy(&f, &bits, 4);
   return f;
 }
+// ---- PIZ (OpenEXR compression 4): 16-bit samples -> range compaction through a bitmap of the values in use -> 2D Haar-like wavelet per
+// channel (14-bit variant when the compacted range allows it, else the modulo-2^16 variant) -> canonical Huffman code over the 65 536 + 1
+// symbols (the extra one: "repeat the previous symbol n times").  Restated from the published format (OpenEXR's ImfPizCompressor / ImfHuf /
+// ImfWav, v2 file layout); the reference reads such files through the `image` crate's exr support.  No PIZ file written by another
+// implementation was available to check against (tests round-trip through an encoder written from the same description): parity unpinned.
+namespace {
+struct PizBits {  // most significant bit first
+  const unsigned char* p; const unsigned char* end;
+  uint64_t c = 0; int lc = 0;
+  bool get(int n, uint32_t* out) {
+    while (lc < n) { if (p >= end) return false; c = (c << 8) | *p++; lc += 8; }
+    lc -= n;
+    *out = (uint32_t)((c >> lc) & ((1ull << n) - 1ull));
+    return true;
+  }
+};
+constexpr uint32_t kHufSymbols = 65537u;  // 16-bit values + the run symbol
+constexpr int kHufMaxLen = 58;
+// the Huffman part of a PIZ block: [im, iM, table bytes (unused), nBits, reserved] (five little-endian 32-bit words), the packed code lengths of
+// symbols im..iM (6 bits each; 59..62 = a run of 2..5 zero lengths, 63 + 8 bits = a run of 6..261), then nBits of code
+const char* piz_huf_decode(const unsigned char* in, size_t n_in, uint16_t* out, size_t n_out) {
+  if (n_in == 0) return n_out == 0 ? nullptr : "not enough Huffman data";
+  if (n_in < 20) return "truncated Huffman header";
+  auto rd = [&](size_t at) { uint32_t v; memcpy(&v, in + at, 4); return v; };
+  const uint32_t im = rd(0), iM = rd(4), n_bits = rd(12);
+  if (im >= kHufSymbols || iM >= kHufSymbols || im > iM) return "bad Huffman symbol range";
+  std::vector<unsigned char> len(kHufSymbols, 0);
+  PizBits tb{in + 20, in + n_in};
+  for (uint32_t k = im; k <= iM; ++k) {
+    uint32_t l;
+    if (!tb.get(6, &l)) return "truncated Huffman table";
+    if (l == 63u) {
+      uint32_t z;
+      if (!tb.get(8, &z)) return "truncated Huffman table";
+      z += 6u;
+      if (k + z > iM + 1u) return "bad zero run in the Huffman table";
+      k += z - 1u;
+    } else if (l >= 59u) {
+      const uint32_t z = l - 59u + 2u;
+      if (k + z > iM + 1u) return "bad zero run in the Huffman table";
+      k += z - 1u;
+    } else len[k] = (unsigned char)l;
+  }
+  // canonical codes: the codes of one length are consecutive numbers in symbol order; the first code of length l follows from the counts of
+  // the longer lengths
+  uint64_t count[kHufMaxLen + 1] = {0}, first[kHufMaxLen + 1] = {0};
+  for (uint32_t k = im; k <= iM; ++k) count[len[k]]++;
+  { uint64_t c = 0; for (int l = kHufMaxLen; l > 0; --l) { const uint64_t nc = (c + count[l]) >> 1; first[l] = c; c = nc; } }
+  std::vector<uint32_t> start(kHufMaxLen + 2, 0), sym;  // symbols sorted by (length, index)
+  for (int l = 1; l <= kHufMaxLen; ++l) start[l + 1] = start[l] + (uint32_t)count[l];
+  sym.resize(start[kHufMaxLen + 1]);
+  { std::vector<uint32_t> fill(start.begin(), start.end()); for (uint32_t k = im; k <= iM; ++k) if (len[k]) sym[fill[len[k]]++] = k; }
+  const unsigned char* data = tb.p;  // the table ends on a byte boundary of its own reader
+  const size_t avail = (size_t)(in + n_in - data);
+  if ((uint64_t)n_bits > (uint64_t)avail * 8u) return "bad Huffman bit count";
+  PizBits db{data, data + (n_bits + 7u) / 8u};
+  uint64_t left = n_bits;
+  size_t o = 0;
+  const uint32_t run_symbol = iM;
+  while (o < n_out) {
+    uint64_t v = 0;
+    int l = 0;
+    uint32_t s = kHufSymbols;
+    while (l < kHufMaxLen) {
+      uint32_t bit;
+      if (left == 0 || !db.get(1, &bit)) return "not enough Huffman data";
+      --left;
+      v = (v << 1) | bit; ++l;
+      if (count[l] && v >= first[l] && v - first[l] < count[l]) { s = sym[start[l] + (uint32_t)(v - first[l])]; break; }
+    }
+    if (s == kHufSymbols) return "bad Huffman code";
+    if (s == run_symbol) {
+      uint32_t n;
+      if (left < 8 || !db.get(8, &n)) return "not enough Huffman data";
+      left -= 8;
+      if (o == 0 || o + n > n_out) return "bad run in the Huffman data";
+      const uint16_t prev = out[o - 1];
+      for (uint32_t k = 0; k < n; ++k) out[o++] = prev;
+    } else out[o++] = (uint16_t)s;
+  }
+  return nullptr;
+}
+// inverse of the two-point transforms: 14-bit data (average / difference in signed 16-bit arithmetic), 16-bit data (modulo 2^16)
+inline void piz_wdec14(uint16_t l, uint16_t h, uint16_t* a, uint16_t* b) {
+  const int ls = (int16_t)l, hs = (int16_t)h;
+  const int ai = ls + (hs & 1) + (hs >> 1);
+  *a = (uint16_t)(int16_t)ai; *b = (uint16_t)(int16_t)(ai - hs);
+}
+inline void piz_wdec16(uint16_t l, uint16_t h, uint16_t* a, uint16_t* b) {
+  const int m = l, d = h;
+  const int bb = (m - (d >> 1)) & 0xffff;
+  const int aa = (d + bb - 0x8000) & 0xffff;
+  *b = (uint16_t)bb; *a = (uint16_t)aa;
+}
+void piz_wav2_decode(uint16_t* in, int nx, int ox, int ny, int oy, uint16_t mx) {
+  const bool w14 = mx < (1u << 14);
+  const int n = nx > ny ? ny : nx;
+  int p = 1, p2;
+  while (p <= n) p <<= 1;
+  p >>= 1; p2 = p; p >>= 1;
+  while (p >= 1) {
+    uint16_t* py = in;
+    uint16_t* const ey = in + (ptrdiff_t)oy * (ny - p2);
+    const ptrdiff_t oy1 = (ptrdiff_t)oy * p, oy2 = (ptrdiff_t)oy * p2, ox1 = (ptrdiff_t)ox * p, ox2 = (ptrdiff_t)ox * p2;
+    uint16_t i00, i01, i10, i11;
+    for (; py <= ey; py += oy2) {
+      uint16_t* px = py;
+      uint16_t* const ex = py + (ptrdiff_t)ox * (nx - p2);
+      for (; px <= ex; px += ox2) {
+        uint16_t* const p01 = px + ox1; uint16_t* const p10 = px + oy1; uint16_t* const p11 = p10 + ox1;
+        if (w14) { piz_wdec14(*px, *p10, &i00, &i10); piz_wdec14(*p01, *p11, &i01, &i11); piz_wdec14(i00, i01, px, p01); piz_wdec14(i10, i11, p10, p11); }
+        else { piz_wdec16(*px, *p10, &i00, &i10); piz_wdec16(*p01, *p11, &i01, &i11); piz_wdec16(i00, i01, px, p01); piz_wdec16(i10, i11, p10, p11); }
+      }
+      if (nx & p) {  // a last column without a right neighbour
+        uint16_t* const p10 = px + oy1;
+        if (w14) piz_wdec14(*px, *p10, &i00, p10); else piz_wdec16(*px, *p10, &i00, p10);
+        *px = i00;
+      }
+    }
+    if (ny & p) {  // a last row without a lower neighbour
+      uint16_t* px = py;
+      uint16_t* const ex = py + (ptrdiff_t)ox * (nx - p2);
+      for (; px <= ex; px += ox2) {
+        uint16_t* const p01 = px + ox1;
+        if (w14) piz_wdec14(*px, *p01, &i00, p01); else piz_wdec16(*px, *p01, &i00, p01);
+        *px = i00;
+      }
+    }
+    p2 = p; p >>= 1;
+  }
+}
+// one PIZ block -> the bytes of its lines in the uncompressed layout (line after line, channel after channel within a line).
+// types[k]: 0 UINT, 1 HALF, 2 FLOAT (32-bit samples travel as two 16-bit halves side by side)
+const char* piz_decode(const unsigned char* src, size_t size, uint32_t cols, uint32_t lines, const std::vector<int>& types, std::vector<unsigned char>* raw) {
+  struct Chan { size_t start; uint32_t halves; };
+  std::vector<Chan> ch(types.size());
+  size_t total = 0;
+  for (size_t k = 0; k < types.size(); ++k) { ch[k].start = total; ch[k].halves = types[k] == 1 ? 1u : 2u; total += (size_t)cols * lines * ch[k].halves; }
+  if (size < 4) return "truncated PIZ block";
+  uint16_t min_nz, max_nz;
+  memcpy(&min_nz, src, 2); memcpy(&max_nz, src + 2, 2);
+  size_t p = 4;
+  std::vector<unsigned char> bitmap(8192, 0);
+  if (max_nz >= 8192) return "bad PIZ bitmap range";
+  if (min_nz <= max_nz) {
+    const size_t n = (size_t)max_nz - min_nz + 1;
+    if (p + n > size) return "truncated PIZ bitmap";
+    memcpy(&bitmap[min_nz], src + p, n);
+    p += n;
+  }
+  std::vector<uint16_t> lut(65536, 0);
+  uint32_t k = 0;
+  for (uint32_t i = 0; i < 65536u; ++i)
+    if (i == 0 || (bitmap[i >> 3] & (1u << (i & 7u)))) lut[k++] = (uint16_t)i;
+  const uint16_t max_value = (uint16_t)(k - 1u);
+  if (p + 4 > size) return "truncated PIZ block";
+  uint32_t huf_len;
+  memcpy(&huf_len, src + p, 4);
+  p += 4;
+  if ((size_t)huf_len > size - p) return "bad PIZ Huffman length";
+  std::vector<uint16_t> tmp(total);
+  if (const char* e = piz_huf_decode(src + p, huf_len, tmp.data(), total)) return e;
+  for (size_t c = 0; c < ch.size(); ++c)
+    for (uint32_t j = 0; j < ch[c].halves; ++j)
+      piz_wav2_decode(tmp.data() + ch[c].start + j, (int)cols, (int)ch[c].halves, (int)lines, (int)(cols * ch[c].halves), max_value);
+  for (uint16_t& v : tmp) v = lut[v];
+  raw->resize(total * 2);
+  size_t o = 0;
+  std::vector<size_t> at(ch.size());
+  for (size_t c = 0; c < ch.size(); ++c) at[c] = ch[c].start;
+  for (uint32_t y = 0; y < lines; ++y)
+    for (size_t c = 0; c < ch.size(); ++c) {
+      const size_t n = (size_t)cols * ch[c].halves;
+      memcpy(raw->data() + o, tmp.data() + at[c], n * 2);
+      at[c] += n; o += n * 2;
+    }
+  return nullptr;
+}
+}  // namespace
+
 static std::string load_exr(FILE* f, HostImage* img) {
   std::vector<unsigned char> d;
   { unsigned char buf[65536]; size_t n; while ((n = fread(buf, 1, sizeof(buf), f)) > 0) d.insert(d.end(), buf, buf + n); }
@@ -337,7 +517,7 @@ static std::string load_exr(FILE* f, HostImage* img) {
     p += size;
   }
   if (chans.empty() || win[2] < win[0] || win[3] < win[1]) return "missing channels or data window";
-  if (compression < 0 || compression > 3) return "only NONE / RLE / ZIPS / ZIP compressed OpenEXR files are supported";
+  if (compression < 0 || compression > 4) return "only NONE / RLE / ZIPS / ZIP / PIZ compressed OpenEXR files are supported";
   (void)line_order;  // chunks carry their own y; the offset table is not needed
   if ((int64_t)win[2] - win[0] >= (1 << 20) || (int64_t)win[3] - win[1] >= (1 << 20)) return "data window too large";
   const uint32_t W = (uint32_t)(win[2] - win[0] + 1), H = (uint32_t)(win[3] - win[1] + 1);
@@ -356,7 +536,7 @@ static std::string load_exr(FILE* f, HostImage* img) {
   if (ci[0] < 0 || ci[1] < 0 || ci[2] < 0) return "no R, G, B (or Y) channels";
   if (tiled && (tile_w == 0 || tile_h == 0 || tile_w > (1u << 16) || tile_h > (1u << 16))) return "bad tile description";
   if (tiled && (tile_mode & 0x0fu) != 0u) return "mip-mapped and rip-mapped tiled OpenEXR files are not supported";
-  const uint32_t block = compression == 3 ? 16u : 1u;
+  const uint32_t block = compression == 3 ? 16u : (compression == 4 ? 32u : 1u);
   const uint32_t tiles_x = tiled ? (W + tile_w - 1) / tile_w : 1u, tiles_y = tiled ? (H + tile_h - 1) / tile_h : 0u;
   const uint32_t chunks = tiled ? tiles_x * tiles_y : (H + block - 1) / block;
   if ((size_t)chunks * 8 > d.size()) return "truncated offset table";
@@ -392,7 +572,11 @@ static std::string load_exr(FILE* f, HostImage* img) {
     for (size_t k = 0; k < chans.size(); ++k) { coff[k] = chunk_line; chunk_line += (size_t)cols * (chans[k].type == 1 ? 2 : 4); }
     const size_t want = chunk_line * lines;
     if (compression == 0 || size == want) raw.assign(d.begin() + p, d.begin() + p + size);
-    else {
+    else if (compression == 4) {
+      std::vector<int> types(chans.size());
+      for (size_t k = 0; k < chans.size(); ++k) types[k] = chans[k].type;
+      if (const char* e = piz_decode(&d[p], size, cols, lines, types, &raw)) return e;
+    } else {
       tmp.resize(want);
       if (compression == 1) {  // RLE
         size_t o = 0, q = p;

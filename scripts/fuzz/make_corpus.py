@@ -123,17 +123,17 @@ for b0 in seeds:
         d = json.loads(json.dumps(doc)); d["images"][0] = {"uri": "data:application/octet-stream;base64," + base64.b64encode(b).decode()}
         json.dump(d, open(os.path.join(out, "png", f"p{n:04d}.gltf"), "w")); n += 1
 
-# float images (set_envmap(path)): OpenEXR scanline + tiled in every compression, .hdr, .pfm, each with byte-level mutations
+# float images (set_envmap(path)): OpenEXR scanline + tiled in every supported compression (NONE / ZIPS / ZIP / PIZ), .hdr, .pfm, each with byte-level mutations
 from test_image_decoders import write_exr  # noqa: E402
 n = 0
 img = (rs.rand(21, 34, 4) * 3).astype(np.float32)
-variants = [dict(compression=c, half=hf, tile=t) for c in ("none", "zips", "zip") for hf in (False, True) for t in (None, (8, 8), (16, 5))]
+variants = [dict(compression=c, half=hf, tile=t) for c in ("none", "zips", "zip", "piz") for hf in (False, True) for t in (None, (8, 8), (16, 5))]
 for v in variants:
     p0 = os.path.join(out, "image", "base.exr")
     write_exr(p0, img, v["compression"], v["half"], channels="RGBA", tile=v["tile"])
     raw = open(p0, "rb").read()
-    for k in range(40):
-        open(os.path.join(out, "image", f"e{n:05d}.exr"), "wb").write(raw if k == 0 else mutate(raw, 8)); n += 1
+    for k in range(120 if v["compression"] == "piz" else 40):  # the PIZ blocks get three times the mutations: bitmap, code table, code, wavelet
+        open(os.path.join(out, "image", f"e{n:05d}.exr"), "wb").write(raw if k == 0 else mutate(raw, 8 if k % 2 else 330)); n += 1
 os.remove(os.path.join(out, "image", "base.exr"))
 hdr = b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 6 +X 9\n" + rs.randint(0, 256, 6 * 9 * 4).astype(np.uint8).tobytes()
 pfm = b"PF\n7 5\n-1.0\n" + rs.rand(5 * 7 * 3).astype(np.float32).tobytes()
