@@ -312,7 +312,7 @@ int hala_rt_set_scene(hala_rt_renderer* r, const hala_scene_desc* scene);
 /* set_envmap (src/rt_renderer.rs:1184-1195) -> EnvMap::new_with_file (src/envmap.rs:38-232).
  * _pixels takes the already decoded image (RGB or RGBA f32, row 0 = top) and applies the same
  * validation (NaN/Inf rejection :63-71), alpha := 1 repack (:72-89) and table build (:239-388);
- * _file decodes Radiance .hdr (RGBE), .pfm or OpenEXR (scanline or single-level tiled; NONE / RLE / ZIPS / ZIP; half, float) itself and honours
+ * _file decodes Radiance .hdr (RGBE), .pfm or OpenEXR (scanline or single-level tiled; NONE / RLE / ZIPS / ZIP / PIZ; half, float) itself and honours
  * ./out/<stem>.dist_cache (:90-142). */
 int hala_rt_set_envmap_pixels(hala_rt_renderer* r, const float* pixels, uint32_t channels,
                               uint32_t width, uint32_t height, float rotation_degrees);

@@ -127,7 +127,7 @@ for b0 in seeds:
 from test_image_decoders import write_exr  # noqa: E402
 n = 0
 img = (rs.rand(21, 34, 4) * 3).astype(np.float32)
-variants = [dict(compression=c, half=hf, tile=t) for c in ("none", "zips", "zip", "piz") for hf in (False, True) for t in (None, (8, 8), (16, 5))]
+variants = [dict(compression=c, half=hf, tile=t) for c in ("none", "rle", "zips", "zip", "piz") for hf in (False, True) for t in (None, (8, 8), (16, 5))]
 for v in variants:
     p0 = os.path.join(out, "image", "base.exr")
     write_exr(p0, img, v["compression"], v["half"], channels="RGBA", tile=v["tile"])

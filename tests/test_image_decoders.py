@@ -180,7 +180,7 @@ def write_exr(path, img, compression="zip", half=False, channels="RGB", data_win
     h, w, nc = img.shape
     assert nc == len(channels)
     order = sorted(range(nc), key=lambda k: channels[k])
-    comp = {"none": 0, "zips": 2, "zip": 3, "piz": 4}[compression]
+    comp = {"none": 0, "rle": 1, "zips": 2, "zip": 3, "piz": 4}[compression]
     block = 16 if comp == 3 else (32 if comp == 4 else 1)
     x0, y0 = data_window_origin
 
@@ -204,7 +204,22 @@ def write_exr(path, img, compression="zip", half=False, channels="RGB", data_win
         t = np.concatenate([a[0::2], a[1::2]]).astype(np.int32)  # interleave halves
         p = t.copy()
         p[1:] = (t[1:] - t[:-1] + 128 + 256) % 256  # predictor
-        z = zlib.compress(p.astype(np.uint8).tobytes())
+        if comp == 1:  # run-length: count byte n >= 0 -> the next byte n + 1 times; n < 0 -> -n literal bytes
+            b, z, i = p.astype(np.uint8).tobytes(), bytearray(), 0
+            while i < len(b):
+                run = 1
+                while i + run < len(b) and run < 128 and b[i + run] == b[i]:
+                    run += 1
+                if run >= 3:
+                    z += bytes([run - 1, b[i]]); i += run
+                else:
+                    j = i
+                    while j < len(b) and j - i < 127 and not (j + 2 < len(b) and b[j] == b[j + 1] == b[j + 2]):
+                        j += 1
+                    z += bytes([(256 - (j - i)) & 0xff]) + b[i:j]; i = j
+            z = bytes(z)
+        else:
+            z = zlib.compress(p.astype(np.uint8).tobytes())
         return z if len(z) < len(raw) else raw
 
     def samples(a):
@@ -244,7 +259,7 @@ def decode(path):
     return out
 
 
-@pytest.mark.parametrize("compression", ["none", "zips", "zip", "piz"])
+@pytest.mark.parametrize("compression", ["none", "rle", "zips", "zip", "piz"])
 @pytest.mark.parametrize("half", [False, True])
 def test_exr_scanline_decoding(tmp_path, compression, half):
     rng = np.random.RandomState(3)
