@@ -289,7 +289,8 @@ def main():
 
     index = 4 if (world > 1 or os.environ.get("BENCH_WORKLOAD") == "configs4") else 3
     cfg = workloads.baseline_config(index)
-    run = Run(H, cfg, local_rank, rank, world, dist, torch)
+    # BENCH_INSTANCING=1 (a probe, not used by the driver): the main workload on a two-level tree, with the per-kernel report of that form
+    run = Run(H, cfg, local_rank, rank, world, dist, torch, instancing=True if os.environ.get("BENCH_INSTANCING") else None)
     # per-launch HIP events (the roofline's avg_launch_ms) on two frames of the timed region (still live, still inside it): a timed frame
     # issues one launch per pass, the others fuse the shadow passes of a bounce with the next bounce's closest-hit pass (renderer.hip)
     # (two timed frames from 8 steps on, else exactly one: any `p` consecutive updates hold one multiple of `p`)
