@@ -254,6 +254,10 @@ RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, 
   static_assert(!(INST && STAGED), "LDS-staged trees have no instance levels");
   constexpr int kS = stack_lds<STAGED, INST>();
   constexpr bool kSlotOrder = ANY;  // RENDER_SPEC 4.4c
+#ifndef RT_INST_BATCH
+#define RT_INST_BATCH 8  // configs[3] as a two-level tree: 11.05 -> 10.88 ms per frame (4 / 8 / 12 / 16 / 24: 10.94 / 10.88 / 10.88 / 10.90 / 11.04); any-hit rays lose by waiting (their paths are short): they move at once
+#endif
+  constexpr int kInstBatch = (INST && !ANY) ? RT_INST_BATCH : 0;  // two-level trees: lanes per batch of instance transitions (0: each lane on its own, at once)
   RT_LDS u32x2* stack = lds.stack + threadIdx.x;
   const RayPre& r = t.r;
   HitRec& best = t.best;
@@ -261,7 +265,62 @@ RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, 
   uint32_t ref[4] = {kAbsent, kAbsent, kAbsent, kAbsent}, key[4] = {kMissKey, kMissKey, kMissKey, kMissKey};
   uint32_t next = kAbsent, next_key = 0;
   bool lf[4] = {false, false, false, false};  // lf[k]: the k-th sorted child is a leaf in reach (a prefix: lf[k] implies lf[k - 1])
-  if (has) {
+  auto pop = [&]() -> uint2 {
+    --sp;
+    if (sp < kS) { const u32x2 v = stack[sp * kTraverseThreads]; return make_uint2(v.x, v.y); }
+    return spill[sp - kS];
+  };
+  auto push = [&](uint32_t a, uint32_t b) {
+    if (sp < kS) stack[sp * kTraverseThreads] = u32x2{a, b}; else spill[sp - kS] = make_uint2(a, b);
+    ++sp;
+  };
+  // moving a ray into an instance's object space (RENDER_SPEC 4.5): the world-space ray is parked under an exit mark; returns the root of the primitive's tree
+  auto enter_instance = [&](uint32_t leaf) -> uint32_t {
+    const float4* ip = reinterpret_cast<const float4*>(sv.inst_refs + (leaf & 0x0fffffffu));
+    const float4 i0 = ip[0], i1 = ip[1], i2 = ip[2], i3 = ip[3];  // r0 | r1 | r2 | tr, then root, gid_base, shade_base, inst
+    push(__float_as_uint(t.r.o.x), __float_as_uint(t.r.o.y));
+    push(__float_as_uint(t.r.o.z), __float_as_uint(t.r.d.x));
+    push(__float_as_uint(t.r.d.y), __float_as_uint(t.r.d.z));
+    push(0u, kExitRef);  // key 0: never culled (parking 1 / d as well, to spare the exit its three divisions, measured no gain: 11.86 vs 11.83 ms)
+    const f3 r0 = mk3(i0.x, i0.y, i0.z), r1 = mk3(i0.w, i1.x, i1.y), r2 = mk3(i1.z, i1.w, i2.x), tr = mk3(i2.y, i2.z, i2.w);
+    const f3 tv = t.r.o - tr, d = t.r.d;
+    t.r = make_ray(mk3(dot3(r0, tv), dot3(r1, tv), dot3(r2, tv)), mk3(dot3(r0, d), dot3(r1, d), dot3(r2, d)), t.r.tmin);
+    t.gid_base = __float_as_uint(i3.y); t.shade_base = __float_as_uint(i3.z) | 0x80000000u;  // bit 31: inside an instance
+    return __float_as_uint(i3.x);
+  };
+  auto leave_instance = [&]() {  // the exit mark has been popped: the world-space ray lies under it
+    const uint2 c2 = pop(), c1 = pop(), c0 = pop();
+    t.r = make_ray(mk3(__uint_as_float(c0.x), __uint_as_float(c0.y), __uint_as_float(c1.x)),
+                   mk3(__uint_as_float(c1.y), __uint_as_float(c2.x), __uint_as_float(c2.y)), t.r.tmin);
+    t.gid_base = 0u; t.shade_base = 0u;
+  };
+  bool work = has;         // the lane visits a node in this step
+  bool done_early = false;  // INST, batched transitions: the ray ended while leaving an instance
+  if (INST && kInstBatch > 0) {
+    // Instance entries and exits are ~120 and ~45 vector instructions that a wave runs whenever ANY of its lanes needs them — 2-3 lanes
+    // in 92 % of the steps on configs[3].  With kInstBatch a lane that reaches an instance leaf, or pops an exit mark, WAITS there
+    // (t.cur = the leaf reference / kExitRef) until that many lanes of the wave wait, or none has a node to visit: the transitions then
+    // run once for all of them.  Which nodes a ray visits, and in which order, does not change.
+    const bool w_out = has && t.cur == kExitRef, w_in = has && is_inst_leaf(t.cur);
+    const unsigned long long mo = __builtin_amdgcn_ballot_w64(w_out), mi = __builtin_amdgcn_ballot_w64(w_in);
+    const unsigned long long mw = __builtin_amdgcn_ballot_w64(has && (int32_t)t.cur >= 0);
+    if ((mo | mi) != 0ull && ((uint32_t)__popcll(mo) + (uint32_t)__popcll(mi) >= (uint32_t)kInstBatch || mw == 0ull)) {
+      uint32_t c = t.cur;
+      if (w_out) {
+        leave_instance();
+        c = kAbsent;
+        while (c == kAbsent) {  // the first entry still in reach (world level: no exit mark can follow)
+          if (sp == 0) { done_early = true; break; }
+          const uint2 e = pop();
+          if (kSlotOrder || key_tn(e.x) <= best.t) c = e.y;
+        }
+      }
+      if (has && !done_early && is_inst_leaf(c)) c = enter_instance(c);
+      if (has && !done_early) t.cur = c;
+    }
+    work = has && !done_early && (int32_t)t.cur >= 0;
+  }
+  if (work) {
     float4 q0, q1, q2, q3;
     if (STAGED) { const RT_LDS f32x4* p = lds.nodes + (size_t)t.cur * 4; q0 = ld4(p); q1 = ld4(p + 1); q2 = ld4(p + 2); q3 = ld4(p + 3); }
     else { const float4* p = reinterpret_cast<const float4*>(sv.nodes) + (size_t)t.cur * 4; q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3]; }
@@ -335,7 +394,7 @@ RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, 
   // predicates of the leaf pass below are scalar work on them, the number of leaves is never formed as a vector value.  (Outside the
   // `has` block on purpose: a bool that crosses that join would be kept as a 0 / 1 byte in a register; a lane without a ray holds four
   // miss keys, 0xffffffff > 0 — slot order: four absent references.)
-  const uint32_t reach = has ? (__float_as_uint(best.t) | 3u) : 0u;
+  const uint32_t reach = work ? (__float_as_uint(best.t) | 3u) : 0u;
 #pragma unroll
   for (int k = 0; k < 4; ++k)  // a bare compare: its ballot is the compare's own lane mask
     lf[k] = !kSlotOrder ? key[k] <= reach : (INST ? (int32_t)ref[k] < (int32_t)kInstLeafTag : (int32_t)ref[k] < -1);
@@ -465,7 +524,7 @@ RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, 
         } else { best.prim = w4.x; best.t = __uint_as_float(w4.y); best.u = __uint_as_float(w4.z); best.v = __uint_as_float(w4.w); }
       }
     }
-    if (!has) return false;
+    if (!work) { if (kInstBatch > 0) t.sp = sp; return done_early; }  // no ray, or a lane that waits at an instance transition (or ended in one)
   }
   if (ANY && found) return true;  // (best.prim != kAbsent: the blocker)
   // go on with the nearest inner child if it is still in reach, else with the first stack entry that is
@@ -479,42 +538,19 @@ RT_DI bool trav_step(const SceneView& sv, const TraverseLds& lds, uint2* spill, 
       if (kSlotOrder || key_tn(e.x) <= best.t) next = e.y;
     }
   } else {
-    auto pop = [&]() -> uint2 {
-      --sp;
-      if (sp < kS) { const u32x2 v = stack[sp * kTraverseThreads]; return make_uint2(v.x, v.y); }
-      return spill[sp - kS];
-    };
-    auto push = [&](uint32_t a, uint32_t b) {
-      if (sp < kS) stack[sp * kTraverseThreads] = u32x2{a, b}; else spill[sp - kS] = make_uint2(a, b);
-      ++sp;
-    };
     for (;;) {
       if (next == kAbsent) {
         if (sp == 0) return true;
         const uint2 e = pop();
         if (e.y == kExitRef) {  // the instance's tree is done: back to the world-space ray parked under the mark
-          const uint2 c2 = pop(), c1 = pop(), c0 = pop();
-          t.r = make_ray(mk3(__uint_as_float(c0.x), __uint_as_float(c0.y), __uint_as_float(c1.x)),
-                         mk3(__uint_as_float(c1.y), __uint_as_float(c2.x), __uint_as_float(c2.y)), t.r.tmin);
-          t.gid_base = 0u; t.shade_base = 0u;
+          if (kInstBatch > 0) { next = kExitRef; break; }  // ... with the wave's next batch of transitions
+          leave_instance();
           continue;
         }
         if (kSlotOrder || key_tn(e.x) <= best.t) next = e.y;
         continue;
       }
-      if (is_inst_leaf(next)) {  // enter the instance (RENDER_SPEC 4.5)
-        const float4* ip = reinterpret_cast<const float4*>(sv.inst_refs + (next & 0x0fffffffu));
-        const float4 i0 = ip[0], i1 = ip[1], i2 = ip[2], i3 = ip[3];  // r0 | r1 | r2 | tr, then root, gid_base, shade_base, inst
-        push(__float_as_uint(t.r.o.x), __float_as_uint(t.r.o.y));
-        push(__float_as_uint(t.r.o.z), __float_as_uint(t.r.d.x));
-        push(__float_as_uint(t.r.d.y), __float_as_uint(t.r.d.z));
-        push(0u, kExitRef);  // key 0: never culled (parking 1 / d as well, to spare the exit its three divisions, measured no gain: 11.86 vs 11.83 ms)
-        const f3 r0 = mk3(i0.x, i0.y, i0.z), r1 = mk3(i0.w, i1.x, i1.y), r2 = mk3(i1.z, i1.w, i2.x), tr = mk3(i2.y, i2.z, i2.w);
-        const f3 tv = t.r.o - tr, d = t.r.d;
-        t.r = make_ray(mk3(dot3(r0, tv), dot3(r1, tv), dot3(r2, tv)), mk3(dot3(r0, d), dot3(r1, d), dot3(r2, d)), t.r.tmin);
-        t.gid_base = __float_as_uint(i3.y); t.shade_base = __float_as_uint(i3.z) | 0x80000000u;  // bit 31: inside an instance
-        next = __float_as_uint(i3.x);
-      }
+      if (kInstBatch == 0 && is_inst_leaf(next)) next = enter_instance(next);  // (batched: the lane waits at the leaf)
       break;
     }
   }
